@@ -1,0 +1,194 @@
+/* plonky2_hip.h — C ABI of libplonky2_hip.so: the MI355X (gfx950) replacement for the reference's
+ * `cuda/` crate (sideprotocol/plonky2-gpu), covering the prover hot path only:
+ * Goldilocks NTT / inverse NTT / coset LDE, Poseidon Merkle-cap construction and the
+ * PolynomialBatch commit.
+ *
+ * Two groups of entry points:
+ *   (A) the reference's own extern "C" symbols (cuda/src/lib.rs:58-145 <-> cuda/plonky2_gpu.cu),
+ *       same names, argument order and memory-layout contract, so the Rust side links unchanged;
+ *   (B) a generic-shape `gl_*` API with 64-bit sizes, explicit strides and real error returns,
+ *       which (A) is implemented on and which new host code should prefer.
+ *
+ * Conventions
+ *   - Field elements are plain-domain Goldilocks u64 (p = 2^64 - 2^32 + 1). Inputs may be any
+ *     u64 representative (field/src/goldilocks_field.rs:26); every OUTPUT buffer holds canonical
+ *     values (< p), i.e. exactly what the reference yields after `to_canonical_u64`.
+ *   - All `d_*` pointers are DEVICE pointers. The callee allocates nothing for data: the caller
+ *     owns every buffer (as in the reference, plonky2/src/fri/oracle.rs:94-106). The library keeps
+ *     a few hundred KiB of twiddle tables per device, created on first use.
+ *   - Errors are returned BY VALUE as {code, message}; code 0 = success; `message` is
+ *     malloc'ed (strdup) and owned by the caller, who frees it with free() — the convention of
+ *     cuda/src/lib.rs:21-35 / cuda/plonky2_gpu.cu:19-31.
+ *   - `ctx` points to {hipStream_t stream; hipStream_t stream2;} — the HIP twin of the reference's
+ *     CudaInnerContext (plonky2/src/fri/oracle.rs:43-47, cuda/plonky2_gpu.cu:4-7). Create one with
+ *     gl_ctx_create() or hand in your own pair of streams.
+ *   - (B) calls are ASYNCHRONOUS on ctx->stream unless stated otherwise; (A) calls synchronise
+ *     the stream before returning, like the reference (cuda/plonky2_gpu.cu:82).
+ */
+#ifndef PLONKY2_HIP_H
+#define PLONKY2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == cuda::Error (cuda/src/lib.rs:21-25) / RustError (cuda/plonky2_gpu.cu:19-31) */
+typedef struct GlError {
+    int code;      /* 0 = ok; >0 = hipError_t; <0 = library error (GL_E_*) */
+    char *message; /* NULL or strdup'ed, caller frees */
+} GlError;
+
+#define GL_E_INVALID (-1)     /* bad argument (sizes, alignment, NULL) */
+#define GL_E_UNSUPPORTED (-2) /* entry point outside the hot path of this build */
+
+/* == DataSlice (cuda/src/lib.rs:52-56): host struct holding a device pointer + i32 length */
+typedef struct GlDataSlice {
+    const void *ptr;
+    int len;
+} GlDataSlice;
+
+/* ---------------------------------------------------------------------------------------------
+ * (B) generic API
+ * ------------------------------------------------------------------------------------------- */
+
+/* Context = two HIP streams on one device (layout-compatible with CudaInnerContext). */
+int gl_device_count(void);
+void *gl_ctx_create(int device); /* NULL on failure; also makes `device` current */
+void gl_ctx_destroy(void *ctx);
+GlError gl_ctx_synchronize(void *ctx); /* waits for both streams */
+
+/* Thin device-memory helpers for hosts without a HIP binding (synchronous). */
+GlError gl_malloc(void **d_ptr, uint64_t bytes);
+GlError gl_free(void *d_ptr);
+GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx);
+GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx);
+GlError gl_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes, void *ctx);
+GlError gl_memset_zero(void *d_dst, uint64_t bytes, void *ctx);
+
+/* HIP-event timing on ctx->stream (what bench.py brackets kernels with). */
+GlError gl_event_create(void **event);
+GlError gl_event_record(void *event, void *ctx);
+GlError gl_event_elapsed_ms(float *ms, void *start_event, void *stop_event); /* syncs on stop */
+void gl_event_destroy(void *event);
+
+/* Batched NTT, in place. Polynomial i occupies d_values[i*stride .. i*stride + 2^log_n).
+ *   inverse = 0: fft_with_options(.., zero_factor None)  (field/src/fft.rs:58-66)
+ *   inverse = 1: ifft_with_options                        (field/src/fft.rs:73-103)
+ *   bit_reversed = 1 (forward only): output slot m holds the value of natural index bitrev(m),
+ *     i.e. reverse_index_bits(fft(x)) (util/src/lib.rs:188) — the Merkle leaf order.
+ * log_n <= 20 in this build. For inverse, stride must be a multiple of 2^log_n. */
+GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, int inverse,
+                     int bit_reversed, void *ctx);
+
+/* Coset low-degree extension of poly_num coefficient vectors (length 2^log_n) to
+ * 2^(log_n+rate_bits) evaluations on shift*H, BIT-REVERSED order:
+ *   d_out[i*dst_stride + m] = coset_fft_with_options(lde(coeffs_i, rate_bits), shift)[bitrev(m)]
+ * (field/src/polynomial/mod.rs:205-207, 286-299; fri/oracle.rs:979-1004 then :942-952 per column).
+ * d_out must not overlap d_coeffs. */
+GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t poly_num, uint32_t log_n,
+                           uint32_t rate_bits, uint64_t shift, uint64_t src_stride, uint64_t dst_stride, void *ctx);
+
+/* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
+GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
+
+/* MerkleTree::new (plonky2/src/hash/merkle_tree.rs:283-319) over n_leaves (power of two) leaves of
+ * leaf_len elements; leaf hash = hash_or_noop (plonk/config.rs:56-67).
+ *   _columns: d_cols[j*col_stride + i] = element j of leaf i   (the NTT's output layout)
+ *   _leaves : d_rows[i*leaf_len + j]                            (the reference's Vec<Vec<F>>)
+ * d_digests: 4*2*(n_leaves - 2^cap_height) u64, reference layout (merkle_tree.rs:46-54);
+ * d_cap: 4*2^cap_height u64. cap_height > log2(n_leaves) -> GL_E_INVALID (the reference panics). */
+GlError gl_merkle_tree_from_columns(const uint64_t *d_cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                                    uint32_t cap_height, uint64_t *d_digests, uint64_t *d_cap, void *ctx);
+GlError gl_merkle_tree_from_leaves(const uint64_t *d_rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
+                                   uint64_t *d_digests, uint64_t *d_cap, void *ctx);
+
+/* d_cols[c*col_stride + r] -> d_rows[r*n_cols + c]  (plonky2/src/util/mod.rs:23-53) */
+GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
+                     void *ctx);
+
+/* PolynomialBatch::from_coeffs (plonky2/src/fri/oracle.rs:911-977) without the host-side struct:
+ *   d_coeffs   [poly_num][2^log_n]            in
+ *   d_lde      [(poly_num+salt_size)][n_ext]  out, column-major, bit-reversed (n_ext = 2^(log_n+rate_bits));
+ *              the salt_size trailing columns are read as given (caller-provided randomness,
+ *              oracle.rs:998-1002) and take part in the leaf hash
+ *   d_leaves   [n_ext][poly_num+salt_size]    out, leaf-major (= merkle_tree.leaves); may be NULL
+ *   d_digests / d_cap as gl_merkle_tree_*.
+ * shift is F::coset_shift() = 7 in the reference (field/src/types.rs:431-433). */
+GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
+                              uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx);
+/* PolynomialBatch::from_values (oracle.rs:709-731): d_values is transformed IN PLACE into the
+ * coefficients (= PolynomialBatch.polynomials), then as gl_commit_from_coeffs. */
+GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
+                              uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * (A) the reference's extern "C" surface (cuda/src/lib.rs:58-145). Synchronous.
+ * ------------------------------------------------------------------------------------------- */
+
+/* lib.rs:59 — declared by the reference, its definition is commented out there
+ * (cuda/plonky2_gpu.cu:59-67). Here: makes device 0 current and builds the twiddle tables. */
+void init(void);
+
+/* lib.rs:61-69 / plonky2_gpu.cu:70-86. In-place inverse NTT of poly_num polynomials of
+ * values_num_per_poly = 2^log_len elements each, contiguous. root_table is accepted and ignored
+ * (twiddles are internal); n_inv is a HOST pointer and is checked against 2^-log_len. */
+GlError ifft(uint64_t *d_values_flatten, int poly_num, int values_num_per_poly, int log_len,
+             const uint64_t *d_root_table, const uint64_t *n_inv, void *ctx);
+
+/* lib.rs:100-114 / plonky2_gpu.cu:435-606. Region contract (element offsets from
+ * d_ext_values_flatten, P = poly_num, S = salt_size, n_ext = values_num_per_poly << rate_bits):
+ *   [pad .. pad + (P+S)*n_ext)          column-major bit-reversed LDE         (plonky2_gpu.cu:461)
+ *   [pad + (P+S)*n_ext .. + 4*num_digests + 4*2^cap_height)  digests || cap   (plonky2_gpu.cu:552)
+ *   [0 .. (P+S)*n_ext)                  leaf-major LDE, written last after ctx->stream2 has been
+ *                                       synchronised (plonky2_gpu.cu:586-591)
+ * with pad = pad_extvalues_len. d_values_flatten holds the coefficients [P][n] and may alias
+ * d_ext_values_flatten (plonky2/src/fri/oracle.rs:409-422 passes the same pointer).
+ * d_shift_powers / root tables are accepted and ignored; the coset shift is 7. */
+GlError merkle_tree_from_coeffs(uint64_t *d_values_flatten, uint64_t *d_ext_values_flatten, int poly_num,
+                                int values_num_per_poly, int log_len, const uint64_t *d_root_table,
+                                const uint64_t *d_root_table2, const uint64_t *d_shift_powers, int rate_bits,
+                                int salt_size, int cap_height, int pad_extvalues_len, void *ctx);
+
+/* lib.rs:83-98. The reference's definition is `assert(0)` (plonky2_gpu.cu:228); here it is the
+ * working composition ifft + merkle_tree_from_coeffs. */
+GlError merkle_tree_from_values(uint64_t *d_values_flatten, uint64_t *d_ext_values_flatten, int poly_num,
+                                int values_num_per_poly, int log_len, const uint64_t *d_root_table,
+                                const uint64_t *d_root_table2, const uint64_t *d_shift_powers, const uint64_t *n_inv,
+                                int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx);
+
+/* lib.rs:71-81 / plonky2_gpu.cu:138-189: Merkle tree over an LDE already resident at
+ * d_ext_values_flatten + pad (column-major, NATURAL order as in the reference, which bit-reverses
+ * it first): bit-reverses each column in place, then hashes and reduces as above. */
+GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly, int log_len,
+                          int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx);
+
+/* lib.rs:117-143 / plonky2_gpu.cu:609-783. The reference kernel is hard-wired to one circuit
+ * (ed25519); the table-driven replacement is the next row of the scope table.
+ * Returns GL_E_UNSUPPORTED in this build. */
+GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly,
+                               int log_len, const uint64_t *d_root_table2, const uint64_t *d_shift_inv_powers,
+                               int rate_bits, int salt_size, const GlDataSlice *zs_partial_products_commitment_leaves,
+                               const GlDataSlice *constants_sigmas_commitment_leaves, void *d_outs,
+                               void *d_quotient_polys, const GlDataSlice *points, const GlDataSlice *z_h_on_coset_evals,
+                               const GlDataSlice *z_h_on_coset_inverses, const GlDataSlice *k_is,
+                               const GlDataSlice *alphas, const GlDataSlice *betas, const GlDataSlice *gammas, void *ctx);
+
+/* The Rust wrapper falls back to this symbol when an Error carries no message
+ * (cuda/src/lib.rs:42-45). Forwards to hipGetErrorString. */
+const char *cudaGetErrorString(int code);
+
+/* Test hook: element-wise field op on device arrays (op: 0 add, 1 sub, 2 mul, 3 neg, 4 x^7,
+ * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b)); output canonical. d_b may be NULL for unary ops. */
+GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx);
+
+/* Library identification: "plonky2_hip <version> gfx950". */
+const char *gl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONKY2_HIP_H */

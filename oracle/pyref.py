@@ -106,7 +106,7 @@ def _load_constants():
     """Parse the committed data header (oracle/poseidon_constants.h)."""
     text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "poseidon_constants.h")).read()
     out = {}
-    for m in re.finditer(r"static const uint64_t (\w+)\[(\d+)\] = \{(.*?)\};", text, re.S):
+    for m in re.finditer(r"(?:static const|POSEIDON_CONST) uint64_t (\w+)\[(\d+)\] = \{(.*?)\};", text, re.S):
         out[m.group(1)] = [int(t.rstrip("UL"), 16) for t in re.findall(r"0x[0-9a-fA-F]+ULL", m.group(3))]
         assert len(out[m.group(1)]) == int(m.group(2))
     return out

@@ -1,0 +1,18 @@
+"""plonky2_gpu_amd — MI355X-native prover hot path for plonky2 (NTT/LDE, Poseidon Merkle caps,
+PolynomialBatch commit) behind the reference's extern "C" boundary.
+
+The product is the HIP library `libplonky2_hip.so` (C ABI: include/plonky2_hip.h). This package is
+the thin host-side mirror of the reference's operator interface for this path
+(`fft_with_options` / `ifft_with_options`, `MerkleTree::new/prove`,
+`PolynomialBatch::from_values/from_coeffs/get_lde_values`) used by the tests and the bench.
+Nothing here computes field arithmetic on the CPU; without the HIP library it raises.
+"""
+from ._lib import GL_E_INVALID, GL_E_UNSUPPORTED, Plonky2HipError, load  # noqa: F401
+from .device import Context, DeviceBuffer, Event  # noqa: F401
+from .fft import coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
+from .merkle_tree import MerkleTree  # noqa: F401
+from .polynomial_batch import PolynomialBatch  # noqa: F401
+
+P = 0xFFFFFFFF00000001
+COSET_SHIFT = 7  # F::coset_shift(), field/src/types.rs:431-433
+SALT_SIZE = 4  # plonky2/src/fri/oracle.rs:41

@@ -1,0 +1,100 @@
+"""ctypes binding of libplonky2_hip.so (the C ABI in include/plonky2_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplonky2_hip.so")
+
+
+class GlError(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_int), ("message", ctypes.c_void_p)]
+
+
+class GlDataSlice(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("len", ctypes.c_int)]
+
+
+class Plonky2HipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"plonky2_hip error {code}: {message}")
+        self.code = code
+
+
+GL_E_INVALID = -1
+GL_E_UNSUPPORTED = -2
+
+_vp, _u64, _u32, _i = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+
+# name -> (restype, argtypes); every symbol declared in include/plonky2_hip.h
+SIGNATURES = {
+    "gl_version": (ctypes.c_char_p, []),
+    "gl_device_count": (_i, []),
+    "gl_ctx_create": (_vp, [_i]),
+    "gl_ctx_destroy": (None, [_vp]),
+    "gl_ctx_synchronize": (GlError, [_vp]),
+    "gl_malloc": (GlError, [ctypes.POINTER(_vp), _u64]),
+    "gl_free": (GlError, [_vp]),
+    "gl_memcpy_h2d": (GlError, [_vp, _vp, _u64, _vp]),
+    "gl_memcpy_d2h": (GlError, [_vp, _vp, _u64, _vp]),
+    "gl_memcpy_d2d": (GlError, [_vp, _vp, _u64, _vp]),
+    "gl_memset_zero": (GlError, [_vp, _u64, _vp]),
+    "gl_event_create": (GlError, [ctypes.POINTER(_vp)]),
+    "gl_event_record": (GlError, [_vp, _vp]),
+    "gl_event_elapsed_ms": (GlError, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
+    "gl_event_destroy": (None, [_vp]),
+    "gl_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _i, _i, _vp]),
+    "gl_coset_lde_batch": (GlError, [_vp, _vp, _u64, _u32, _u32, _u64, _u64, _u64, _vp]),
+    "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
+    "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
+    "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),
+    "gl_transpose": (GlError, [_vp, _vp, _u32, _u64, _u64, _vp]),
+    "gl_commit_from_coeffs": (GlError, [_vp, _u64, _u32, _u32, _u32, _u32, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "gl_debug_field_op": (GlError, [_i, _vp, _vp, _vp, _u64, _vp]),
+    "gl_commit_from_values": (GlError, [_vp, _u64, _u32, _u32, _u32, _u32, _u64, _vp, _vp, _vp, _vp, _vp]),
+    # the reference's extern "C" surface (cuda/src/lib.rs:58-145)
+    "init": (None, []),
+    "ifft": (GlError, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "merkle_tree_from_coeffs": (GlError, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "merkle_tree_from_values": (GlError, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "build_merkle_tree": (GlError, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "compute_quotient_polys": (GlError, [_vp, _i, _i, _i, _vp, _vp, _i, _i] + [_vp] * 12),
+    "cudaGetErrorString": (ctypes.c_char_p, [_i]),
+}
+
+_lib = None
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+
+def load():
+    """Load the shared library (no GPU needed for loading or symbol lookup)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C plonky2_gpu_amd/csrc). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(lib, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(err):
+    """Raise if a returned GlError carries a non-zero code; frees the message like the Rust Drop."""
+    if err.code != 0:
+        msg = ctypes.string_at(err.message).decode() if err.message else load().cudaGetErrorString(err.code).decode()
+        if err.message:
+            _libc.free(err.message)
+        raise Plonky2HipError(err.code, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

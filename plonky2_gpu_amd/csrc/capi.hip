@@ -1,0 +1,445 @@
+// capi.hip — the extern "C" boundary of libplonky2_hip.so (declared in include/plonky2_hip.h).
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/plonky2_hip.h"
+#include "gl_field.cuh"
+#include "merkle.h"
+#include "ntt.h"
+
+using namespace plonky2_hip;
+
+namespace {
+
+struct Streams {  // == CudaInnerContext {stream, stream2} (plonky2/src/fri/oracle.rs:43-47)
+    hipStream_t stream;
+    hipStream_t stream2;
+};
+
+GlError ok() { return GlError{0, nullptr}; }
+
+GlError fail(int code, const std::string &msg) { return GlError{code, strdup(msg.c_str())}; }
+
+GlError hip_fail(hipError_t e, const char *what) {
+    return fail((int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+    } while (0)
+
+// Per-device table registry (twiddles are data-independent, a few hundred KiB).
+struct DeviceState {
+    bool have_tables = false;
+    NttTables tables;
+    std::vector<CosetTables> cosets;
+};
+std::mutex g_mu;
+DeviceState g_dev[64];
+
+hipError_t get_tables(const NttTables **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (!st.have_tables) {
+        e = ntt_tables_create(&st.tables);
+        if (e != hipSuccess) return e;
+        st.have_tables = true;
+    }
+    *out = &st.tables;
+    return hipSuccess;
+}
+
+hipError_t get_coset_tables(uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream, const CosetTables **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState &st = g_dev[dev & 63];
+    for (auto &c : st.cosets)
+        if (c.log_n == log_n && c.rate_bits == rate_bits && c.shift == shift) {
+            *out = &c;
+            return hipSuccess;
+        }
+    st.cosets.reserve(64);  // pointers handed out stay valid
+    if (st.cosets.size() >= 64) return hipErrorOutOfMemory;
+    CosetTables ct;
+    e = coset_tables_create(&ct, log_n, rate_bits, shift, stream);
+    if (e != hipSuccess) return e;
+    // tables are built on `stream`; other streams of this device may use them later
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    st.cosets.push_back(ct);
+    *out = &st.cosets.back();
+    return hipSuccess;
+}
+
+Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
+
+__global__ void bit_reverse_columns_kernel(uint64_t *v, uint32_t log_n, uint64_t total) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint64_t n = 1ull << log_n, i = g & (n - 1), base = g - i;
+    uint64_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
+    if (i < j) {
+        uint64_t a = v[base + i], b = v[base + j];
+        v[base + i] = b;
+        v[base + j] = a;
+    }
+}
+
+
+// Element-wise field ops, exported only so that the parity tests can drive gl_field.cuh with the
+// reference's edge operands (field/src/prime_field_testing.rs:7-17).
+template <int K>
+__device__ uint64_t pow2_case(uint64_t x, int k) {
+    if constexpr (K >= 192) {
+        return 0;
+    } else {
+        return k == K ? gl::mul_pow2<K>(x) : pow2_case<K + 1>(x, k);
+    }
+}
+
+__global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = a[i], y = b ? b[i] : 0, r = 0;
+    switch (op) {
+        case 0: r = gl::add(x, y); break;
+        case 1: r = gl::sub(x, y); break;
+        case 2: r = gl::mul(x, y); break;
+        case 3: r = gl::neg(x); break;
+        case 4: r = gl::pow7(x); break;
+        case 5: r = gl::mac(x, y, y); break;
+        case 6: r = pow2_case<0>(x, (int)(y % 192)); break;
+        case 7: r = gl::add_canonical(x, gl::canon(y)); break;
+        default: r = x; break;
+    }
+    out[i] = gl::canon(r);
+}
+
+GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
+                                uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
+                                uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, Streams *s,
+                                bool sync_stream2_before_leaves) {
+    if (!d_coeffs || !d_lde || !d_digests || !d_cap || !s) return fail(GL_E_INVALID, "null pointer");
+    if (log_n + rate_bits > 32 || cap_height > log_n + rate_bits)
+        return fail(GL_E_INVALID, "cap_height should be at most log2(leaves.len())");
+    if (poly_num + salt_size == 0 || poly_num + salt_size > 0xFFFFFFFFull) return fail(GL_E_INVALID, "bad poly_num");
+    const uint64_t n = 1ull << log_n, n_ext = n << rate_bits;
+    const NttTables *tb;
+    const CosetTables *ct;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
+    HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
+    HIP_TRY(merkle_tree_from_columns(d_lde, (uint32_t)(poly_num + salt_size), n_ext, n_ext, cap_height, d_digests, d_cap,
+                                     s->stream));
+    if (d_leaves) {
+        if (sync_stream2_before_leaves) HIP_TRY(hipStreamSynchronize(s->stream2));  // plonky2_gpu.cu:586
+        HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, (uint32_t)(poly_num + salt_size), n_ext, n_ext, s->stream));
+    }
+    return ok();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gl_version(void) { return "plonky2_hip 0.1.0 gfx950"; }
+
+int gl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void *gl_ctx_create(int device) {
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    Streams *s = (Streams *)calloc(1, sizeof(Streams));
+    if (!s) return nullptr;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess) {
+        free(s);
+        return nullptr;
+    }
+    const NttTables *tb;
+    if (get_tables(&tb) != hipSuccess) {
+        free(s);
+        return nullptr;
+    }
+    return s;
+}
+
+void gl_ctx_destroy(void *ctx) {
+    if (!ctx) return;
+    (void)hipStreamDestroy(S(ctx)->stream);
+    (void)hipStreamDestroy(S(ctx)->stream2);
+    free(ctx);
+}
+
+GlError gl_ctx_synchronize(void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream2));
+    return ok();
+}
+
+GlError gl_malloc(void **d_ptr, uint64_t bytes) {
+    if (!d_ptr) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return ok();
+}
+
+GlError gl_free(void *d_ptr) {
+    HIP_TRY(hipFree(d_ptr));
+    return ok();
+}
+
+GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(ctx)->stream));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(ctx)->stream));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_memset_zero(void *d_dst, uint64_t bytes, void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipMemsetAsync(d_dst, 0, bytes, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_event_create(void **event) {
+    if (!event) return fail(GL_E_INVALID, "null pointer");
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    *event = ev;
+    return ok();
+}
+
+GlError gl_event_record(void *event, void *ctx) {
+    if (!event || !ctx) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(hipEventRecord((hipEvent_t)event, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_event_elapsed_ms(float *ms, void *start_event, void *stop_event) {
+    if (!ms || !start_event || !stop_event) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop_event));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event));
+    return ok();
+}
+
+void gl_event_destroy(void *event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, int inverse,
+                     int bit_reversed, void *ctx) {
+    if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
+    if (log_n > 20) return fail(GL_E_INVALID, "log_n > 20 is not supported by this build");
+    if (stride < (1ull << log_n)) return fail(GL_E_INVALID, "stride smaller than the polynomial");
+    if (inverse && bit_reversed) return fail(GL_E_INVALID, "bit-reversed inverse is not on the hot path");
+    if (inverse && (stride & ((1ull << log_n) - 1))) return fail(GL_E_INVALID, "inverse needs stride % n == 0");
+    if ((stride & 1) && log_n > 0 && poly_num > 1) return fail(GL_E_INVALID, "stride must be even (16-byte accesses)");
+    if ((uintptr_t)d_values & 15) return fail(GL_E_INVALID, "d_values must be 16-byte aligned");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(ntt_batch(*tb, d_values, d_values, poly_num, log_n, stride, stride,
+                      bit_reversed ? NttOrder::BitReversed : NttOrder::Natural, inverse != 0, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t poly_num, uint32_t log_n,
+                           uint32_t rate_bits, uint64_t shift, uint64_t src_stride, uint64_t dst_stride, void *ctx) {
+    if (!ctx || ((!d_coeffs || !d_out) && poly_num)) return fail(GL_E_INVALID, "null pointer");
+    if (log_n > 20 || rate_bits > 8) return fail(GL_E_INVALID, "log_n > 20 or rate_bits > 8 not supported");
+    const uint64_t n = 1ull << log_n;
+    if (src_stride < n || dst_stride < (n << rate_bits)) return fail(GL_E_INVALID, "stride too small");
+    if (((uintptr_t)d_coeffs | (uintptr_t)d_out) & 15) return fail(GL_E_INVALID, "buffers must be 16-byte aligned");
+    if (log_n > 0 && ((src_stride | dst_stride) & 1)) return fail(GL_E_INVALID, "strides must be even");
+    const NttTables *tb;
+    const CosetTables *ct;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_coset_tables(log_n, rate_bits, shift, S(ctx)->stream, &ct));
+    HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_out, poly_num, src_stride, dst_stride, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx) {
+    if (!ctx || (!d_states && count)) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(poseidon_permute_batch(d_states, count, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_merkle_tree_from_columns(const uint64_t *d_cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                                    uint32_t cap_height, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    if (!ctx || !d_cols || !d_cap) return fail(GL_E_INVALID, "null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return fail(GL_E_INVALID, "n_leaves must be a power of two");
+    if ((1ull << cap_height) > n_leaves || cap_height > 63)
+        return fail(GL_E_INVALID, "cap_height should be at most log2(leaves.len())");
+    HIP_TRY(merkle_tree_from_columns(d_cols, leaf_len, n_leaves, col_stride, cap_height, d_digests, d_cap, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_merkle_tree_from_leaves(const uint64_t *d_rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
+                                   uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    if (!ctx || !d_rows || !d_cap) return fail(GL_E_INVALID, "null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return fail(GL_E_INVALID, "n_leaves must be a power of two");
+    if ((1ull << cap_height) > n_leaves || cap_height > 63)
+        return fail(GL_E_INVALID, "cap_height should be at most log2(leaves.len())");
+    HIP_TRY(merkle_tree_from_rows(d_rows, leaf_len, n_leaves, cap_height, d_digests, d_cap, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
+                     void *ctx) {
+    if (!ctx || !d_cols || !d_rows) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(transpose_to_leaf_major(d_cols, d_rows, n_cols, n_rows, col_stride, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
+                              uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    if (log_n > 20) return fail(GL_E_INVALID, "log_n > 20 is not supported by this build");
+    return commit_from_coeffs_impl(d_coeffs, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
+                                   d_digests, d_cap, S(ctx), false);
+}
+
+GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
+                              uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
+                              uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    GlError e = gl_ntt_batch(d_values, poly_num, log_n, 1ull << log_n, 1, 0, ctx);
+    if (e.code) return e;
+    return gl_commit_from_coeffs(d_values, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
+                                 d_digests, d_cap, ctx);
+}
+
+GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx) {
+    if (!ctx || !d_a || !d_out) return fail(GL_E_INVALID, "null pointer");
+    if (n == 0) return ok();
+    hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(ctx)->stream, op, d_a, d_b,
+                       d_out, n);
+    HIP_TRY(hipGetLastError());
+    return ok();
+}
+
+// ------------------------------------------------------------------------------------------
+// reference ABI (cuda/src/lib.rs:58-145)
+// ------------------------------------------------------------------------------------------
+
+void init(void) {
+    if (hipSetDevice(0) != hipSuccess) return;
+    const NttTables *tb;
+    (void)get_tables(&tb);
+}
+
+GlError ifft(uint64_t *d_values_flatten, int poly_num, int values_num_per_poly, int log_len,
+             const uint64_t *d_root_table, const uint64_t *n_inv, void *ctx) {
+    (void)d_root_table;
+    if (poly_num < 0 || log_len < 0 || values_num_per_poly != (1 << log_len)) return fail(GL_E_INVALID, "bad sizes");
+    if (n_inv) {
+        uint64_t expect = glh::P - ((glh::P - 1) >> log_len);
+        if (*n_inv % glh::P != expect) return fail(GL_E_INVALID, "n_inv does not equal 2^-log_len");
+    }
+    GlError e = gl_ntt_batch(d_values_flatten, (uint64_t)poly_num, (uint32_t)log_len, (uint64_t)values_num_per_poly, 1, 0, ctx);
+    if (e.code) return e;
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
+}
+
+GlError merkle_tree_from_coeffs(uint64_t *d_values_flatten, uint64_t *d_ext_values_flatten, int poly_num,
+                                int values_num_per_poly, int log_len, const uint64_t *d_root_table,
+                                const uint64_t *d_root_table2, const uint64_t *d_shift_powers, int rate_bits,
+                                int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    (void)d_root_table;
+    (void)d_root_table2;
+    (void)d_shift_powers;
+    if (poly_num <= 0 || log_len < 0 || rate_bits < 0 || salt_size < 0 || cap_height < 0 || pad_extvalues_len < 0 ||
+        values_num_per_poly != (1 << log_len))
+        return fail(GL_E_INVALID, "bad sizes");
+    if (log_len > 20) return fail(GL_E_INVALID, "log_len > 20 is not supported by this build");
+    const uint64_t n_ext = (uint64_t)values_num_per_poly << rate_bits;
+    const uint64_t ext_polys = (uint64_t)poly_num + salt_size;
+    if ((uint64_t)pad_extvalues_len < ext_polys * n_ext)
+        return fail(GL_E_INVALID, "pad_extvalues_len smaller than (poly_num+salt_size)*n_ext: regions would overlap");
+    uint64_t *region_b = d_ext_values_flatten + pad_extvalues_len;
+    uint64_t *digests = region_b + ext_polys * n_ext;
+    uint64_t num_digests = 2 * (n_ext - (1ull << cap_height));
+    GlError e = commit_from_coeffs_impl(d_values_flatten, (uint64_t)poly_num, (uint32_t)log_len, (uint32_t)rate_bits,
+                                        (uint32_t)cap_height, (uint32_t)salt_size, 7, region_b, d_ext_values_flatten,
+                                        digests, digests + 4 * num_digests, S(ctx), true);
+    if (e.code) return e;
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
+}
+
+GlError merkle_tree_from_values(uint64_t *d_values_flatten, uint64_t *d_ext_values_flatten, int poly_num,
+                                int values_num_per_poly, int log_len, const uint64_t *d_root_table,
+                                const uint64_t *d_root_table2, const uint64_t *d_shift_powers, const uint64_t *n_inv,
+                                int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    GlError e = ifft(d_values_flatten, poly_num, values_num_per_poly, log_len, d_root_table, n_inv, ctx);
+    if (e.code) return e;
+    return merkle_tree_from_coeffs(d_values_flatten, d_ext_values_flatten, poly_num, values_num_per_poly, log_len,
+                                   d_root_table, d_root_table2, d_shift_powers, rate_bits, salt_size, cap_height,
+                                   pad_extvalues_len, ctx);
+}
+
+GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly, int log_len,
+                          int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    if (!ctx || !d_ext_values_flatten) return fail(GL_E_INVALID, "null pointer");
+    if (poly_num <= 0 || log_len < 0 || rate_bits < 0 || salt_size < 0 || cap_height < 0 || pad_extvalues_len < 0 ||
+        values_num_per_poly != (1 << log_len) || cap_height > log_len + rate_bits)
+        return fail(GL_E_INVALID, "bad sizes");
+    const uint32_t log_ext = (uint32_t)(log_len + rate_bits);
+    const uint64_t n_ext = 1ull << log_ext, ext_polys = (uint64_t)poly_num + salt_size;
+    uint64_t *region_b = d_ext_values_flatten + pad_extvalues_len;
+    uint64_t *digests = region_b + ext_polys * n_ext;
+    uint64_t num_digests = 2 * (n_ext - (1ull << cap_height));
+    uint64_t total = (uint64_t)poly_num * n_ext;  // plonky2_gpu.cu:159-161: salt columns are not permuted
+    hipLaunchKernelGGL(bit_reverse_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(ctx)->stream,
+                       region_b, log_ext, total);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(merkle_tree_from_columns(region_b, (uint32_t)ext_polys, n_ext, n_ext, (uint32_t)cap_height, digests,
+                                     digests + 4 * num_digests, S(ctx)->stream));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
+}
+
+GlError compute_quotient_polys(const uint64_t *, int, int, int, const uint64_t *, const uint64_t *, int, int,
+                               const GlDataSlice *, const GlDataSlice *, void *, void *, const GlDataSlice *,
+                               const GlDataSlice *, const GlDataSlice *, const GlDataSlice *, const GlDataSlice *,
+                               const GlDataSlice *, const GlDataSlice *, void *) {
+    return fail(GL_E_UNSUPPORTED,
+                "compute_quotient_polys: the reference kernel is specialised to one circuit; the table-driven "
+                "quotient kernel is not part of this build");
+}
+
+const char *cudaGetErrorString(int code) {
+    if (code < 0) return code == GL_E_INVALID ? "plonky2_hip: invalid argument" : "plonky2_hip: unsupported";
+    return hipGetErrorString((hipError_t)code);
+}
+
+}  // extern "C"

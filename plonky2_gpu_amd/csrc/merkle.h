@@ -1,0 +1,21 @@
+// merkle.h — internal interface of the Poseidon / Merkle / transpose kernels (see merkle.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plonky2_hip {
+
+// MerkleTree::new over leaves given column-major: cols[j*col_stride + i] = element j of leaf i.
+// digests: 4*2*(n_leaves - 2^cap_height) u64 in the reference layout; cap: 4*2^cap_height u64.
+hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream);
+// Same for leaf-major rows[i*leaf_len + j].
+hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
+                                 uint64_t *digests, uint64_t *cap, hipStream_t stream);
+// states[count][12] permuted in place, canonical output.
+hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t stream);
+// cols[c*col_stride + r] -> rows[r*n_cols + c]
+hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
+                                   uint64_t col_stride, hipStream_t stream);
+
+}  // namespace plonky2_hip

@@ -1,0 +1,237 @@
+// merkle.hip — Poseidon leaf hashing, Merkle-cap construction and the leaf-major transpose.
+//
+// Replaces MerkleTree::new (plonky2/src/hash/merkle_tree.rs:283-319; fill_digests_buf :210-244,
+// fill_subtree :78-105) together with the transpose + reverse_index_bits that precede it in
+// PolynomialBatch::from_coeffs (plonky2/src/fri/oracle.rs:942-952), and the reference's
+// hash_leaves_kernel / reduce_digests_kernel / transpose_kernel
+// (cuda/plonky2_gpu_impl.cuh:349-479).
+//
+// Layout contract kept bit-for-bit: `digests` is the reference's recursive
+// "left subtree | left digest | right digest | right subtree" array (merkle_tree.rs:46-54). We do
+// not recurse: the closed form used by MerkleTree::prove (merkle_tree.rs:424-435) says the pair q
+// of layer L lives at hash index 2*((q << (L+1)) + 2^L - 1) + parity inside its cap subtree, so
+// every layer is a flat data-parallel launch over ALL cap subtrees at once (the reference's GPU
+// code uses one 256-thread block per cap entry, i.e. 16 blocks for the whole chip).
+//
+// Leaves are hashed straight from the NTT's column-major output: thread i walks the columns of
+// row i, so a wavefront reads 64 consecutive u64 (512 B) of one column per load instruction —
+// fully coalesced without materialising the leaf-major matrix first.
+#include "merkle.h"
+
+#include "poseidon.cuh"
+
+namespace plonky2_hip {
+
+namespace {
+
+struct alignas(16) u64x2 {
+    uint64_t x, y;
+};
+
+__device__ __forceinline__ void store_hash(uint64_t *dst, const uint64_t (&s)[12]) {
+    u64x2 a = {gl::canon(s[0]), gl::canon(s[1])}, b = {gl::canon(s[2]), gl::canon(s[3])};
+    reinterpret_cast<u64x2 *>(dst)[0] = a;
+    reinterpret_cast<u64x2 *>(dst)[1] = b;
+}
+
+// hash index (in units of 4 u64) of node `idx` of layer L inside a cap subtree
+__device__ __forceinline__ uint64_t digest_slot(uint64_t idx, uint32_t L) {
+    uint64_t q = idx >> 1, parity = idx & 1;
+    return 2 * ((q << (L + 1)) + (1ull << L) - 1) + parity;
+}
+
+// H::hash_or_noop on every row of a column-major matrix (plonky2/src/plonk/config.rs:56-67,
+// hash/hashing.rs:81-108). cols[j*col_stride + i] = element j of leaf i.
+__global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__restrict__ cols, uint32_t leaf_len,
+                                                          uint64_t n_leaves, uint64_t col_stride,
+                                                          uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
+                                                          uint32_t log_sub_leaves) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    if (leaf_len <= 4) {
+        // not hashed: copied, zero padded, canonicalised by store_hash (config.rs:57-63)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((uint32_t)k < leaf_len) s[k] = cols[(uint64_t)k * col_stride + i];
+    } else {
+        uint32_t j = 0;
+        for (; j + 8 <= leaf_len; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+            poseidon::permute(s);
+        }
+        if (j < leaf_len) {
+            // short last chunk overwrites only its own lanes (hashing.rs:89-92)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (j + k < leaf_len) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+            poseidon::permute(s);
+        }
+    }
+    if (log_sub_leaves == 0) {
+        store_hash(cap + 4 * i, s);
+    } else {
+        uint64_t sub = i >> log_sub_leaves, idx = i & ((1ull << log_sub_leaves) - 1);
+        uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+        store_hash(digests + 4 * (sub * sub_digests + digest_slot(idx, 0)), s);
+    }
+}
+
+// Same, for leaf-major input rows[i*leaf_len + j] (used by gl_merkle_tree_from_leaves).
+__global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restrict__ rows, uint32_t leaf_len,
+                                                        uint64_t n_leaves, uint64_t *__restrict__ digests,
+                                                        uint64_t *__restrict__ cap, uint32_t log_sub_leaves) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    const uint64_t *row = rows + i * leaf_len;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    if (leaf_len <= 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((uint32_t)k < leaf_len) s[k] = row[k];
+    } else {
+        uint32_t j = 0;
+        for (; j + 8 <= leaf_len; j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = row[j + k];
+            poseidon::permute(s);
+        }
+        if (j < leaf_len) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (j + k < leaf_len) s[k] = row[j + k];
+            poseidon::permute(s);
+        }
+    }
+    if (log_sub_leaves == 0) {
+        store_hash(cap + 4 * i, s);
+    } else {
+        uint64_t sub = i >> log_sub_leaves, idx = i & ((1ull << log_sub_leaves) - 1);
+        uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+        store_hash(digests + 4 * (sub * sub_digests + digest_slot(idx, 0)), s);
+    }
+}
+
+// One tree layer for all cap subtrees: parent = two_to_one(left, right) (hashing.rs:65-72).
+// Thread g handles pair q = g mod pairs_per_sub of subtree g / pairs_per_sub at layer L.
+__global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
+                                                         uint32_t L, uint32_t log_sub_leaves, uint64_t total_pairs) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_pairs) return;
+    uint32_t log_pairs = log_sub_leaves - L - 1;
+    uint64_t sub = g >> log_pairs, q = g & ((1ull << log_pairs) - 1);
+    uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+    uint64_t *tree = digests + 4 * sub * sub_digests;
+    const u64x2 *pair = reinterpret_cast<const u64x2 *>(tree + 4 * digest_slot(2 * q, L));
+    uint64_t s[12];
+    u64x2 a = pair[0], b = pair[1], c = pair[2], d = pair[3];
+    s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y;
+    s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
+    s[8] = s[9] = s[10] = s[11] = 0;
+    poseidon::permute(s);
+    if (log_pairs == 0)
+        store_hash(cap + 4 * sub, s);
+    else
+        store_hash(tree + 4 * digest_slot(q, L + 1), s);
+}
+
+__global__ __launch_bounds__(256) void permute_batch_kernel(uint64_t *states, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+    poseidon::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
+}
+
+// [n_cols][col_stride] column-major -> [n_rows][n_cols] leaf-major through a 64x64 LDS tile
+// (+1 pad): both the global read (along rows of a column) and the global write (along columns of
+// a row) are 512 B contiguous per wavefront.
+constexpr int TP = 64;
+__global__ __launch_bounds__(256) void transpose_kernel(const uint64_t *__restrict__ cols, uint64_t *__restrict__ rows,
+                                                        uint32_t n_cols, uint64_t n_rows, uint64_t col_stride) {
+    __shared__ uint64_t tile[TP][TP + 1];
+    uint64_t r0 = (uint64_t)blockIdx.x * TP;
+    uint32_t c0 = blockIdx.y * TP;
+    uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+    for (int k = 0; k < TP; k += 4) {
+        uint32_t c = c0 + ty + k;
+        uint64_t r = r0 + tx;
+        if (c < n_cols && r < n_rows) tile[ty + k][tx] = cols[(uint64_t)c * col_stride + r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TP; k += 4) {
+        uint64_t r = r0 + ty + k;
+        uint32_t c = c0 + tx;
+        if (c < n_cols && r < n_rows) rows[r * n_cols + c] = tile[tx][ty + k];
+    }
+}
+
+unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t log_sub_leaves, hipStream_t stream) {
+    uint64_t n_sub = n_leaves >> log_sub_leaves;
+    for (uint32_t L = 0; L < log_sub_leaves; L++) {
+        uint64_t total = n_sub << (log_sub_leaves - L - 1);
+        hipLaunchKernelGGL(tree_layer_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L,
+                           log_sub_leaves, total);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+static int log2_exact(uint64_t n) {
+    int l = 0;
+    while ((1ull << l) < n) l++;
+    return (1ull << l) == n ? l : -1;
+}
+
+hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream) {
+    int lg = log2_exact(n_leaves);
+    if (lg < 0 || (int)cap_height > lg) return hipErrorInvalidValue;
+    uint32_t log_sub = lg - cap_height;
+    hipLaunchKernelGGL(hash_leaves_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, cols, leaf_len, n_leaves,
+                       col_stride, digests, cap, log_sub);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return tree_layers(digests, cap, n_leaves, log_sub, stream);
+}
+
+hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
+                                 uint64_t *digests, uint64_t *cap, hipStream_t stream) {
+    int lg = log2_exact(n_leaves);
+    if (lg < 0 || (int)cap_height > lg) return hipErrorInvalidValue;
+    uint32_t log_sub = lg - cap_height;
+    hipLaunchKernelGGL(hash_rows_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, rows, leaf_len, n_leaves,
+                       digests, cap, log_sub);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return tree_layers(digests, cap, n_leaves, log_sub, stream);
+}
+
+hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(permute_batch_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, states, count);
+    return hipGetLastError();
+}
+
+hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
+                                   uint64_t col_stride, hipStream_t stream) {
+    if (n_cols == 0 || n_rows == 0) return hipSuccess;
+    dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, cols, rows, n_cols, n_rows, col_stride);
+    return hipGetLastError();
+}
+
+}  // namespace plonky2_hip

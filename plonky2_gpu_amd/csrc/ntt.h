@@ -1,0 +1,48 @@
+// ntt.h — internal interface of the NTT / coset-LDE planner (see ntt.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plonky2_hip {
+
+constexpr uint32_t NTT_MAX_LOG = 24;
+
+// Device-resident twiddle tables shared by every transform size (64 KiB, L2-resident):
+//   twl[e] = w_{2^24}^e, twh[e] = w_{2^12}^e, e < 4096, so w_{2^24}^x = twh[x>>12] * twl[x&4095].
+struct NttTables {
+    uint64_t *twl = nullptr;
+    uint64_t *twh = nullptr;
+};
+
+// Per-(log_n, rate_bits, shift) coset tables: s_r = shift * w_{n<<rate_bits}^r,
+//   lo[r*1024 + e] = s_r^e (e < 1024), hi[r*hi_len + e] = s_r^(1024 e) (e < hi_len = max(n/1024, 1)).
+struct CosetTables {
+    uint64_t *lo = nullptr;
+    uint64_t *hi = nullptr;
+    uint32_t hi_len = 0;
+    uint32_t log_n = 0, rate_bits = 0;
+    uint64_t shift = 0;
+};
+
+enum class NttOrder { Natural, BitReversed };
+
+hipError_t ntt_tables_create(NttTables *tb);
+void ntt_tables_destroy(NttTables *tb);
+hipError_t coset_tables_create(CosetTables *ct, uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream);
+void coset_tables_destroy(CosetTables *ct);
+
+// Forward (or inverse) NTT of n_polys polynomials of length 2^log_n; polynomial i lives at
+// src + i*src_stride and is written to dst + i*dst_stride (src == dst allowed when the strides
+// match). Natural order = fft_with_options / ifft_with_options (field/src/fft.rs:58-103);
+// BitReversed = position m holds frequency bitrev(m) (forward only).
+hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, uint64_t n_polys, uint32_t log_n,
+                     uint64_t src_stride, uint64_t dst_stride, NttOrder order, bool inverse, hipStream_t stream);
+
+// Coset low-degree extension (PolynomialCoeffs::lde + coset_fft_with_options,
+// field/src/polynomial/mod.rs:205-207, 286-299) of n_polys coefficient vectors of length 2^log_n
+// to 2^(log_n+rate_bits) evaluations on shift*H, written in BIT-REVERSED order (leaf order,
+// fri/oracle.rs:942-952): dst[i*dst_stride + m] = evaluation at natural index bitrev(m).
+hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uint64_t *coeffs, uint64_t *dst,
+                           uint64_t n_polys, uint64_t src_stride, uint64_t dst_stride, hipStream_t stream);
+
+}  // namespace plonky2_hip

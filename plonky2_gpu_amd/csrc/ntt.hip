@@ -1,0 +1,628 @@
+// ntt.hip — batched Goldilocks NTT for gfx950 (MI355X).
+//
+// What it replaces: fft_dispatch / fft_classic (field/src/fft.rs:37-50, 188-229),
+// ifft_with_options (fft.rs:73-103) and, on the reference's GPU side, ifft_kernel / fft_kernel
+// (cuda/plonky2_gpu_impl.cuh:214-257), which run one 256-thread block per whole polynomial with
+// every radix-2 stage going through global memory.
+//
+// Design (MI355X-first, not a translation):
+//  * A transform of size n = 2^lg is split into at most three "passes" (four-step /
+//    Bailey decomposition). One pass = one kernel launch in which every workgroup owns a tile of
+//    E = 8192 field elements (64 KiB of the CU's 160 KiB LDS), does an R-point sub-transform on
+//    T = E/R interleaved columns entirely in LDS + registers, and touches HBM exactly once for
+//    the load and once for the store. HBM traffic per transform is therefore
+//    16 B/element/pass (the algorithmic minimum is 16 B/element).
+//  * Inside a pass each of the 512 threads (8 wave64) keeps 16 elements in VGPRs and does a
+//    radix-16 decimation-in-frequency butterfly. The radix-16 twiddles are powers of
+//    w_64 = 2^39 (mod p), so they are shifts (gl::mul_pow2), not multiplies: only the
+//    inter-digit twiddles (one per element per digit boundary) cost a 64x64 multiply.
+//  * Global accesses are 16 B/lane. "Column" passes read/write T-element (>= 64 B) contiguous
+//    segments; "row" passes read whole contiguous rows. LDS uses a +T pad per 16T block so every
+//    radix round is bank-conflict free for ds_read_b64 (32 x 8 B slots).
+//  * Natural-order output (the fft.rs contract) is produced by the last pass writing the tile
+//    transposed (T adjacent outputs per segment); bit-reversed output (what the Merkle leaf order
+//    wants, fri/oracle.rs:942-952) falls out of running every pass in place.
+//  * The inverse transform is the forward one with the index flip i -> n-i and the n^-1 scale
+//    (fft.rs:92-101) folded into the last pass's store addresses.
+#include "ntt.h"
+
+#include <type_traits>
+
+#include "gl_field.cuh"
+
+namespace plonky2_hip {
+
+namespace {
+
+constexpr int NT = 512;            // threads per workgroup (8 wavefronts)
+constexpr int LOGE = 13;           // tile = 8192 elements
+constexpr int E = 1 << LOGE;
+constexpr int LDS_DATA = E + E / 16;  // padded tile
+
+enum : uint32_t { F_LOAD_ROWS = 1, F_STORE_ROWS = 2, F_NATURAL = 4, F_INVERSE = 8, F_COSET = 16 };
+
+struct PassParams {
+    const uint64_t *src;
+    uint64_t *dst;
+    const uint64_t *twl;  // w_{2^24}^e, e < 4096
+    const uint64_t *twh;  // w_{2^12}^e, e < 4096
+    const uint64_t *cs_hi;  // coset scale tables (F_COSET): s_r^(e<<10), per coset r
+    const uint64_t *cs_lo;  // s_r^e, e < 1024
+    uint64_t in_sa, in_sb, in_sz, in_t, in_m;
+    uint64_t out_sa, out_sb, out_sz, out_t, out_m;
+    uint64_t scale;      // multiplied into every output (1 = none)
+    uint32_t logt;       // log2 T
+    uint32_t t_limit;    // valid range of b*T + t
+    uint32_t flags;
+    uint32_t log_n;      // polynomial length (index flip for the inverse)
+    uint32_t tw_hi;      // inter-pass twiddle root = w_{2^tw_hi}
+    uint32_t cs_hi_len;  // entries per coset in cs_hi
+    uint32_t rate_bits;  // F_COSET: blockIdx.z = coset r, written to block bitrev(r)
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int brev_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t brev_rt(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+__device__ __forceinline__ uint32_t phys(uint32_t idx, uint32_t logt) { return idx + ((idx >> (4 + logt)) << logt); }
+
+// w_{2^hi}^x through the two-level table of w_{2^24}
+__device__ __forceinline__ uint64_t wpow(const PassParams &p, uint64_t x) {
+    uint32_t e = (uint32_t)(x << (24 - p.tw_hi)) & 0xFFFFFFu;
+    uint64_t h = p.twh[e >> 12];
+    uint32_t lo = e & 4095u;
+    return lo ? gl::mul(h, p.twl[lo]) : h;
+}
+
+// In-register radix-2^D DIF butterfly on v[BASE .. BASE+2^D): output slot i holds frequency
+// bitrev_D(i). Stage twiddles w_{2^(s+1)}^j = 2^(39*j*(32>>s)) are multiply-free.
+template <int D, int BASE>
+__device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
+    static_for<0, D>([&](auto S_) {
+        constexpr int s = D - 1 - decltype(S_)::value;
+        constexpr int half = 1 << s;
+        static_for<0, (1 << D) / 2>([&](auto B_) {
+            constexpr int bf = decltype(B_)::value;
+            constexpr int blk = bf / half, j = bf % half;
+            constexpr int i0 = BASE + blk * 2 * half + j, i1 = i0 + half;
+            constexpr int K = (39 * j * (32 >> s)) % 192;
+            uint64_t a = v[i0], c = v[i1];
+            v[i0] = gl::add(a, c);
+            v[i1] = gl::mul_pow2<K>(gl::sub(a, c));
+        });
+    });
+}
+
+// One radix round over the digit occupying bits [SH, SH+D) of the LDS row index m.
+template <int LOGR, int D, int SH, bool TWIDDLE>
+__device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
+                                            uint32_t b) {
+    constexpr int RD = 1 << D, G = 16 >> D;
+    const uint32_t logt = p.logt, tmask = (1u << logt) - 1;
+    const bool natural = (SH == 0) && (p.flags & F_NATURAL);
+    uint64_t v[16];
+    static_for<0, G>([&](auto G_) {
+        constexpr int g = decltype(G_)::value;
+        uint32_t gid = tid + g * NT, l = gid & tmask, rest = gid >> logt;
+        uint32_t rest_lo = rest & ((1u << SH) - 1), rest_hi = rest >> SH;
+        uint32_t mbase = (rest_hi << (SH + D)) | rest_lo;
+        static_for<0, RD>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            uint32_t idx = ((mbase | (i << SH)) << logt) + l;
+            v[g * RD + i] = data[phys(idx, logt)];
+        });
+    });
+    if (natural) __syncthreads();  // slots are permuted on write-back: everyone must have read
+    static_for<0, G>([&](auto G_) { radix_dif<D, decltype(G_)::value * RD>(v); });
+
+    if constexpr (SH > 0) {
+        // inter-digit twiddle w_{2^(SH+D)}^(low * k1), k1 = bitrev_D(i), from the LDS table of w_R
+        static_for<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            uint32_t gid = tid + g * NT, rest = gid >> logt;
+            uint32_t rest_lo = rest & ((1u << SH) - 1);
+            static_for<1, RD>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                constexpr int k1 = brev_c(i, D);
+                uint32_t e = (rest_lo * k1) << (LOGR - SH - D);
+                v[g * RD + i] = gl::mul(v[g * RD + i], tw[e]);
+            });
+        });
+    } else if constexpr (TWIDDLE) {
+        // inter-pass twiddle w_{2^tw_hi}^(L * k1), k1 = bitrev4(i)*(R/16) + kr  (G == 1, D == 4)
+        static_assert(D == 4 || !TWIDDLE, "twiddled passes end with a radix-16 round");
+        uint32_t l = tid & tmask, rest = tid >> logt;
+        uint64_t L = (uint64_t)b * (1u << logt) + l;
+        uint32_t kr = brev_rt(rest, LOGR - 4);
+        uint64_t c = wpow(p, L * kr);
+        if (p.flags & F_COSET) {
+            // fold s_r^L (coset shift power of the low index) into the chain start
+            uint32_t r = blockIdx.z;
+            uint64_t sl = gl::mul(p.cs_hi[r * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[r * 1024 + (uint32_t)(L & 1023)]);
+            c = gl::mul(c, sl);
+        }
+        uint64_t step = wpow(p, L << (LOGR - 4));
+        static_for<0, 16>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            constexpr int i = brev_c(j, 4);
+            v[i] = gl::mul(v[i], c);
+            if constexpr (j < 15) c = gl::mul(c, step);
+        });
+    }
+
+    static_for<0, G>([&](auto G_) {
+        constexpr int g = decltype(G_)::value;
+        uint32_t gid = tid + g * NT, l = gid & tmask, rest = gid >> logt;
+        uint32_t rest_lo = rest & ((1u << SH) - 1), rest_hi = rest >> SH;
+        uint32_t mbase = (rest_hi << (SH + D)) | rest_lo;
+        uint32_t kr = natural ? brev_rt(rest_hi, LOGR - D) : 0;
+        static_for<0, RD>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            uint32_t m = natural ? ((uint32_t)(brev_c(i, D) << (LOGR - D)) | kr) : (mbase | (i << SH));
+            data[phys((m << logt) + l, logt)] = v[g * RD + i];
+        });
+    });
+}
+
+template <int LOGR, int SH, bool TWIDDLE>
+__device__ __forceinline__ void radix16_rounds(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
+                                               uint32_t b) {
+    if constexpr (SH >= 0) {
+        radix_round<LOGR, 4, SH, TWIDDLE>(data, tw, p, tid, b);
+        if constexpr (SH > 0) {
+            __syncthreads();
+            radix16_rounds<LOGR, SH - 4, TWIDDLE>(data, tw, p, tid, b);
+        }
+    }
+}
+
+struct alignas(16) u64x2 {
+    uint64_t x, y;
+};
+
+__device__ __forceinline__ uint64_t flip_index(uint64_t o, uint32_t log_n) {
+    uint64_t mask = (1ull << log_n) - 1;
+    return (o & ~mask) | (((1ull << log_n) - (o & mask)) & mask);
+}
+
+template <int LOGR, bool TWIDDLE>
+__global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    uint64_t *data = lds;
+    uint64_t *tw = lds + LDS_DATA;
+    constexpr int R = 1 << LOGR;
+    const uint32_t tid = threadIdx.x, logt = p.logt, T = 1u << logt;
+    const uint32_t a = blockIdx.y, b = blockIdx.x, z = blockIdx.z;
+
+    // local twiddles w_R^e = w_4096^(e * 4096/R)
+    if constexpr (LOGR >= 5)
+        for (uint32_t e = tid; e < (uint32_t)R; e += NT) tw[e] = p.twh[e << (12 - LOGR)];
+
+    // ---- load tile -------------------------------------------------------------------------
+    const uint64_t in_base = a * p.in_sa + b * p.in_sb + z * p.in_sz;
+    const bool coset = p.flags & F_COSET;
+    if (!(p.flags & F_LOAD_ROWS)) {
+        // t contiguous: T/2 lanes x 16 B per row segment
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t c = tid + it * NT;
+            uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+            u64x2 val = {0, 0};
+            if (b * T + t < p.t_limit) val = *reinterpret_cast<const u64x2 *>(p.src + in_base + t + (uint64_t)m * p.in_m);
+            if (coset) {
+                // input scale (s_r^N2)^m = s_r^(m * in_m): in_m is a multiple of 1024 or the
+                // two-level split below is still exact because exponents add.
+                uint64_t ex = (uint64_t)m * p.in_m;
+                uint64_t sc = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(ex >> 10)], p.cs_lo[z * 1024 + (uint32_t)(ex & 1023)]);
+                val.x = gl::mul(val.x, sc);
+                val.y = gl::mul(val.y, sc);
+            }
+            *reinterpret_cast<u64x2 *>(&data[phys((m << logt) + t, logt)]) = val;
+        }
+    } else {
+        // m contiguous (whole rows): lane = (t, m pair)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t c = tid + it * NT;
+            uint32_t t = c & (T - 1), m = (c >> logt) * 2;
+            u64x2 val = {0, 0};
+            if (b * T + t < p.t_limit) val = *reinterpret_cast<const u64x2 *>(p.src + in_base + (uint64_t)t * p.in_t + m);
+            data[phys((m << logt) + t, logt)] = val.x;
+            data[phys(((m + 1) << logt) + t, logt)] = val.y;
+        }
+    }
+    __syncthreads();
+
+    // ---- R-point DIF in LDS/registers ------------------------------------------------------
+    constexpr int D0 = LOGR % 4;
+    if constexpr (D0 != 0) {
+        radix_round<LOGR, D0, LOGR - D0, TWIDDLE>(data, tw, p, tid, b);
+        if constexpr (LOGR - D0 > 0) __syncthreads();
+    }
+    radix16_rounds<LOGR, LOGR - D0 - 4, TWIDDLE>(data, tw, p, tid, b);
+    __syncthreads();
+
+    // ---- store tile ------------------------------------------------------------------------
+    const uint32_t zo = coset ? brev_rt(z, p.rate_bits) : z;
+    const uint64_t out_base = a * p.out_sa + b * p.out_sb + zo * p.out_sz;
+    const bool inverse = p.flags & F_INVERSE, do_scale = p.scale != 1;
+    if (!(p.flags & F_STORE_ROWS)) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t c = tid + it * NT;
+            uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+            if (b * T + t >= p.t_limit) continue;
+            u64x2 val = *reinterpret_cast<const u64x2 *>(&data[phys((m << logt) + t, logt)]);
+            if (do_scale) {
+                val.x = gl::mul(val.x, p.scale);
+                val.y = gl::mul(val.y, p.scale);
+            }
+            val.x = gl::canon(val.x);
+            val.y = gl::canon(val.y);
+            uint64_t o = out_base + t + (uint64_t)m * p.out_m;
+            if (!inverse) {
+                *reinterpret_cast<u64x2 *>(p.dst + o) = val;
+            } else {
+                p.dst[flip_index(o, p.log_n)] = val.x;
+                p.dst[flip_index(o + 1, p.log_n)] = val.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t c = tid + it * NT;
+            uint32_t t = c & (T - 1), m = (c >> logt) * 2;
+            if (b * T + t >= p.t_limit) continue;
+            u64x2 val;
+            val.x = data[phys((m << logt) + t, logt)];
+            val.y = data[phys(((m + 1) << logt) + t, logt)];
+            if (do_scale) {
+                val.x = gl::mul(val.x, p.scale);
+                val.y = gl::mul(val.y, p.scale);
+            }
+            val.x = gl::canon(val.x);
+            val.y = gl::canon(val.y);
+            uint64_t o = out_base + (uint64_t)t * p.out_t + m;
+            if (!inverse) {
+                *reinterpret_cast<u64x2 *>(p.dst + o) = val;
+            } else {
+                p.dst[flip_index(o, p.log_n)] = val.x;
+                p.dst[flip_index(o + 1, p.log_n)] = val.y;
+            }
+        }
+    }
+}
+
+template <int LOGR, bool TWIDDLE>
+hipError_t launch_pass(const PassParams &p, dim3 grid, hipStream_t stream) {
+    size_t lds_bytes = (size_t)(LDS_DATA + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<LOGR, TWIDDLE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ntt_pass_kernel<LOGR, TWIDDLE>), grid, dim3(NT), lds_bytes, stream, p);
+    return hipGetLastError();
+}
+
+template <bool TWIDDLE>
+hipError_t dispatch_pass(int logr, const PassParams &p, dim3 grid, hipStream_t stream) {
+    switch (logr) {
+#define CASE(L) \
+    case L:     \
+        return launch_pass<L, TWIDDLE>(p, grid, stream);
+        CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+        default:
+            break;
+    }
+    if constexpr (!TWIDDLE) {
+        switch (logr) {
+            case 1: return launch_pass<1, false>(p, grid, stream);
+            case 2: return launch_pass<2, false>(p, grid, stream);
+            case 3: return launch_pass<3, false>(p, grid, stream);
+            case 11: return launch_pass<11, false>(p, grid, stream);
+            case 12: return launch_pass<12, false>(p, grid, stream);
+            default: break;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Planner
+// ---------------------------------------------------------------------------------------------
+
+static void base_params(PassParams &p, const NttTables &tb) {
+    p = PassParams{};
+    p.twl = tb.twl;
+    p.twh = tb.twh;
+    p.scale = 1;
+}
+
+hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, uint64_t n_polys, uint32_t log_n,
+                     uint64_t src_stride, uint64_t dst_stride, NttOrder order, bool inverse, hipStream_t stream) {
+    if (log_n > NTT_MAX_LOG) return hipErrorInvalidValue;
+    if (n_polys == 0) return hipSuccess;
+    const uint64_t n = 1ull << log_n;
+    if (log_n == 0) {
+        if (src != dst)
+            for (uint64_t i = 0; i < n_polys; i++) {
+                hipError_t e = hipMemcpyAsync(dst + i * dst_stride, src + i * src_stride, 8, hipMemcpyDeviceToDevice, stream);
+                if (e != hipSuccess) return e;
+            }
+        return hipSuccess;
+    }
+    const bool natural = order == NttOrder::Natural;
+    const uint64_t n_inv = inverse ? (glh::P - ((glh::P - 1) >> log_n)) : 1;  // types.rs:227-266
+    PassParams p;
+
+    if (log_n <= 12) {
+        // one pass: tile rows = T different polynomials
+        base_params(p, tb);
+        uint32_t logt = LOGE - log_n, T = 1u << logt;
+        p.src = src;
+        p.dst = dst;
+        p.logt = logt;
+        p.t_limit = (uint32_t)n_polys;
+        p.in_sb = (uint64_t)T * src_stride;
+        p.in_t = src_stride;
+        p.in_m = 1;
+        p.out_sb = (uint64_t)T * dst_stride;
+        p.out_t = dst_stride;
+        p.out_m = 1;
+        p.flags = F_LOAD_ROWS | F_STORE_ROWS | (natural ? F_NATURAL : 0) | (inverse ? F_INVERSE : 0);
+        p.log_n = log_n;
+        p.scale = n_inv;
+        if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
+        if (n_polys > 0xFFFFFFFFull) return hipErrorInvalidValue;
+        dim3 grid((unsigned)((n_polys + T - 1) / T), 1, 1);
+        return dispatch_pass<false>(log_n, p, grid, stream);
+    }
+
+    if (log_n <= 20) {
+        // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass)
+        const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+        const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
+        if (n_polys > 65535) {
+            // grid.y limit: split the batch
+            for (uint64_t off = 0; off < n_polys; off += 65535) {
+                uint64_t cnt = n_polys - off < 65535 ? n_polys - off : 65535;
+                hipError_t e = ntt_batch(tb, src + off * src_stride, dst + off * dst_stride, cnt, log_n, src_stride,
+                                         dst_stride, order, inverse, stream);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+        // pass A
+        base_params(p, tb);
+        uint32_t logtA = LOGE - la, TA = 1u << logtA;
+        p.src = src;
+        p.dst = dst;
+        p.logt = logtA;
+        p.t_limit = (uint32_t)N2;
+        p.in_sa = src_stride;
+        p.in_sb = TA;
+        p.in_t = 1;
+        p.in_m = N2;
+        p.out_sa = dst_stride;
+        p.out_sb = TA;
+        p.out_t = 1;
+        p.out_m = N2;
+        p.flags = natural ? F_NATURAL : 0;
+        p.log_n = log_n;
+        p.tw_hi = log_n;
+        hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)n_polys, 1), stream);
+        if (e != hipSuccess) return e;
+        // pass B (in place on dst)
+        base_params(p, tb);
+        uint32_t logtB = LOGE - lb, TB = 1u << logtB;
+        p.src = dst;
+        p.dst = dst;
+        p.logt = logtB;
+        p.t_limit = (uint32_t)N1;
+        p.in_sa = dst_stride;
+        p.in_sb = (uint64_t)TB * N2;
+        p.in_t = N2;
+        p.in_m = 1;
+        p.out_sa = dst_stride;
+        p.log_n = log_n;
+        p.scale = n_inv;
+        if (natural) {
+            p.out_sb = TB;
+            p.out_t = 1;
+            p.out_m = N1;
+            p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
+            if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
+        } else {
+            if (inverse) return hipErrorInvalidValue;  // bit-reversed inverse is not on the path
+            p.out_sb = (uint64_t)TB * N2;
+            p.out_t = N2;
+            p.out_m = 1;
+            p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+        }
+        return dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)n_polys, 1), stream);
+    }
+    return hipErrorInvalidValue;  // > 2^20: three-pass plan (see ntt_batch3 below)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tables
+// ---------------------------------------------------------------------------------------------
+
+hipError_t ntt_tables_create(NttTables *tb) {
+    uint64_t *h = (uint64_t *)malloc(2 * 4096 * sizeof(uint64_t));
+    if (!h) return hipErrorOutOfMemory;
+    const uint64_t w24 = glh::root_of_unity(24), w12 = glh::root_of_unity(12);
+    uint64_t a = 1, b = 1;
+    for (int e = 0; e < 4096; e++) {
+        h[e] = a;
+        h[4096 + e] = b;
+        a = glh::mul(a, w24);
+        b = glh::mul(b, w12);
+    }
+    hipError_t e = hipMalloc(&tb->twl, 2 * 4096 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        free(h);
+        return e;
+    }
+    tb->twh = tb->twl + 4096;
+    e = hipMemcpy(tb->twl, h, 2 * 4096 * sizeof(uint64_t), hipMemcpyHostToDevice);
+    free(h);
+    return e;
+}
+
+void ntt_tables_destroy(NttTables *tb) {
+    if (tb->twl) (void)hipFree(tb->twl);
+    tb->twl = tb->twh = nullptr;
+}
+
+namespace {
+__global__ void coset_tables_kernel(uint64_t *lo, uint64_t *hi, uint32_t hi_len, uint32_t n_cosets, uint64_t shift,
+                                    uint64_t w_ext) {
+    uint32_t per = 1024 + hi_len;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cosets * per) return;
+    uint32_t r = i / per, e = i % per;
+    uint64_t s = gl::mul(shift, gl::pow(w_ext, r));
+    if (e < 1024)
+        lo[r * 1024 + e] = gl::canon(gl::pow(s, e));
+    else
+        hi[r * hi_len + (e - 1024)] = gl::canon(gl::pow(s, (uint64_t)(e - 1024) << 10));
+}
+
+// dst[(poly, block q, i)] = coeffs[poly, i] * s_{bitrev(q)}^i  (small-n LDE path)
+__global__ void coset_scale_kernel(const uint64_t *coeffs, uint64_t *dst, const uint64_t *lo, const uint64_t *hi,
+                                   uint32_t hi_len, uint32_t log_n, uint32_t rate_bits, uint64_t src_stride,
+                                   uint64_t dst_stride, uint64_t total) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint64_t n = 1ull << log_n;
+    uint64_t i = g & (n - 1);
+    uint32_t q = (uint32_t)(g >> log_n) & ((1u << rate_bits) - 1);
+    uint64_t poly = g >> (log_n + rate_bits);
+    uint32_t r = rate_bits ? (__brev(q) >> (32 - rate_bits)) : 0;
+    uint64_t sc = gl::mul(hi[r * hi_len + (uint32_t)(i >> 10)], lo[r * 1024 + (uint32_t)(i & 1023)]);
+    dst[poly * dst_stride + (uint64_t)q * n + i] = gl::mul(coeffs[poly * src_stride + i], sc);
+}
+}  // namespace
+
+hipError_t coset_tables_create(CosetTables *ct, uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream) {
+    if (log_n + rate_bits > 32 || rate_bits > 8) return hipErrorInvalidValue;
+    uint32_t n_cosets = 1u << rate_bits;
+    uint32_t hi_len = log_n > 10 ? (1u << (log_n - 10)) : 1;
+    size_t total = (size_t)n_cosets * (1024 + hi_len);
+    hipError_t e = hipMalloc(&ct->lo, total * sizeof(uint64_t));
+    if (e != hipSuccess) return e;
+    ct->hi = ct->lo + (size_t)n_cosets * 1024;
+    ct->hi_len = hi_len;
+    ct->log_n = log_n;
+    ct->rate_bits = rate_bits;
+    ct->shift = shift;
+    uint64_t w_ext = glh::root_of_unity(log_n + rate_bits);
+    hipLaunchKernelGGL(coset_tables_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ct->lo, ct->hi,
+                       hi_len, n_cosets, shift % glh::P, w_ext);
+    return hipGetLastError();
+}
+
+void coset_tables_destroy(CosetTables *ct) {
+    if (ct->lo) (void)hipFree(ct->lo);
+    ct->lo = ct->hi = nullptr;
+}
+
+hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uint64_t *coeffs, uint64_t *dst,
+                           uint64_t n_polys, uint64_t src_stride, uint64_t dst_stride, hipStream_t stream) {
+    const uint32_t log_n = ct.log_n, rate_bits = ct.rate_bits;
+    const uint64_t n = 1ull << log_n, n_cosets = 1ull << rate_bits;
+    if (n_polys == 0) return hipSuccess;
+    if (log_n <= 12 || log_n > 20) {
+        if (log_n > 20) return hipErrorInvalidValue;
+        // small polynomials: scaled copies, then 2^rate_bits * n_polys in-place bit-reversed NTTs
+        uint64_t total = n_polys * n_cosets * n;
+        hipLaunchKernelGGL(coset_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, coeffs, dst,
+                           ct.lo, ct.hi, ct.hi_len, log_n, rate_bits, src_stride, dst_stride, total);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (dst_stride == n_cosets * n)
+            return ntt_batch(tb, dst, dst, n_polys * n_cosets, log_n, n, n, NttOrder::BitReversed, false, stream);
+        for (uint64_t i = 0; i < n_polys; i++) {
+            e = ntt_batch(tb, dst + i * dst_stride, dst + i * dst_stride, n_cosets, log_n, n, n, NttOrder::BitReversed,
+                          false, stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    // two-pass sizes: the coset scaling is fused into pass A (input scale (s^N2)^j1 on load,
+    // s^j2 folded into the inter-pass twiddle chain); coefficients are read once per coset from
+    // L2/Infinity Cache and each coset block is written in place by pass B.
+    const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+    const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
+    for (uint64_t off = 0; off < n_polys; off += 65535) {
+        uint64_t cnt = n_polys - off < 65535 ? n_polys - off : 65535;
+        PassParams p;
+        base_params(p, tb);
+        uint32_t logtA = LOGE - la, TA = 1u << logtA;
+        p.src = coeffs + off * src_stride;
+        p.dst = dst + off * dst_stride;
+        p.cs_hi = ct.hi;
+        p.cs_lo = ct.lo;
+        p.cs_hi_len = ct.hi_len;
+        p.rate_bits = rate_bits;
+        p.logt = logtA;
+        p.t_limit = (uint32_t)N2;
+        p.in_sa = src_stride;
+        p.in_sb = TA;
+        p.in_sz = 0;
+        p.in_t = 1;
+        p.in_m = N2;
+        p.out_sa = dst_stride;
+        p.out_sb = TA;
+        p.out_sz = n;
+        p.out_t = 1;
+        p.out_m = N2;
+        p.flags = F_COSET;
+        p.log_n = log_n;
+        p.tw_hi = log_n;
+        hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)cnt, (unsigned)n_cosets), stream);
+        if (e != hipSuccess) return e;
+        base_params(p, tb);
+        uint32_t logtB = LOGE - lb, TB = 1u << logtB;
+        p.src = dst + off * dst_stride;
+        p.dst = dst + off * dst_stride;
+        p.logt = logtB;
+        p.t_limit = (uint32_t)N1;
+        p.in_sa = dst_stride;
+        p.in_sb = (uint64_t)TB * N2;
+        p.in_sz = n;
+        p.in_t = N2;
+        p.in_m = 1;
+        p.out_sa = dst_stride;
+        p.out_sb = (uint64_t)TB * N2;
+        p.out_sz = n;
+        p.out_t = N2;
+        p.out_m = 1;
+        p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+        p.log_n = log_n;
+        e = dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)cnt, (unsigned)n_cosets), stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace plonky2_hip

@@ -1,0 +1,74 @@
+"""Host-side mirror of plonky2/src/hash/merkle_tree.rs over device-resident leaves."""
+import numpy as np
+
+from . import _lib
+from .device import DeviceBuffer
+
+
+def _log2_strict(n):
+    if n <= 0 or n & (n - 1):
+        raise ValueError("not a power of two")
+    return n.bit_length() - 1
+
+
+class MerkleTree:
+    """MerkleTree<F, PoseidonHash> (merkle_tree.rs:41-70): `digests` in the reference layout,
+    `cap` = 2^cap_height subtree roots. Leaves stay in HBM."""
+
+    def __init__(self, ctx, n_leaves, leaf_len, cap_height, digests_buf, cap_buf, leaves_buf=None):
+        self.ctx = ctx
+        self.n_leaves = n_leaves
+        self.leaf_len = leaf_len
+        self.cap_height = cap_height
+        self.d_digests = digests_buf
+        self.d_cap = cap_buf
+        self.d_leaves = leaves_buf  # leaf-major [n_leaves][leaf_len] or None
+        self._digests = None
+        self._cap = None
+
+    @classmethod
+    def new(cls, ctx, leaves, cap_height):
+        """MerkleTree::new(leaves, cap_height) (merkle_tree.rs:283-319); leaves [n_leaves, leaf_len]."""
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64)
+        n, ll = lv.shape
+        if cap_height > _log2_strict(n):
+            # the reference asserts (merkle_tree.rs:285-290)
+            raise ValueError(f"cap_height={cap_height} should be at most log2(leaves.len())={_log2_strict(n)}")
+        d_leaves = DeviceBuffer.from_host(ctx, lv)
+        d_dig = DeviceBuffer(ctx, 4 * 2 * (n - (1 << cap_height)))
+        d_cap = DeviceBuffer(ctx, 4 << cap_height)
+        _lib.call("gl_merkle_tree_from_leaves", d_leaves.ptr, ll, n, cap_height, d_dig.ptr, d_cap.ptr, ctx.ptr)
+        return cls(ctx, n, ll, cap_height, d_dig, d_cap, d_leaves)
+
+    @property
+    def digests(self):
+        if self._digests is None:
+            self._digests = self.d_digests.download(0, 4 * 2 * (self.n_leaves - (1 << self.cap_height))).reshape(-1, 4)
+        return self._digests
+
+    @property
+    def cap(self):
+        if self._cap is None:
+            self._cap = self.d_cap.download(0, 4 << self.cap_height).reshape(-1, 4)
+        return self._cap
+
+    def get(self, i):
+        """MerkleTree::get (merkle_tree.rs:385-391): leaf i, fetched from HBM."""
+        if self.d_leaves is None:
+            raise ValueError("leaf-major copy was not requested")
+        return self.d_leaves.download(i * self.leaf_len, self.leaf_len)
+
+    def prove(self, leaf_index):
+        """MerkleTree::prove (merkle_tree.rs:392-440): sibling digests from the leaf up to the cap."""
+        num_layers = _log2_strict(self.n_leaves) - self.cap_height
+        assert leaf_index >> (self.cap_height + num_layers) == 0
+        tree_len = self.digests.shape[0] >> self.cap_height
+        tree = self.digests[tree_len * (leaf_index >> num_layers) : tree_len * ((leaf_index >> num_layers) + 1)]
+        pair_index = leaf_index & ((1 << num_layers) - 1)
+        siblings = []
+        for i in range(num_layers):
+            parity = pair_index & 1
+            pair_index >>= 1
+            siblings_index = (pair_index << (i + 1)) + (1 << i) - 1
+            siblings.append(tree[2 * siblings_index + (1 - parity)])
+        return np.array(siblings, dtype=np.uint64).reshape(num_layers, 4)

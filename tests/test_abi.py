@@ -1,0 +1,64 @@
+"""CPU-side checks of the boundary: the C-ABI library builds/loads without a GPU and exports
+every symbol include/plonky2_hip.h declares; no compute is launched here."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    if not os.path.exists(os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip.so")):
+        g.build()
+    import plonky2_gpu_amd as pg
+
+    return pg.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "plonky2_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:GlError|void|int|const char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(lib):
+    from plonky2_gpu_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/plonky2_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    # the reference's FFI names (cuda/src/lib.rs:58-145) are all present
+    for n in ["init", "ifft", "build_merkle_tree", "merkle_tree_from_values", "merkle_tree_from_coeffs",
+              "compute_quotient_polys", "cudaGetErrorString"]:
+        assert n in names
+
+
+def test_version_and_error_strings(lib):
+    assert lib.gl_version().startswith(b"plonky2_hip")
+    assert b"invalid" in lib.cudaGetErrorString(-1)
+    assert b"unsupported" in lib.cudaGetErrorString(-2)
+
+
+def test_product_never_imports_oracle():
+    """③: only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "plonky2_gpu_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("fri/oracle.rs", "").replace("oracle.rs", ""), os.path.join(dirpath, f)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import plonky2_gpu_amd as pg
+
+    if lib.gl_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        pg.Context(0)

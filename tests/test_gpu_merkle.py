@@ -1,0 +1,173 @@
+"""HIP Poseidon / Merkle tree / PolynomialBatch commit vs the CPU oracle and the reference's
+known answers. Bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from gpu_util import P, gpu  # noqa: F401
+from test_oracle_poseidon import TEST_VECTORS
+
+pytestmark = pytest.mark.gpu
+
+
+def permute(gpu, states):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12)
+    buf = pg.DeviceBuffer.from_host(gpu, s)
+    _lib.call("gl_poseidon_permute_batch", buf.ptr, s.shape[0], gpu.ptr)
+    return buf.download().reshape(-1, 12)
+
+
+def test_poseidon_known_answers(gpu):
+    # plonky2/src/hash/poseidon_goldilocks.rs:286-309
+    inp = np.array([v[0] for v in TEST_VECTORS], dtype=np.uint64)
+    exp = np.array([v[1] for v in TEST_VECTORS], dtype=np.uint64)
+    assert (permute(gpu, inp) == exp).all()
+
+
+def test_poseidon_random_and_noncanonical(gpu, oracle):
+    x = oracle.random_field((1000, 12), seed=11)
+    x[0, :] = np.uint64(2**64 - 1)
+    x[1, :] = np.uint64(P)
+    x[2, ::2] = np.uint64(P + 5)
+    got = permute(gpu, x)
+    for i in range(0, 1000, 7):
+        assert (got[i] == oracle.canon(oracle.poseidon(x[i]))).all(), i
+    for i in range(3):
+        assert (got[i] == oracle.canon(oracle.poseidon(x[i]))).all(), i
+
+
+@pytest.mark.parametrize("n,k,h", [(256, 7, 1), (256, 7, 8), (256, 7, 0), (2, 5, 1), (1, 9, 0), (16, 4, 2), (16, 3, 0),
+                                   (8, 1, 1), (64, 8, 3), (64, 9, 3), (32, 16, 2), (128, 135, 4), (4096, 20, 4),
+                                   (1024, 88, 10), (512, 17, 5)])
+def test_merkle_tree_matches_oracle(gpu, oracle, n, k, h):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    leaves = oracle.random_field((n, k), seed=n * 131 + k * 7 + h)
+    leaves[0, 0] = np.uint64(2**64 - 1)  # non-canonical input
+    dig, cap = oracle.merkle_tree(leaves, h, threads=4)
+    dig, cap = oracle.canon(dig), oracle.canon(cap)
+    tree = pg.MerkleTree.new(gpu, leaves, h)
+    assert (tree.cap == cap).all()
+    assert tree.digests.shape == dig.shape and (tree.digests == dig).all()
+    # the same tree from the column-major layout the NTT produces
+    cols = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(leaves.T))
+    d2 = pg.DeviceBuffer(gpu, max(dig.size, 1))
+    c2 = pg.DeviceBuffer(gpu, cap.size)
+    _lib.call("gl_merkle_tree_from_columns", cols.ptr, k, n, n, h, d2.ptr, c2.ptr, gpu.ptr)
+    assert (c2.download().reshape(-1, 4) == cap).all()
+    assert (d2.download(0, dig.size).reshape(-1, 4) == dig).all()
+    # merkle_tree.rs:456-468: every (sampled) leaf's proof verifies against the cap
+    for i in sorted(set([0, 1, n // 2, n - 1] + list(range(0, n, max(1, n // 16))))):
+        if i < n:
+            assert oracle.merkle_verify(leaves[i], i, tree.cap, tree.prove(i))
+
+
+def test_merkle_cap_height_too_big(gpu, oracle):
+    # merkle_tree.rs:470-482 (should_panic) -> ValueError in the mirror, GL_E_INVALID at the C ABI
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    leaves = oracle.random_field((256, 7))
+    with pytest.raises(ValueError):
+        pg.MerkleTree.new(gpu, leaves, 9)
+    buf = pg.DeviceBuffer.from_host(gpu, leaves)
+    with pytest.raises(pg.Plonky2HipError) as e:
+        _lib.call("gl_merkle_tree_from_leaves", buf.ptr, 7, 256, 9, buf.ptr, buf.ptr, gpu.ptr)
+    assert e.value.code == pg.GL_E_INVALID
+
+
+@pytest.mark.parametrize("n_polys,log_n,rate_bits,h", [(5, 4, 3, 2), (135, 6, 3, 4), (3, 0, 3, 1), (20, 10, 3, 4), (2, 13, 3, 4),
+                                                       (16, 14, 1, 0), (234, 8, 3, 4), (4, 5, 3, 8), (9, 12, 2, 4)])
+def test_commit_from_values_matches_oracle(gpu, oracle, n_polys, log_n, rate_bits, h):
+    """PolynomialBatch::from_values (fri/oracle.rs:709-731): coefficients, leaf-major leaves,
+    digests and cap all equal the CPU path's."""
+    import plonky2_gpu_amd as pg
+
+    vals = oracle.random_field((n_polys, 1 << log_n), seed=n_polys * 1000 + log_n * 10 + rate_bits)
+    exp = oracle.commit_from_values(vals, rate_bits, h, threads=4)
+    batch = pg.PolynomialBatch.from_values(gpu, vals, rate_bits, False, h)
+    assert (batch.polynomials == oracle.canon(exp["coeffs"])).all()
+    assert (batch.merkle_tree.cap == oracle.canon(exp["cap"])).all()
+    assert (batch.merkle_tree.digests == oracle.canon(exp["digests"])).all()
+    leaves = batch.merkle_tree.d_leaves.download().reshape(-1, n_polys)
+    assert (leaves == oracle.canon(exp["leaves"])).all()
+    assert (batch.lde_column_major() == oracle.canon(exp["leaves"]).T).all()
+    # get_lde_values (oracle.rs:1007-1018) returns the row of the natural-order point
+    n_ext = 1 << (log_n + rate_bits)
+    for idx in (0, 1, n_ext - 1, n_ext // 3):
+        nat = oracle.canon(oracle.coset_lde(oracle.canon(exp["coeffs"])[0], rate_bits))[idx]
+        assert batch.get_lde_values(idx)[0] == nat
+    # from_coeffs on the same coefficients gives the same commitment (oracle.rs:911-977)
+    b2 = pg.PolynomialBatch.from_coeffs(gpu, batch.polynomials, rate_bits, False, h, leaf_major=False)
+    assert (b2.merkle_tree.cap == batch.merkle_tree.cap).all()
+
+
+def test_commit_with_blinding_salt(gpu, oracle):
+    """blinding appends SALT_SIZE columns to every leaf (oracle.rs:985-1002); with caller-provided
+    salt the tree equals the oracle's tree over [LDE | salt]."""
+    import plonky2_gpu_amd as pg
+
+    n_polys, log_n, rate_bits, h = 6, 5, 3, 2
+    n_ext = 1 << (log_n + rate_bits)
+    vals = oracle.random_field((n_polys, 1 << log_n), seed=9)
+    salt = oracle.random_field((4, n_ext), seed=10)
+    batch = pg.PolynomialBatch.from_values(gpu, vals, rate_bits, True, h, salt=salt)
+    exp = oracle.commit_from_values(vals, rate_bits, h)
+    leaves = np.concatenate([oracle.canon(exp["leaves"]), salt.T], axis=1)
+    dig, cap = oracle.merkle_tree(leaves, h)
+    assert (batch.merkle_tree.cap == oracle.canon(cap)).all()
+    assert (batch.merkle_tree.digests == oracle.canon(dig)).all()
+    assert (batch.merkle_tree.d_leaves.download().reshape(n_ext, -1) == leaves).all()
+    assert len(batch.get_lde_values(3)) == n_polys
+
+
+def test_reference_abi_entry_points(gpu, oracle):
+    """The drop-in symbols with the reference's region contract (cuda/plonky2_gpu.cu:435-606):
+    ext[0..] leaf-major, ext[pad..] column-major bit-reversed LDE, then digests || cap."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    P_, log_n, rate_bits, h = 20, 9, 3, 4
+    n, n_ext = 1 << log_n, 1 << (log_n + rate_bits)
+    vals = oracle.random_field((P_, n), seed=31)
+    exp = oracle.commit_from_values(vals, rate_bits, h, threads=4)
+    pad = P_ * n_ext
+    nd = 2 * (n_ext - (1 << h))
+    total = 2 * pad + 4 * nd + 4 * (1 << h)
+    ext = pg.DeviceBuffer(gpu, total)
+    ext.upload(vals, 0)  # values live at the start of the region, as in oracle.rs:352-362
+    n_inv = ctypes.c_uint64(P - ((P - 1) >> log_n))
+    _lib.call("ifft", ext.ptr, P_, n, log_n, None, ctypes.addressof(n_inv), gpu.ptr)
+    assert (ext.download(0, P_ * n).reshape(P_, n) == oracle.canon(exp["coeffs"])).all()
+    _lib.call("merkle_tree_from_coeffs", ext.ptr, ext.ptr, P_, n, log_n, None, None, None, rate_bits, 0, h, pad, gpu.ptr)
+    leaves = ext.download(0, pad).reshape(n_ext, P_)
+    assert (leaves == oracle.canon(exp["leaves"])).all()
+    colmajor = ext.download(pad, pad).reshape(P_, n_ext)
+    assert (colmajor == oracle.canon(exp["leaves"]).T).all()
+    dig = ext.download(2 * pad, 4 * nd).reshape(-1, 4)
+    cap = ext.download(2 * pad + 4 * nd, 4 << h).reshape(-1, 4)
+    assert (dig == oracle.canon(exp["digests"])).all() and (cap == oracle.canon(exp["cap"])).all()
+    # merkle_tree_from_values = ifft + merkle_tree_from_coeffs (the reference's body is assert(0))
+    ext2 = pg.DeviceBuffer(gpu, total)
+    ext2.upload(vals, 0)
+    _lib.call("merkle_tree_from_values", ext2.ptr, ext2.ptr, P_, n, log_n, None, None, None, ctypes.addressof(n_inv),
+              rate_bits, 0, h, pad, gpu.ptr)
+    assert (ext2.download(2 * pad + 4 * nd, 4 << h).reshape(-1, 4) == cap).all()
+    # build_merkle_tree: natural-order LDE resident at ext+pad -> same tree
+    ext3 = pg.DeviceBuffer(gpu, total)
+    nat = np.stack([oracle.canon(oracle.coset_lde(oracle.canon(exp["coeffs"])[i], rate_bits)) for i in range(P_)])
+    ext3.upload(nat, pad)
+    _lib.call("build_merkle_tree", ext3.ptr, P_, n, log_n, rate_bits, 0, h, pad, gpu.ptr)
+    assert (ext3.download(2 * pad + 4 * nd, 4 << h).reshape(-1, 4) == cap).all()
+    # wrong n_inv is rejected instead of silently ignored; quotient entry reports unsupported
+    bad = ctypes.c_uint64(12345)
+    with pytest.raises(pg.Plonky2HipError):
+        _lib.call("ifft", ext.ptr, P_, n, log_n, None, ctypes.addressof(bad), gpu.ptr)
+    with pytest.raises(pg.Plonky2HipError) as e:
+        _lib.call("compute_quotient_polys", None, 0, 0, 0, None, None, 0, 0, *([None] * 12))
+    assert e.value.code == pg.GL_E_UNSUPPORTED

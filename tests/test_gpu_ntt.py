@@ -1,0 +1,126 @@
+"""HIP NTT / inverse NTT / coset LDE vs the CPU oracle (field/src/fft.rs, polynomial/mod.rs).
+Integer arithmetic: every comparison is bit-exact on canonical values."""
+import numpy as np
+import pytest
+
+from gpu_util import P, bitrev_perm, gpu  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fft_rs_fixed_vector(gpu, oracle):
+    # field/src/fft.rs:252-282
+    import plonky2_gpu_amd as pg
+
+    coeffs = np.array([(i * 1337) % 100 for i in range(200)] + [0] * 56, dtype=np.uint64)
+    pts = pg.fft_with_options(gpu, coeffs)
+    assert (pts == oracle.canon(oracle.fft(coeffs))).all()
+    back = pg.ifft_with_options(gpu, pts)
+    assert (back == coeffs).all()
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 17)))
+def test_ntt_matches_oracle_small(gpu, oracle, log_n):
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    n_polys = 5 if log_n < 14 else 3
+    x = oracle.random_field((n_polys, n), seed=1000 + log_n)
+    x[0, :] = np.uint64(P - 1)  # all -1
+    if n > 1:
+        x[1, 0] = np.uint64(2**64 - 1)  # non-canonical input representative
+    exp_f = oracle.canon(oracle.fft_batch(x))
+    exp_i = oracle.canon(oracle.fft_batch(x, inverse=True))
+    got_f = pg.fft_with_options(gpu, x)
+    assert (got_f == exp_f).all()
+    got_i = pg.ifft_with_options(gpu, x)
+    assert (got_i == exp_i).all()
+    got_b = pg.fft_with_options(gpu, x, bit_reversed=True)
+    assert (got_b == exp_f[:, bitrev_perm(log_n)]).all()
+
+
+@pytest.mark.parametrize("log_n", [17, 18, 19, 20])
+def test_ntt_matches_oracle_large(gpu, oracle, log_n):
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    x = oracle.random_field((2, n), seed=2000 + log_n)
+    exp_f = oracle.canon(oracle.fft_batch(x, threads=4))
+    got_f = pg.fft_with_options(gpu, x)
+    assert (got_f == exp_f).all()
+    got_i = pg.ifft_with_options(gpu, got_f)
+    assert (got_i == x).all()  # ifft(fft(x)) == x, and x is canonical
+    got_b = pg.fft_with_options(gpu, x, bit_reversed=True)
+    assert (got_b == exp_f[:, bitrev_perm(log_n)]).all()
+
+
+def test_ntt_strided_batch_in_place(gpu, oracle):
+    """polynomials embedded with stride > n (the LDE buffer layout), others untouched."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    log_n, stride, n_polys = 10, 4096, 7
+    n = 1 << log_n
+    host = oracle.random_field((n_polys, stride), seed=5)
+    buf = pg.DeviceBuffer.from_host(gpu, host)
+    _lib.call("gl_ntt_batch", buf.ptr, n_polys, log_n, stride, 0, 0, gpu.ptr)
+    out = buf.download().reshape(n_polys, stride)
+    assert (out[:, :n] == oracle.canon(oracle.fft_batch(host[:, :n].copy()))).all()
+    assert (out[:, n:] == host[:, n:]).all()
+
+
+@pytest.mark.parametrize("log_n,rate_bits,n_polys", [(0, 3, 2), (1, 3, 3), (3, 3, 4), (6, 3, 135), (8, 1, 3), (10, 2, 2),
+                                                     (12, 3, 2), (13, 3, 3), (14, 1, 2), (16, 3, 2), (17, 0, 1)])
+def test_coset_lde_matches_oracle(gpu, oracle, log_n, rate_bits, n_polys):
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    c = oracle.random_field((n_polys, n), seed=3000 + log_n * 10 + rate_bits)
+    got = pg.coset_lde_bit_reversed(gpu, c, rate_bits)
+    perm = bitrev_perm(log_n + rate_bits)
+    for i in range(n_polys):
+        exp = oracle.canon(oracle.coset_lde(c[i], rate_bits))
+        assert (got[i] == exp[perm]).all(), i
+
+
+def test_full_size_round_trip_and_linearity(gpu, oracle):
+    """BASELINE config #2 size (2^20) through size-independent properties:
+    ifft(fft(x)) == x, fft(a*x + y) == a*fft(x) + fft(y), and oracle equality on 2 columns."""
+    import plonky2_gpu_amd as pg
+
+    log_n, n_polys = 20, 8
+    n = 1 << log_n
+    x = oracle.random_field((n_polys, n), seed=77)
+    f = pg.fft_with_options(gpu, x)
+    assert (pg.ifft_with_options(gpu, f) == x).all()
+    exp = oracle.canon(oracle.fft_batch(x[:2].copy(), threads=2))
+    assert (f[:2] == exp).all()
+    # linearity with Python ints on a strided sample of outputs
+    a = 0x123456789ABCDEF
+    z = np.array([[(a * int(u) + int(v)) % P for u, v in zip(x[0, :4096], x[1, :4096])]], dtype=np.uint64)
+    zfull = np.zeros((1, n), dtype=np.uint64)
+    zfull[0, :4096] = z
+    x0 = np.zeros((2, n), dtype=np.uint64)
+    x0[0, :4096] = x[0, :4096]
+    x0[1, :4096] = x[1, :4096]
+    fz = pg.fft_with_options(gpu, zfull)[0]
+    f0 = pg.fft_with_options(gpu, x0)
+    idx = np.arange(0, n, 4099)
+    assert [int(v) for v in fz[idx]] == [(a * int(u) + int(v)) % P for u, v in zip(f0[0, idx], f0[1, idx])]
+
+
+def test_ntt_argument_errors(gpu):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    buf = pg.DeviceBuffer(gpu, 1 << 10)
+    with pytest.raises(pg.Plonky2HipError) as e:
+        _lib.call("gl_ntt_batch", buf.ptr, 1, 21, 1 << 21, 0, 0, gpu.ptr)
+    assert e.value.code == pg.GL_E_INVALID
+    with pytest.raises(pg.Plonky2HipError):
+        _lib.call("gl_ntt_batch", buf.ptr, 1, 10, 512, 0, 0, gpu.ptr)  # stride < n
+    with pytest.raises(pg.Plonky2HipError):
+        _lib.call("gl_ntt_batch", buf.ptr, 1, 4, 16, 1, 1, gpu.ptr)  # bit-reversed inverse
+    with pytest.raises(ValueError):
+        pg.fft_with_options(gpu, np.zeros(12, dtype=np.uint64))  # not a power of two
+    _lib.call("gl_ntt_batch", buf.ptr, 0, 10, 1024, 0, 0, gpu.ptr)  # empty batch is a no-op
