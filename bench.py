@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X prover hot path.
+
+Metric (BASELINE.json): NTTs/sec at 2^20 Goldilocks.
+Workload at N=1 (BASELINE.json configs[1]): a batch of 64 independent 2^20-point columns
+(512 MiB, resident in HBM before the timed region), one step = forward NTT of the batch followed
+by the inverse NTT of the batch = 128 transforms, natural order in and out, bit-exact against
+field/src/fft.rs (checked every run on sampled columns against the CPU oracle, outside the timed
+region). Each rank owns its own batch on its own GPU: the path shards by column with no
+data-path collective, so scaling is weak and torch.distributed is only used for
+the barrier and the max-over-ranks of the elapsed time.
+
+Also reported in the same JSON line:
+  roofline      HBM roofline of the forward batch transform (the two ntt_pass_kernel launches),
+                algorithmic bytes = 16 B x 2^20 x 64 per batch transform,
+                duration from HIP events on the launch stream.
+  cpu_baseline  the C oracle (a restatement of the reference's fft_classic, "port") on this
+                host's cores, bounded sample.
+  extra         PolynomialBatch::from_values on BASELINE configs[2] (2^20 rows x 135 columns,
+                rate 8, cap 4): ms per commit and Merkle leaves hashed/s (skipped with --no-commit).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6300
+LOG_N = 20
+BATCH = 64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--no-commit", action="store_true", help="skip the configs[2] commit measurement")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--commit-cols", type=int, default=135)
+    ap.add_argument("--commit-log-n", type=int, default=20)
+    return ap.parse_args()
+
+
+class Dist:
+    """Barrier + max-reduce across ranks (gloo on CPU tensors: no data-path collective exists)."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.td = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as td
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.td, self.torch = td, torch
+
+    def barrier(self):
+        if self.td:
+            self.td.barrier()
+
+    def max(self, x):
+        if not self.td:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+    def close(self):
+        if self.td:
+            self.td.destroy_process_group()
+
+
+def cpu_baseline(log_n):
+    """The oracle's threaded fft/ifft (port of fft.rs:73-229) on a bounded sample."""
+    from oracle import oracle as o
+
+    cores = o.hardware_threads()
+    cols = max(4, min(32, cores))
+    x = o.random_field((cols, 1 << log_n), seed=7)
+    t0 = time.perf_counter()
+    f = o.fft_batch(x, inverse=False, threads=cores)
+    o.fft_batch(f, inverse=True, threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": 2 * cols / dt,
+        "unit": "NTT/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cols} columns x 2^{log_n}: forward + inverse NTT ({2 * cols} transforms) in {dt:.2f} s, "
+                  f"C restatement of fft_classic, one OpenMP task per column",
+    }
+
+
+def main():
+    args = parse()
+    dist = Dist()
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    ndev = pg.load().gl_device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    ctx = pg.Context(dist.local_rank % ndev)
+    log_n, batch = args.log_n, args.batch
+    n = 1 << log_n
+
+    # synthetic input, resident in HBM before timing (SplitMix-style seeded uniform field elements)
+    rng = np.random.Generator(np.random.PCG64(0x706C6F6E6B7932 + dist.rank))
+    host = rng.integers(0, 2**64, size=(batch, n), dtype=np.uint64)
+    host = np.where(host >= np.uint64(pg.P), host - np.uint64(pg.P), host)
+    buf = pg.DeviceBuffer.from_host(ctx, host)
+
+    def step():
+        _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 0, 0, ctx.ptr)
+        _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 1, 0, ctx.ptr)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    dist.barrier()
+    elapsed = dist.max(time.perf_counter() - t0)
+
+    # parity: after an equal number of forward/inverse transforms the batch must equal the input
+    back = buf.download().reshape(batch, n)
+    if not (back == host).all():
+        raise SystemExit("bench: ifft(fft(x)) != x — results invalid")
+
+    # forward transform timed with HIP events on the launch stream (roofline numerator: 16 B/elt)
+    reps = max(5, args.steps)
+    ev = [pg.Event() for _ in range(2 * reps)]
+    fwd_ms = []
+    for r in range(reps):
+        ev[2 * r].record(ctx)
+        _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 0, 0, ctx.ptr)
+        ev[2 * r + 1].record(ctx)
+        _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 1, 0, ctx.ptr)
+    ctx.synchronize()
+    for r in range(reps):
+        fwd_ms.append(ev[2 * r + 1].elapsed_ms_since(ev[2 * r]))
+    fwd = float(np.median(fwd_ms))
+    alg_bytes = 16.0 * n * batch
+    achieved = alg_bytes / (fwd * 1e-3) / 1e9
+
+    out = None
+    if dist.rank == 0:
+        # oracle equality on two columns of a fresh forward transform (outside the timed region)
+        from oracle import oracle as o
+
+        _lib.call("gl_ntt_batch", buf.ptr, 2, log_n, n, 0, 0, ctx.ptr)
+        got = buf.download(0, 2 * n).reshape(2, n)
+        if not (got == o.canon(o.fft_batch(host[:2].copy(), threads=2))).all():
+            raise SystemExit("bench: forward NTT differs from the oracle")
+        _lib.call("gl_ntt_batch", buf.ptr, 2, log_n, n, 1, 0, ctx.ptr)
+        ctx.synchronize()
+
+    extra = {}
+    if not args.no_commit and dist.rank == 0:
+        extra = bench_commit(pg, _lib, ctx, args.commit_cols, args.commit_log_n)
+
+    if dist.rank == 0:
+        ntts = 2 * batch * args.steps * dist.world
+        out = {
+            "metric": "NTTs/sec at 2^20 Goldilocks",
+            "value": ntts / elapsed,
+            "unit": "NTT/s",
+            "n_gpus": dist.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 (Goldilocks, integer modular)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: {batch} columns x 2^{log_n} points per GPU, forward + inverse NTT per step "
+                            f"(natural order in/out, bit-exact vs field/src/fft.rs), inputs resident in HBM",
+                "batch_columns": batch,
+                "log_n": log_n,
+                "parallelism": f"columns sharded over {dist.world} GPU(s), no collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "forward batch NTT = ntt_pass_kernel<10,true> + ntt_pass_kernel<10,false>",
+                "algorithmic_bytes_per_launch_pair": alg_bytes,
+                "ms": fwd,
+            },
+            "cpu_baseline": None if args.no_cpu else cpu_baseline(log_n),
+            "extra": extra,
+        }
+        print(json.dumps(out))
+    buf.free()
+    ctx.close()
+    dist.close()
+
+
+def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3):
+    """PolynomialBatch::from_values on configs[2]; leaf-major copy included (reference contract)."""
+    n = 1 << log_n
+    n_ext = n << rate_bits
+    rng = np.random.Generator(np.random.PCG64(99))
+    d_vals = pg.DeviceBuffer(ctx, cols * n)
+    chunk = 16
+    for c0 in range(0, cols, chunk):
+        k = min(chunk, cols - c0)
+        h = rng.integers(0, 2**64, size=(k, n), dtype=np.uint64)
+        h = np.where(h >= np.uint64(pg.P), h - np.uint64(pg.P), h)
+        d_vals.upload(h, c0 * n)
+    d_work = pg.DeviceBuffer(ctx, cols * n)
+    d_lde = pg.DeviceBuffer(ctx, cols * n_ext)
+    d_leaves = pg.DeviceBuffer(ctx, cols * n_ext)
+    d_dig = pg.DeviceBuffer(ctx, 4 * 2 * (n_ext - (1 << cap_height)))
+    d_cap = pg.DeviceBuffer(ctx, 4 << cap_height)
+    times, caps = [], []
+    for it in range(iters + 1):
+        _lib.call("gl_memcpy_d2d", d_work.ptr, d_vals.ptr, cols * n * 8, ctx.ptr)
+        ctx.synchronize()
+        e0, e1 = pg.Event(), pg.Event()
+        e0.record(ctx)
+        _lib.call("gl_commit_from_values", d_work.ptr, cols, log_n, rate_bits, cap_height, 0, 7, d_lde.ptr, d_leaves.ptr,
+                  d_dig.ptr, d_cap.ptr, ctx.ptr)
+        e1.record(ctx)
+        ctx.synchronize()
+        if it:
+            times.append(e1.elapsed_ms_since(e0))
+        caps.append(d_cap.download().tobytes())
+    assert all(c == caps[0] for c in caps), "commit is not deterministic"
+    ms = float(np.median(times))
+    alg = 8.0 * cols * n + 8.0 * cols * n_ext + 32.0 * (2 * (n_ext - (1 << cap_height)) + (1 << cap_height))
+    perms = n_ext * ((cols + 7) // 8) + n_ext - (1 << cap_height)
+    for b in (d_vals, d_work, d_lde, d_leaves, d_dig, d_cap):
+        b.free()
+    return {
+        "commit_workload": f"configs[2]: from_values {cols} cols x 2^{log_n} rows, rate 8, cap_height {cap_height}, "
+                           f"leaf-major copy included",
+        "commit_ms": ms,
+        "merkle_leaves_per_s": n_ext / (ms * 1e-3),
+        "poseidon_permutations_per_s": perms / (ms * 1e-3),
+        "commit_algorithmic_GBps": alg / (ms * 1e-3) / 1e9,
+        "commit_hbm_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "cap0": [hex(int(x)) for x in np.frombuffer(caps[0], dtype=np.uint64)[:4]],
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,11 @@
  *     u64 representative (field/src/goldilocks_field.rs:26); every OUTPUT buffer holds canonical
  *     values (< p), i.e. exactly what the reference yields after `to_canonical_u64`.
  *   - All `d_*` pointers are DEVICE pointers. The callee allocates nothing for data: the caller
- *     owns every buffer (as in the reference, plonky2/src/fri/oracle.rs:94-106). The library keeps
- *     a few hundred KiB of twiddle tables per device, created on first use.
+ *     owns every buffer (as in the reference, plonky2/src/fri/oracle.rs:94-106). The library keeps,
+ *     per device, a few hundred KiB of twiddle tables and one 128 MiB workspace for the
+ *     natural-order transforms (created by gl_ctx_create()/init() or on first use). Because that
+ *     workspace is shared, run at most one gl_ntt_batch / ifft per device at a time (the
+ *     reference's callers are single-threaded and synchronous, oracle.rs:394-422).
  *   - Errors are returned BY VALUE as {code, message}; code 0 = success; `message` is
  *     malloc'ed (strdup) and owned by the caller, who frees it with free() — the convention of
  *     cuda/src/lib.rs:21-35 / cuda/plonky2_gpu.cu:19-31.

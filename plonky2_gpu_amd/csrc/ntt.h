@@ -12,7 +12,13 @@ constexpr uint32_t NTT_MAX_LOG = 24;
 struct NttTables {
     uint64_t *twl = nullptr;
     uint64_t *twh = nullptr;
+    // Workspace for natural-order multi-pass transforms (the last pass writes transposed, so the
+    // intermediate cannot live in the caller's buffer). 128 MiB = 16 columns of 2^20: small enough
+    // to stay in the 256 MiB Infinity Cache between the two passes of a chunk.
+    uint64_t *scratch = nullptr;
+    uint64_t scratch_elems = 0;
 };
+constexpr uint64_t NTT_SCRATCH_ELEMS = 1ull << 24;
 
 // Per-(log_n, rate_bits, shift) coset tables: s_r = shift * w_{n<<rate_bits}^r,
 //   lo[r*1024 + e] = s_r^e (e < 1024), hi[r*hi_len + e] = s_r^(1024 e) (e < hi_len = max(n/1024, 1)).

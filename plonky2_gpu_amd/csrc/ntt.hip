@@ -400,64 +400,70 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass)
         const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
-        if (n_polys > 65535) {
-            // grid.y limit: split the batch
-            for (uint64_t off = 0; off < n_polys; off += 65535) {
-                uint64_t cnt = n_polys - off < 65535 ? n_polys - off : 65535;
-                hipError_t e = ntt_batch(tb, src + off * src_stride, dst + off * dst_stride, cnt, log_n, src_stride,
-                                         dst_stride, order, inverse, stream);
-                if (e != hipSuccess) return e;
-            }
-            return hipSuccess;
-        }
-        // pass A
-        base_params(p, tb);
-        uint32_t logtA = LOGE - la, TA = 1u << logtA;
-        p.src = src;
-        p.dst = dst;
-        p.logt = logtA;
-        p.t_limit = (uint32_t)N2;
-        p.in_sa = src_stride;
-        p.in_sb = TA;
-        p.in_t = 1;
-        p.in_m = N2;
-        p.out_sa = dst_stride;
-        p.out_sb = TA;
-        p.out_t = 1;
-        p.out_m = N2;
-        p.flags = natural ? F_NATURAL : 0;
-        p.log_n = log_n;
-        p.tw_hi = log_n;
-        hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)n_polys, 1), stream);
-        if (e != hipSuccess) return e;
-        // pass B (in place on dst)
-        base_params(p, tb);
-        uint32_t logtB = LOGE - lb, TB = 1u << logtB;
-        p.src = dst;
-        p.dst = dst;
-        p.logt = logtB;
-        p.t_limit = (uint32_t)N1;
-        p.in_sa = dst_stride;
-        p.in_sb = (uint64_t)TB * N2;
-        p.in_t = N2;
-        p.in_m = 1;
-        p.out_sa = dst_stride;
-        p.log_n = log_n;
-        p.scale = n_inv;
+        const uint32_t logtA = LOGE - la, TA = 1u << logtA, logtB = LOGE - lb, TB = 1u << logtB;
+        if (inverse && !natural) return hipErrorInvalidValue;  // bit-reversed inverse is not on the path
+        if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
+        // Bit-reversed order: both passes rewrite exactly the addresses they read -> in place.
+        // Natural order: pass B writes its tile transposed (k1 + N1*k2), i.e. into rows that other
+        // workgroups still have to read, so the intermediate goes through the scratch workspace,
+        // a chunk of columns at a time (the chunk's intermediate stays in L2 / Infinity Cache).
+        uint64_t chunk = 65535;
         if (natural) {
-            p.out_sb = TB;
-            p.out_t = 1;
-            p.out_m = N1;
-            p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
-            if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
-        } else {
-            if (inverse) return hipErrorInvalidValue;  // bit-reversed inverse is not on the path
-            p.out_sb = (uint64_t)TB * N2;
-            p.out_t = N2;
-            p.out_m = 1;
-            p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+            if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
+            chunk = tb.scratch_elems / n;
+            if (chunk > 65535) chunk = 65535;
         }
-        return dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)n_polys, 1), stream);
+        for (uint64_t off = 0; off < n_polys; off += chunk) {
+            const uint64_t cnt = n_polys - off < chunk ? n_polys - off : chunk;
+            uint64_t *mid = natural ? tb.scratch : dst + off * dst_stride;
+            const uint64_t mid_stride = natural ? n : dst_stride;
+            // pass A
+            base_params(p, tb);
+            p.src = src + off * src_stride;
+            p.dst = mid;
+            p.logt = logtA;
+            p.t_limit = (uint32_t)N2;
+            p.in_sa = src_stride;
+            p.in_sb = TA;
+            p.in_t = 1;
+            p.in_m = N2;
+            p.out_sa = mid_stride;
+            p.out_sb = TA;
+            p.out_t = 1;
+            p.out_m = N2;
+            p.flags = natural ? F_NATURAL : 0;
+            p.log_n = log_n;
+            p.tw_hi = log_n;
+            hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)cnt, 1), stream);
+            if (e != hipSuccess) return e;
+            // pass B
+            base_params(p, tb);
+            p.src = mid;
+            p.dst = dst + off * dst_stride;
+            p.logt = logtB;
+            p.t_limit = (uint32_t)N1;
+            p.in_sa = mid_stride;
+            p.in_sb = (uint64_t)TB * N2;
+            p.in_t = N2;
+            p.in_m = 1;
+            p.out_sa = dst_stride;
+            p.log_n = log_n;
+            p.scale = n_inv;
+            if (natural) {
+                p.out_sb = TB;
+                p.out_t = 1;
+                p.out_m = N1;
+                p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
+            } else {
+                p.out_sb = (uint64_t)TB * N2;
+                p.out_t = N2;
+                p.out_m = 1;
+                p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+            }
+            e = dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     return hipErrorInvalidValue;  // > 2^20: three-pass plan (see ntt_batch3 below)
 }
@@ -485,12 +491,15 @@ hipError_t ntt_tables_create(NttTables *tb) {
     tb->twh = tb->twl + 4096;
     e = hipMemcpy(tb->twl, h, 2 * 4096 * sizeof(uint64_t), hipMemcpyHostToDevice);
     free(h);
-    return e;
+    if (e != hipSuccess) return e;
+    tb->scratch_elems = NTT_SCRATCH_ELEMS;
+    return hipMalloc(&tb->scratch, tb->scratch_elems * sizeof(uint64_t));
 }
 
 void ntt_tables_destroy(NttTables *tb) {
     if (tb->twl) (void)hipFree(tb->twl);
-    tb->twl = tb->twh = nullptr;
+    if (tb->scratch) (void)hipFree(tb->scratch);
+    tb->twl = tb->twh = tb->scratch = nullptr;
 }
 
 namespace {

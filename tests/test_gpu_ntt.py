@@ -54,6 +54,25 @@ def test_ntt_matches_oracle_large(gpu, oracle, log_n):
     assert (got_b == exp_f[:, bitrev_perm(log_n)]).all()
 
 
+@pytest.mark.parametrize("log_n,n_polys", [(13, 1500), (14, 700), (16, 150), (20, 40)])
+def test_ntt_many_columns_more_workgroups_than_the_chip_holds(gpu, oracle, log_n, n_polys):
+    """Batches whose grid exceeds the resident workgroups (2 per CU): the natural-order last pass
+    writes transposed, so a transform that kept its intermediate in place would read rows that
+    earlier workgroups have already overwritten. Round trip + oracle equality on sampled columns."""
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    x = oracle.random_field((n_polys, n), seed=4000 + log_n)
+    f = pg.fft_with_options(gpu, x)
+    sample = sorted(set([0, 1, n_polys // 2, n_polys - 2, n_polys - 1]))
+    exp = oracle.canon(oracle.fft_batch(x[sample].copy(), threads=4))
+    assert (f[sample] == exp).all()
+    assert (pg.ifft_with_options(gpu, f) == x).all()
+    b = pg.fft_with_options(gpu, x, bit_reversed=True)
+    assert (b[sample] == exp[:, bitrev_perm(log_n)]).all()
+    assert (b[:, bitrev_perm(log_n)] == f).all()
+
+
 def test_ntt_strided_batch_in_place(gpu, oracle):
     """polynomials embedded with stride > n (the LDE buffer layout), others untouched."""
     import plonky2_gpu_amd as pg
