@@ -50,38 +50,6 @@ def parse():
     return ap.parse_args()
 
 
-class Dist:
-    """Barrier + max-reduce across ranks (gloo on CPU tensors: no data-path collective exists)."""
-
-    def __init__(self):
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.td = None
-        if self.world > 1:
-            import torch
-            import torch.distributed as td
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
-            self.td, self.torch = td, torch
-
-    def barrier(self):
-        if self.td:
-            self.td.barrier()
-
-    def max(self, x):
-        if not self.td:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
-        return float(t[0])
-
-    def close(self):
-        if self.td:
-            self.td.destroy_process_group()
-
-
 def cpu_baseline(log_n):
     """The oracle's threaded fft/ifft (port of fft.rs:73-229) on a bounded sample."""
     from oracle import oracle as o
@@ -105,8 +73,12 @@ def cpu_baseline(log_n):
 
 def main():
     args = parse()
-    dist = Dist()
     import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd.dist import ProverGroup
+
+    # barrier / max-reduce only: gloo on CPU tensors by default (no data-path collective exists);
+    # PLONKY2_DIST_BACKEND=nccl routes them over RCCL/xGMI instead.
+    dist = ProverGroup(backend=os.environ.get("PLONKY2_DIST_BACKEND", "gloo"))
     from plonky2_gpu_amd import _lib
 
     ndev = pg.load().gl_device_count()

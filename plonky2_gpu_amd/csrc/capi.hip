@@ -122,9 +122,14 @@ __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, ui
         case 5: r = gl::mac(x, y, y); break;
         case 6: r = pow2_case<0>(x, (int)(y % 192)); break;
         case 7: r = gl::add_canonical(x, gl::canon(y)); break;
+        case 8: r = gl::add_c(gl::canon_c(x), gl::canon_c(y)); break;
+        case 9: r = gl::sub_c(gl::canon_c(x), gl::canon_c(y)); break;
+        case 10: r = gl::mul_c(x, y); break;
+        case 11: r = gl::canon_c(x); break;
+        case 12: { uint64_t lo, hi; gl::mul_wide(x, y, lo, hi); r = gl::reduce128_c(lo ^ y, hi ^ x) ; } break;
         default: r = x; break;
     }
-    out[i] = gl::canon(r);
+    out[i] = (op >= 8) ? r : gl::canon(r);  // canonical-domain ops must already be canonical
 }
 
 GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,

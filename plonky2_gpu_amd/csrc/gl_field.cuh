@@ -65,6 +65,109 @@ __device__ __forceinline__ uint64_t reduce96(uint64_t lo, uint32_t hi) {
     return r + ((r < lo) ? EPS : 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Canonical-domain primitives (inputs and outputs < p), hand-scheduled carry chains.
+//
+// hipcc lowers `s < a` carry tests to v_cmp_lt_u64 + v_lshl_add_u64 (both double-pumped 64-bit
+// ops) and never uses the carry-out of v_add_co/v_addc, so the portable versions above cost
+// 15-21 lane-cycles per add/sub (measured, profiles/r01_v1_ubench.txt). These use the carry
+// flag directly: 5-7 single-rate VALU instructions. `s_nop 1` = the two wait states gfx950 needs
+// between a VALU instruction that writes VCC/SGPR and a VALU instruction that reads it as
+// carry-in or select mask (the compiler inserts the same for its own code; inside asm we must).
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// x (any u64) -> x mod p
+__device__ __forceinline__ uint64_t canon_c(uint64_t x) {
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), rl, rh;
+    asm("v_add_co_u32_e32 %0, vcc, -1, %2\n\t"       // t = x + (2^32-1): carries out iff x >= p
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %3, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %0, %2, %0, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %3, %1, vcc"
+        : "=&v"(rl), "=&v"(rh)
+        : "v"(xl), "v"(xh)
+        : "vcc");
+    return pack64(rl, rh);
+}
+
+// a, b < p  ->  (a + b) mod p, canonical
+__device__ __forceinline__ uint64_t add_c(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t sl, sh, tl, th;
+    uint64_t c1;
+    asm("v_add_co_u32_e32 %0, vcc, %5, %7\n\t"       // s = a + b, carry c1
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e64 %1, %4, %6, %8, vcc\n\t"
+        "v_add_co_u32_e32 %2, vcc, -1, %0\n\t"       // t = s - p (mod 2^64), carry c2 iff s >= p
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %1, vcc\n\t"
+        "s_or_b64 vcc, vcc, %4\n\t"                   // take t when the true sum was >= p
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %0, %0, %2, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %3, vcc"
+        : "=&v"(sl), "=&v"(sh), "=&v"(tl), "=&v"(th), "=&s"(c1)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc");
+    return pack64(sl, sh);
+}
+
+// a, b < p  ->  (a - b) mod p, canonical
+__device__ __forceinline__ uint64_t sub_c(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t dl, dh, e;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"       // d = a - b, borrow
+        "s_nop 1\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"        // e = borrow ? 2^32-1 : 0
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"        // d += p  ==  d -= (2^32-1)  (mod 2^64)
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(dl), "=&v"(dh), "=&v"(e)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc");
+    return pack64(dl, dh);
+}
+
+// x = lo + 2^64*hi (any 128-bit value)  ->  x mod p, canonical.
+//   x = lo - hh + hl*(2^32-1)  with hi = hh*2^32 + hl   (goldilocks_field.rs:345-358)
+__device__ __forceinline__ uint64_t reduce128_c(uint64_t lo, uint64_t hi) {
+    uint32_t ll = (uint32_t)lo, lh = (uint32_t)(lo >> 32), hl = (uint32_t)hi, hh = (uint32_t)(hi >> 32);
+    uint32_t rl, rh, ul, uh, e;
+    asm("v_sub_co_u32_e32 %0, vcc, %5, %8\n\t"       // t0 = lo - hh
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %6, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %4, 0, -1, vcc\n\t"        // borrow: t0 -= 2^32-1
+        "v_sub_co_u32_e32 %0, vcc, %0, %4\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32_e32 %2, vcc, 0, %7\n\t"         // u = hl*(2^32-1) = (hl<<32) - hl
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, 0, %7, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"        // r = t0 + u
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %3, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %4, 0, -1, vcc\n\t"        // carry: r += 2^32-1 (cannot carry again)
+        "v_add_co_u32_e32 %0, vcc, %0, %4\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_add_co_u32_e32 %2, vcc, -1, %0\n\t"        // canonicalise: r >= p ? r - p : r
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %1, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %0, %0, %2, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %3, vcc"
+        : "=&v"(rl), "=&v"(rh), "=&v"(ul), "=&v"(uh), "=&v"(e)
+        : "v"(ll), "v"(lh), "v"(hl), "v"(hh)
+        : "vcc");
+    return pack64(rl, rh);
+}
+
 __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
     u128 x = (u128)a * (u128)b;
     lo = (uint64_t)x;
@@ -85,9 +188,21 @@ __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
     return reduce128((uint64_t)t, (uint64_t)(t >> 64));
 }
 
-// x * 2^k mod p for a compile-time 0 <= k < 192, multiply-free.
-// 2^96 = -1 (mod p) so k >= 96 is a negated shift by k-96; for k < 96 the 160-bit value
-// x*2^k = lo + mid*2^64 + top*2^96 reduces to lo - top + mid*(2^32-1).
+// canonical-output product (inputs may be any u64)
+__device__ __forceinline__ uint64_t mul_c(uint64_t a, uint64_t b) {
+    uint64_t lo, hi;
+    mul_wide(a, b, lo, hi);
+    return reduce128_c(lo, hi);
+}
+
+// x * 2^k mod p for a compile-time 0 <= k < 192, multiply-free; x any u64, result any u64.
+// 2^96 = -1 (mod p), so k >= 96 is the negated shift by k-96 (callers that can absorb the sign —
+// the NTT butterflies — never take that branch). For k = 32q + s < 96 the 64-bit x shifted left
+// by s is a 96-bit number (w2:w1:w0), and with 2^64 = 2^32-1 =: e, 2^96 = -1, 2^128 = -2^32:
+//   q = 0:  (w1:w0) + w2*e
+//   q = 1:  (w0:0)  + w1*e - w2
+//   q = 2:   w0*e   - (w2:w1)
+// Every line needs at most one wrap correction per add/sub (bounds in the comments below).
 template <int K>
 __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
     static_assert(K >= 0 && K < 192, "shift out of range");
@@ -95,22 +210,33 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
         return x;
     } else if constexpr (K >= 96) {
         return neg(mul_pow2<K - 96>(x));
-    } else if constexpr (K < 32) {
-        uint64_t lo = x << K, hi = x >> (64 - K);  // hi < 2^32
-        return reduce96(lo, (uint32_t)hi);
-    } else if constexpr (K == 32) {
-        return reduce128(x << 32, x >> 32);
-    } else if constexpr (K < 64) {
-        return reduce128(x << K, x >> (64 - K));
-    } else if constexpr (K == 64) {
-        return reduce128(0, x);
     } else {
-        // 64 < K < 96: value = (x << (K-64)) * 2^64 ; the part above 2^96 is top = x >> (160-K)...
-        // split x*2^(K-64) = h (128-bit: hlo + hhi*2^64), then x*2^K = hlo*2^64 + hhi*2^128,
-        // and 2^128 = -2^32 (mod p): result = reduce128(0, hlo) - hhi*2^32.
-        constexpr int S = K - 64;  // 1..31
-        uint64_t hlo = x << S, hhi = x >> (64 - S);  // hhi < 2^31
-        return sub(reduce128(0, hlo), hhi << 32);
+        constexpr int Q = K / 32, S = K % 32;
+        const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+        uint32_t w0, w1, w2;
+        if constexpr (S == 0) {
+            w0 = xl; w1 = xh; w2 = 0;
+        } else {
+            w0 = xl << S;
+            w1 = __builtin_amdgcn_alignbit(xh, xl, 32 - S);
+            w2 = xh >> (32 - S);
+        }
+        auto times_eps = [](uint32_t w) { return ((uint64_t)w << 32) - w; };  // w * (2^32 - 1) < 2^64
+        if constexpr (Q == 0) {
+            uint64_t lo = ((uint64_t)w1 << 32) | w0, t = times_eps(w2);
+            uint64_t r = lo + t;
+            return r + ((r < t) ? EPS : 0);  // wrapped r < t <= (2^32-1)^2, so r + e cannot wrap again
+        } else if constexpr (Q == 1) {
+            uint64_t a = (uint64_t)w0 << 32, t = times_eps(w1);
+            uint64_t r = a + t;
+            r += (r < t) ? EPS : 0;
+            uint64_t r2 = r - w2;
+            return r2 - ((r < (uint64_t)w2) ? EPS : 0);  // borrow => r2 >= 2^64 - 2^32 > e
+        } else {
+            uint64_t t = times_eps(w0), u = ((uint64_t)w2 << 32) | w1;
+            uint64_t r = t - u;
+            return r - ((t < u) ? EPS : 0);  // borrow => r >= 2^64 - u > 2^63 > e (u < 2^63)
+        }
     }
 }
 

@@ -100,7 +100,12 @@ __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
             constexpr int K = (39 * j * (32 >> s)) % 192;
             uint64_t a = v[i0], c = v[i1];
             v[i0] = gl::add(a, c);
-            v[i1] = gl::mul_pow2<K>(gl::sub(a, c));
+            // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by
+            // swapping the operands of the subtraction instead of negating the product.
+            if constexpr (K >= 96)
+                v[i1] = gl::mul_pow2<K - 96>(gl::sub(c, a));
+            else
+                v[i1] = gl::mul_pow2<K>(gl::sub(a, c));
         });
     });
 }

@@ -52,3 +52,26 @@ def test_unary_ops_and_shifts(gpu):
     for k in range(192):  # x * 2^k for every shift the radix butterflies can use
         kk = np.full(len(ops), k, dtype=np.uint64)
         assert run_op(gpu, 6, a, kk) == [(x << k) % P for x in ops], k
+
+
+def test_canonical_domain_asm_primitives(gpu):
+    """add_c / sub_c / canon_c / mul_c / reduce128_c (hand-written carry chains) on the edge
+    operands and on random data; outputs must already be canonical (no fix-up on the way out)."""
+    ops = edge_operands()
+    pairs = list(itertools.product(ops, ops))
+    rng = np.random.default_rng(7)
+    rnd = rng.integers(0, 2**64, size=(20000, 2), dtype=np.uint64).tolist()
+    pairs += [(int(x), int(y)) for x, y in rnd]
+    a = np.array([x for x, _ in pairs], dtype=np.uint64)
+    b = np.array([y for _, y in pairs], dtype=np.uint64)
+    assert run_op(gpu, 8, a, b) == [(x + y) % P for x, y in pairs]
+    assert run_op(gpu, 9, a, b) == [(x - y) % P for x, y in pairs]
+    assert run_op(gpu, 10, a, b) == [(x * y) % P for x, y in pairs]
+    assert run_op(gpu, 11, a) == [x % P for x, _ in pairs]
+    M = (1 << 64) - 1
+    exp = []
+    for x, y in pairs:
+        prod = x * y
+        lo, hi = (prod & M) ^ y, (prod >> 64) ^ x
+        exp.append(((hi << 64) | lo) % P)
+    assert run_op(gpu, 12, a, b) == exp

@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) 
     uint64_t a[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) a[k] = seed * (i + 1) + k * 0x9E3779B97F4A7C15ull;
-    uint64_t b = seed ^ 0xD1B54A32D192ED03ull;
+    uint64_t b = gl::canon(seed ^ 0xD1B54A32D192ED03ull);
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = gl::canon(a[k]);
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -31,6 +33,10 @@ __global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) 
             if constexpr (OP == 7) { uint64_t lo, hi; gl::mul_wide(a[k], b, lo, hi); a[k] = lo ^ hi; }
             if constexpr (OP == 8) a[k] = a[k] * 0x9E3779B97F4A7C15ull + b;  // plain 64-bit mul low
             if constexpr (OP == 9) a[k] = (uint64_t)((uint32_t)a[k]) * (uint32_t)b + a[k];  // one v_mad_u64_u32
+            if constexpr (OP == 10) a[k] = gl::add_c(a[k], b);
+            if constexpr (OP == 11) a[k] = gl::sub_c(a[k], b);
+            if constexpr (OP == 12) a[k] = gl::mul_c(a[k], b);
+            if constexpr (OP == 13) a[k] = gl::canon_c(a[k] + b);
         }
     }
     out[i] = a[0] ^ a[1] ^ a[2] ^ a[3];
@@ -77,7 +83,8 @@ int main() {
     uint64_t *out;
     CK(hipMalloc(&out, (size_t)blocks * threads * 8));
     const char *names[] = {"gl::mul", "gl::add", "gl::sub", "mul_pow2<39>", "mul_pow2<156>", "gl::sqr", "gl::mac",
-                           "mul_wide(64x64->128)", "u64 mul lo", "v_mad_u64_u32"};
+                           "mul_wide(64x64->128)", "u64 mul lo", "v_mad_u64_u32",
+                           "add_c (asm)", "sub_c (asm)", "mul_c (asm reduce)", "canon_c (asm)+add64"};
     auto run = [&](auto tag, int op) {
         constexpr int OP = decltype(tag)::value;
         float ms = time_ms([&] { hipLaunchKernelGGL(alu_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull); });
@@ -96,6 +103,10 @@ int main() {
     run(std::integral_constant<int, 7>{}, 7);
     run(std::integral_constant<int, 8>{}, 8);
     run(std::integral_constant<int, 9>{}, 9);
+    run(std::integral_constant<int, 10>{}, 10);
+    run(std::integral_constant<int, 11>{}, 11);
+    run(std::integral_constant<int, 12>{}, 12);
+    run(std::integral_constant<int, 13>{}, 13);
     {
         int perms = 64;
         float ms = time_ms([&] { hipLaunchKernelGGL(poseidon_kernel, dim3(blocks), dim3(threads), 0, 0, out, 777ull, perms); });
