@@ -81,7 +81,7 @@ void gl_event_destroy(void *event);
  *   inverse = 1: ifft_with_options                        (field/src/fft.rs:73-103)
  *   bit_reversed = 1 (forward only): output slot m holds the value of natural index bitrev(m),
  *     i.e. reverse_index_bits(fft(x)) (util/src/lib.rs:188) — the Merkle leaf order.
- * log_n <= 20 in this build. For inverse, stride must be a multiple of 2^log_n. */
+ * log_n <= 24. For inverse, stride must be a multiple of 2^log_n. */
 GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, int inverse,
                      int bit_reversed, void *ctx);
 

@@ -263,7 +263,7 @@ void gl_event_destroy(void *event) {
 GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, int inverse,
                      int bit_reversed, void *ctx) {
     if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
-    if (log_n > 20) return fail(GL_E_INVALID, "log_n > 20 is not supported by this build");
+    if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24 is not supported by this build");
     if (stride < (1ull << log_n)) return fail(GL_E_INVALID, "stride smaller than the polynomial");
     if (inverse && bit_reversed) return fail(GL_E_INVALID, "bit-reversed inverse is not on the hot path");
     if (inverse && (stride & ((1ull << log_n) - 1))) return fail(GL_E_INVALID, "inverse needs stride % n == 0");
@@ -279,7 +279,7 @@ GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint
 GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t poly_num, uint32_t log_n,
                            uint32_t rate_bits, uint64_t shift, uint64_t src_stride, uint64_t dst_stride, void *ctx) {
     if (!ctx || ((!d_coeffs || !d_out) && poly_num)) return fail(GL_E_INVALID, "null pointer");
-    if (log_n > 20 || rate_bits > 8) return fail(GL_E_INVALID, "log_n > 20 or rate_bits > 8 not supported");
+    if (log_n > 24 || rate_bits > 8) return fail(GL_E_INVALID, "log_n > 24 or rate_bits > 8 not supported");
     const uint64_t n = 1ull << log_n;
     if (src_stride < n || dst_stride < (n << rate_bits)) return fail(GL_E_INVALID, "stride too small");
     if (((uintptr_t)d_coeffs | (uintptr_t)d_out) & 15) return fail(GL_E_INVALID, "buffers must be 16-byte aligned");
@@ -328,7 +328,7 @@ GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, 
 GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                               uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
-    if (log_n > 20) return fail(GL_E_INVALID, "log_n > 20 is not supported by this build");
+    if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24 is not supported by this build");
     return commit_from_coeffs_impl(d_coeffs, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
                                    d_digests, d_cap, S(ctx), false);
 }
@@ -385,7 +385,7 @@ GlError merkle_tree_from_coeffs(uint64_t *d_values_flatten, uint64_t *d_ext_valu
     if (poly_num <= 0 || log_len < 0 || rate_bits < 0 || salt_size < 0 || cap_height < 0 || pad_extvalues_len < 0 ||
         values_num_per_poly != (1 << log_len))
         return fail(GL_E_INVALID, "bad sizes");
-    if (log_len > 20) return fail(GL_E_INVALID, "log_len > 20 is not supported by this build");
+    if (log_len > 24) return fail(GL_E_INVALID, "log_len > 24 is not supported by this build");
     const uint64_t n_ext = (uint64_t)values_num_per_poly << rate_bits;
     const uint64_t ext_polys = (uint64_t)poly_num + salt_size;
     if ((uint64_t)pad_extvalues_len < ext_polys * n_ext)

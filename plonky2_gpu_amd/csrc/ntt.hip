@@ -470,7 +470,101 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         }
         return hipSuccess;
     }
-    return hipErrorInvalidValue;  // > 2^20: three-pass plan (see ntt_batch3 below)
+    // three passes (2^21 .. 2^24): n = N1*N2*N3, index j = j1*N2N3 + j2*N3 + j3.
+    //   pass 1: column pass over the whole polynomial (N1 points, stride N2N3, twiddle w_n^(L*k1))
+    //   pass 2: column pass inside each of the N1 blocks (N2 points, stride N3, twiddle w_{N2N3}^(j3*k2))
+    //   pass 3: row pass over rows of N3 contiguous points
+    // Bit-reversed order runs all three in place; natural order keeps the intermediate in the
+    // scratch workspace and lets pass 3 write X[k1 + N1*k2 + N1*N2*k3] (T adjacent k1 per segment).
+    {
+        const uint32_t la = (log_n + 2) / 3, lb = (log_n - la + 1) / 2, lc = log_n - la - lb;
+        const uint64_t N1 = 1ull << la, N2 = 1ull << lb, N3 = 1ull << lc, N23 = N2 * N3;
+        const uint32_t logt1 = LOGE - la, T1 = 1u << logt1, logt2 = LOGE - lb, T2 = 1u << logt2, logt3 = LOGE - lc,
+                       T3 = 1u << logt3;
+        if (inverse && !natural) return hipErrorInvalidValue;
+        if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
+        uint64_t chunk = 65535;
+        if (natural) {
+            if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
+            chunk = tb.scratch_elems / n;
+        }
+        for (uint64_t off = 0; off < n_polys; off += chunk) {
+            const uint64_t cnt = n_polys - off < chunk ? n_polys - off : chunk;
+            uint64_t *mid = natural ? tb.scratch : dst + off * dst_stride;
+            const uint64_t mid_stride = natural ? n : dst_stride;
+            base_params(p, tb);
+            p.src = src + off * src_stride;
+            p.dst = mid;
+            p.logt = logt1;
+            p.t_limit = (uint32_t)N23;
+            p.in_sa = src_stride;
+            p.in_sb = T1;
+            p.in_t = 1;
+            p.in_m = N23;
+            p.out_sa = mid_stride;
+            p.out_sb = T1;
+            p.out_t = 1;
+            p.out_m = N23;
+            p.flags = natural ? F_NATURAL : 0;
+            p.log_n = log_n;
+            p.tw_hi = log_n;
+            hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N23 / T1), (unsigned)cnt, 1), stream);
+            if (e != hipSuccess) return e;
+            base_params(p, tb);
+            p.src = mid;
+            p.dst = mid;
+            p.logt = logt2;
+            p.t_limit = (uint32_t)N3;
+            p.in_sa = mid_stride;
+            p.in_sb = T2;
+            p.in_sz = N23;
+            p.in_t = 1;
+            p.in_m = N3;
+            p.out_sa = mid_stride;
+            p.out_sb = T2;
+            p.out_sz = N23;
+            p.out_t = 1;
+            p.out_m = N3;
+            p.flags = natural ? F_NATURAL : 0;
+            p.log_n = log_n;
+            p.tw_hi = lb + lc;
+            e = dispatch_pass<true>(lb, p, dim3((unsigned)(N3 / T2), (unsigned)cnt, (unsigned)N1), stream);
+            if (e != hipSuccess) return e;
+            base_params(p, tb);
+            p.src = mid;
+            p.dst = dst + off * dst_stride;
+            p.logt = logt3;
+            p.in_sa = mid_stride;
+            p.in_m = 1;
+            p.out_sa = dst_stride;
+            p.log_n = log_n;
+            p.scale = n_inv;
+            if (natural) {
+                // tile = T3 rows with consecutive k1 at fixed k2 (blockIdx.z): row (k1, k2) starts at (k1*N2 + k2)*N3
+                p.t_limit = (uint32_t)N1;
+                p.in_sb = (uint64_t)T3 * N23;
+                p.in_sz = N3;
+                p.in_t = N23;
+                p.out_sb = T3;
+                p.out_sz = N1;
+                p.out_t = 1;
+                p.out_m = N1 * N2;
+                p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
+                e = dispatch_pass<false>(lc, p, dim3((unsigned)(N1 / T3), (unsigned)cnt, (unsigned)N2), stream);
+            } else {
+                p.t_limit = (uint32_t)(N1 * N2);
+                p.in_sb = (uint64_t)T3 * N3;
+                p.in_t = N3;
+                p.out_sb = (uint64_t)T3 * N3;
+                p.out_t = N3;
+                p.out_m = 1;
+                p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+                e = dispatch_pass<false>(lc, p, dim3((unsigned)(N1 * N2 / T3), (unsigned)cnt, 1), stream);
+            }
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -565,8 +659,8 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
     const uint32_t log_n = ct.log_n, rate_bits = ct.rate_bits;
     const uint64_t n = 1ull << log_n, n_cosets = 1ull << rate_bits;
     if (n_polys == 0) return hipSuccess;
-    if (log_n <= 12 || log_n > 20) {
-        if (log_n > 20) return hipErrorInvalidValue;
+    if (log_n > NTT_MAX_LOG) return hipErrorInvalidValue;
+    if (log_n <= 12) {
         // small polynomials: scaled copies, then 2^rate_bits * n_polys in-place bit-reversed NTTs
         uint64_t total = n_polys * n_cosets * n;
         hipLaunchKernelGGL(coset_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, coeffs, dst,
@@ -578,6 +672,79 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
         for (uint64_t i = 0; i < n_polys; i++) {
             e = ntt_batch(tb, dst + i * dst_stride, dst + i * dst_stride, n_cosets, log_n, n, n, NttOrder::BitReversed,
                           false, stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    if (log_n > 20) {
+        // three-pass sizes; needs the coset blocks of all polynomials contiguous (dst_stride = n << rate_bits)
+        if (dst_stride != n_cosets * n) return hipErrorInvalidValue;
+        const uint32_t la = (log_n + 2) / 3, lb = (log_n - la + 1) / 2, lc = log_n - la - lb;
+        const uint64_t N1 = 1ull << la, N2 = 1ull << lb, N3 = 1ull << lc, N23 = N2 * N3;
+        const uint32_t logt1 = LOGE - la, T1 = 1u << logt1, logt2 = LOGE - lb, T2 = 1u << logt2, logt3 = LOGE - lc,
+                       T3 = 1u << logt3;
+        const uint64_t max_polys = 65535 / n_cosets;
+        for (uint64_t off = 0; off < n_polys; off += max_polys) {
+            uint64_t cnt = n_polys - off < max_polys ? n_polys - off : max_polys;
+            PassParams p;
+            base_params(p, tb);
+            p.src = coeffs + off * src_stride;
+            p.dst = dst + off * dst_stride;
+            p.cs_hi = ct.hi;
+            p.cs_lo = ct.lo;
+            p.cs_hi_len = ct.hi_len;
+            p.rate_bits = rate_bits;
+            p.logt = logt1;
+            p.t_limit = (uint32_t)N23;
+            p.in_sa = src_stride;
+            p.in_sb = T1;
+            p.in_t = 1;
+            p.in_m = N23;
+            p.out_sa = dst_stride;
+            p.out_sb = T1;
+            p.out_sz = n;
+            p.out_t = 1;
+            p.out_m = N23;
+            p.flags = F_COSET;
+            p.log_n = log_n;
+            p.tw_hi = log_n;
+            hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N23 / T1), (unsigned)cnt, (unsigned)n_cosets), stream);
+            if (e != hipSuccess) return e;
+            base_params(p, tb);  // pass 2: y enumerates (poly, coset block), z = slot m1
+            p.src = dst + off * dst_stride;
+            p.dst = dst + off * dst_stride;
+            p.logt = logt2;
+            p.t_limit = (uint32_t)N3;
+            p.in_sa = n;
+            p.in_sb = T2;
+            p.in_sz = N23;
+            p.in_t = 1;
+            p.in_m = N3;
+            p.out_sa = n;
+            p.out_sb = T2;
+            p.out_sz = N23;
+            p.out_t = 1;
+            p.out_m = N3;
+            p.log_n = log_n;
+            p.tw_hi = lb + lc;
+            e = dispatch_pass<true>(lb, p, dim3((unsigned)(N3 / T2), (unsigned)(cnt * n_cosets), (unsigned)N1), stream);
+            if (e != hipSuccess) return e;
+            base_params(p, tb);  // pass 3: rows of N3, in place
+            p.src = dst + off * dst_stride;
+            p.dst = dst + off * dst_stride;
+            p.logt = logt3;
+            p.t_limit = (uint32_t)(N1 * N2);
+            p.in_sa = n;
+            p.in_sb = (uint64_t)T3 * N3;
+            p.in_t = N3;
+            p.in_m = 1;
+            p.out_sa = n;
+            p.out_sb = (uint64_t)T3 * N3;
+            p.out_t = N3;
+            p.out_m = 1;
+            p.flags = F_LOAD_ROWS | F_STORE_ROWS;
+            p.log_n = log_n;
+            e = dispatch_pass<false>(lc, p, dim3((unsigned)(N1 * N2 / T3), (unsigned)(cnt * n_cosets), 1), stream);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;

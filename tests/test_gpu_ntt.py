@@ -128,13 +128,40 @@ def test_full_size_round_trip_and_linearity(gpu, oracle):
     assert [int(v) for v in fz[idx]] == [(a * int(u) + int(v)) % P for u, v in zip(f0[0, idx], f0[1, idx])]
 
 
+@pytest.mark.parametrize("log_n", [21, 22, 23])
+def test_ntt_three_pass_sizes(gpu, oracle, log_n):
+    """2^21..2^23 (the three-pass plan): oracle equality on one column, round trip and the
+    bit-reversed variant on a second one."""
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    x = oracle.random_field((2, n), seed=5000 + log_n)
+    exp = oracle.canon(oracle.fft_batch(x, threads=2))
+    f = pg.fft_with_options(gpu, x)
+    assert (f == exp).all()
+    assert (pg.ifft_with_options(gpu, f) == x).all()
+    b = pg.fft_with_options(gpu, x[1], bit_reversed=True)
+    assert (b == exp[1][bitrev_perm(log_n)]).all()
+
+
+def test_coset_lde_three_pass(gpu, oracle):
+    import plonky2_gpu_amd as pg
+
+    log_n, rate_bits = 21, 1
+    c = oracle.random_field((2, 1 << log_n), seed=6000)
+    got = pg.coset_lde_bit_reversed(gpu, c, rate_bits)
+    perm = bitrev_perm(log_n + rate_bits)
+    for i in range(2):
+        assert (got[i] == oracle.canon(oracle.coset_lde(c[i], rate_bits))[perm]).all()
+
+
 def test_ntt_argument_errors(gpu):
     import plonky2_gpu_amd as pg
     from plonky2_gpu_amd import _lib
 
     buf = pg.DeviceBuffer(gpu, 1 << 10)
     with pytest.raises(pg.Plonky2HipError) as e:
-        _lib.call("gl_ntt_batch", buf.ptr, 1, 21, 1 << 21, 0, 0, gpu.ptr)
+        _lib.call("gl_ntt_batch", buf.ptr, 1, 25, 1 << 25, 0, 0, gpu.ptr)
     assert e.value.code == pg.GL_E_INVALID
     with pytest.raises(pg.Plonky2HipError):
         _lib.call("gl_ntt_batch", buf.ptr, 1, 10, 512, 0, 0, gpu.ptr)  # stride < n
