@@ -93,6 +93,13 @@ GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint
 GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t poly_num, uint32_t log_n,
                            uint32_t rate_bits, uint64_t shift, uint64_t src_stride, uint64_t dst_stride, void *ctx);
 
+/* Natural-order coset transforms, in place:
+ *   inverse = 0: PolynomialCoeffs::coset_fft(shift)   (field/src/polynomial/mod.rs:281-299)
+ *   inverse = 1: PolynomialValues::coset_ifft(shift)  (field/src/polynomial/mod.rs:64-77) — the
+ *               last step of compute_quotient_polys (plonk/prover.rs:1009-1021). */
+GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, uint64_t shift, int inverse,
+                           void *ctx);
+
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
 

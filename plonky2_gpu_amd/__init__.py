@@ -9,7 +9,7 @@ Nothing here computes field arithmetic on the CPU; without the HIP library it ra
 """
 from ._lib import GL_E_INVALID, GL_E_UNSUPPORTED, Plonky2HipError, load  # noqa: F401
 from .device import Context, DeviceBuffer, Event  # noqa: F401
-from .fft import coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
+from .fft import coset_fft, coset_ifft, coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
 from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401
 

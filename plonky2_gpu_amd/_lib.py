@@ -47,6 +47,7 @@ SIGNATURES = {
     "gl_event_destroy": (None, [_vp]),
     "gl_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _i, _i, _vp]),
     "gl_coset_lde_batch": (GlError, [_vp, _vp, _u64, _u32, _u32, _u64, _u64, _u64, _vp]),
+    "gl_coset_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _u64, _i, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),

@@ -292,6 +292,25 @@ GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t p
     return ok();
 }
 
+GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, uint64_t shift, int inverse,
+                           void *ctx) {
+    if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
+    if (shift % glh::P == 0) return fail(GL_E_INVALID, "shift must be non-zero");
+    const CosetTables *ct;
+    if (!inverse) {
+        // coset_fft: c_i *= shift^i, then fft (polynomial/mod.rs:286-299)
+        HIP_TRY(get_coset_tables(log_n, 0, shift % glh::P, S(ctx)->stream, &ct));
+        HIP_TRY(scale_by_powers(*ct, d_values, poly_num, stride, S(ctx)->stream));
+        return gl_ntt_batch(d_values, poly_num, log_n, stride, 0, 0, ctx);
+    }
+    // coset_ifft: ifft, then c_i *= shift^-i (polynomial/mod.rs:64-77)
+    GlError e = gl_ntt_batch(d_values, poly_num, log_n, stride, 1, 0, ctx);
+    if (e.code) return e;
+    HIP_TRY(get_coset_tables(log_n, 0, glh::inv(shift), S(ctx)->stream, &ct));
+    HIP_TRY(scale_by_powers(*ct, d_values, poly_num, stride, S(ctx)->stream));
+    return ok();
+}
+
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx) {
     if (!ctx || (!d_states && count)) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(poseidon_permute_batch(d_states, count, S(ctx)->stream));

@@ -51,4 +51,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
 hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uint64_t *coeffs, uint64_t *dst,
                            uint64_t n_polys, uint64_t src_stride, uint64_t dst_stride, hipStream_t stream);
 
+// values[poly*stride + i] *= s^i with s = ct.shift (ct built with rate_bits = 0).
+hipError_t scale_by_powers(const CosetTables &ct, uint64_t *values, uint64_t n_polys, uint64_t stride, hipStream_t stream);
+
 }  // namespace plonky2_hip

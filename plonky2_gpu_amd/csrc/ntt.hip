@@ -629,7 +629,26 @@ __global__ void coset_scale_kernel(const uint64_t *coeffs, uint64_t *dst, const 
     uint64_t sc = gl::mul(hi[r * hi_len + (uint32_t)(i >> 10)], lo[r * 1024 + (uint32_t)(i & 1023)]);
     dst[poly * dst_stride + (uint64_t)q * n + i] = gl::mul(coeffs[poly * src_stride + i], sc);
 }
+// v[poly*stride + i] *= s^i  (coset_fft_with_options' shift.powers() scaling, polynomial/mod.rs:292-297,
+// and coset_ifft's shift^-i, polynomial/mod.rs:64-77); lo/hi are the coset tables of s (one coset).
+__global__ void scale_by_powers_kernel(uint64_t *v, const uint64_t *lo, const uint64_t *hi, uint32_t log_n, uint64_t stride,
+                                       uint64_t total) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint64_t i = g & ((1ull << log_n) - 1), poly = g >> log_n;
+    uint64_t sc = gl::mul(hi[(uint32_t)(i >> 10)], lo[(uint32_t)(i & 1023)]);
+    uint64_t *p = v + poly * stride + i;
+    *p = gl::canon(gl::mul(*p, sc));
+}
 }  // namespace
+
+hipError_t scale_by_powers(const CosetTables &ct, uint64_t *values, uint64_t n_polys, uint64_t stride, hipStream_t stream) {
+    uint64_t total = n_polys << ct.log_n;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_by_powers_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, values, ct.lo, ct.hi,
+                       ct.log_n, stride, total);
+    return hipGetLastError();
+}
 
 hipError_t coset_tables_create(CosetTables *ct, uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream) {
     if (log_n + rate_bits > 32 || rate_bits > 8) return hipErrorInvalidValue;

@@ -50,3 +50,23 @@ def coset_lde_bit_reversed(ctx, coeffs, rate_bits, shift=7):
     src.free()
     dst.free()
     return out if np.ndim(coeffs) > 1 else out[0]
+
+
+def coset_fft(ctx, coeffs, shift=7):
+    """PolynomialCoeffs::coset_fft(shift) (field/src/polynomial/mod.rs:281-299), natural order."""
+    a, log_n = _as_batch(coeffs)
+    buf = DeviceBuffer.from_host(ctx, a)
+    _lib.call("gl_coset_ntt_batch", buf.ptr, a.shape[0], log_n, a.shape[1], shift, 0, ctx.ptr)
+    out = buf.download().reshape(a.shape)
+    buf.free()
+    return out if np.ndim(coeffs) > 1 else out[0]
+
+
+def coset_ifft(ctx, values, shift=7):
+    """PolynomialValues::coset_ifft(shift) (field/src/polynomial/mod.rs:64-77)."""
+    a, log_n = _as_batch(values)
+    buf = DeviceBuffer.from_host(ctx, a)
+    _lib.call("gl_coset_ntt_batch", buf.ptr, a.shape[0], log_n, a.shape[1], shift, 1, ctx.ptr)
+    out = buf.download().reshape(a.shape)
+    buf.free()
+    return out if np.ndim(values) > 1 else out[0]

@@ -155,6 +155,21 @@ def test_coset_lde_three_pass(gpu, oracle):
         assert (got[i] == oracle.canon(oracle.coset_lde(c[i], rate_bits))[perm]).all()
 
 
+@pytest.mark.parametrize("log_n", [0, 3, 8, 12, 15, 21])
+def test_coset_fft_and_ifft_natural_order(gpu, oracle, log_n):
+    # field/src/polynomial/mod.rs:482-522 (random poly, shift = generator) and a second shift
+    import plonky2_gpu_amd as pg
+
+    x = oracle.random_field((2, 1 << log_n), seed=7000 + log_n)
+    for shift in (7, 0x1234567890ABCDEF):
+        ev = pg.coset_fft(gpu, x, shift)
+        for i in range(2):
+            assert (ev[i] == oracle.canon(oracle.coset_fft(x[i], shift))).all()
+        assert (pg.coset_ifft(gpu, ev, shift) == x).all()
+        for i in range(2):
+            assert (pg.coset_ifft(gpu, x[i], shift) == oracle.canon(oracle.coset_ifft(x[i], shift))).all()
+
+
 def test_ntt_argument_errors(gpu):
     import plonky2_gpu_amd as pg
     from plonky2_gpu_amd import _lib
