@@ -111,22 +111,30 @@ __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
 }
 
 // One radix round over the digit occupying bits [SH, SH+D) of the LDS row index m.
+// LOGT = LOGE - LOGR is a compile-time constant, and the padded LDS address of element i of a
+// group is (group base) + i * (compile-time stride): bits [SH, SH+D) of m are zero in the base, so
+// neither the index nor its pad term (idx >> (4+LOGT)) << LOGT can carry — every ds_read/ds_write
+// of the round uses one base VGPR and an immediate offset.
 template <int LOGR, int D, int SH, bool TWIDDLE>
 __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
                                             uint32_t b) {
-    constexpr int RD = 1 << D, G = 16 >> D;
-    const uint32_t logt = p.logt, tmask = (1u << logt) - 1;
+    constexpr int RD = 1 << D, G = 16 >> D, LOGT = LOGE - LOGR;
+    constexpr uint32_t TMASK = (1u << LOGT) - 1;
+    static_assert(SH == 0 || SH >= 4, "digits below the top one are radix-16");
+    // element stride in the padded image
+    constexpr uint32_t STRIDE = (SH >= 4) ? ((1u << (SH + LOGT)) + (1u << (SH - 4 + LOGT))) : (1u << LOGT);
     const bool natural = (SH == 0) && (p.flags & F_NATURAL);
     uint64_t v[16];
+    uint32_t base[G];
     static_for<0, G>([&](auto G_) {
         constexpr int g = decltype(G_)::value;
-        uint32_t gid = tid + g * NT, l = gid & tmask, rest = gid >> logt;
+        uint32_t gid = tid + g * NT, l = gid & TMASK, rest = gid >> LOGT;
         uint32_t rest_lo = rest & ((1u << SH) - 1), rest_hi = rest >> SH;
         uint32_t mbase = (rest_hi << (SH + D)) | rest_lo;
+        base[g] = phys((mbase << LOGT) + l, LOGT);
         static_for<0, RD>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
-            uint32_t idx = ((mbase | (i << SH)) << logt) + l;
-            v[g * RD + i] = data[phys(idx, logt)];
+            v[g * RD + i] = data[base[g] + i * STRIDE];
         });
     });
     if (natural) __syncthreads();  // slots are permuted on write-back: everyone must have read
@@ -136,7 +144,7 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
         // inter-digit twiddle w_{2^(SH+D)}^(low * k1), k1 = bitrev_D(i), from the LDS table of w_R
         static_for<0, G>([&](auto G_) {
             constexpr int g = decltype(G_)::value;
-            uint32_t gid = tid + g * NT, rest = gid >> logt;
+            uint32_t gid = tid + g * NT, rest = gid >> LOGT;
             uint32_t rest_lo = rest & ((1u << SH) - 1);
             static_for<1, RD>([&](auto I_) {
                 constexpr int i = decltype(I_)::value;
@@ -148,8 +156,8 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
     } else if constexpr (TWIDDLE) {
         // inter-pass twiddle w_{2^tw_hi}^(L * k1), k1 = bitrev4(i)*(R/16) + kr  (G == 1, D == 4)
         static_assert(D == 4 || !TWIDDLE, "twiddled passes end with a radix-16 round");
-        uint32_t l = tid & tmask, rest = tid >> logt;
-        uint64_t L = (uint64_t)b * (1u << logt) + l;
+        uint32_t l = tid & TMASK, rest = tid >> LOGT;
+        uint64_t L = (uint64_t)b * (1u << LOGT) + l;
         uint32_t kr = brev_rt(rest, LOGR - 4);
         uint64_t c = wpow(p, L * kr);
         if (p.flags & F_COSET) {
@@ -167,18 +175,32 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
         });
     }
 
-    static_for<0, G>([&](auto G_) {
-        constexpr int g = decltype(G_)::value;
-        uint32_t gid = tid + g * NT, l = gid & tmask, rest = gid >> logt;
-        uint32_t rest_lo = rest & ((1u << SH) - 1), rest_hi = rest >> SH;
-        uint32_t mbase = (rest_hi << (SH + D)) | rest_lo;
-        uint32_t kr = natural ? brev_rt(rest_hi, LOGR - D) : 0;
-        static_for<0, RD>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            uint32_t m = natural ? ((uint32_t)(brev_c(i, D) << (LOGR - D)) | kr) : (mbase | (i << SH));
-            data[phys((m << logt) + l, logt)] = v[g * RD + i];
+    if (!natural) {
+        static_for<0, G>([&](auto G_) {
+            constexpr int g = decltype(G_)::value;
+            static_for<0, RD>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                data[base[g] + i * STRIDE] = v[g * RD + i];
+            });
         });
-    });
+    } else {
+        // natural order: slot of frequency k = (bitrev_D(i) << (LOGR-D)) | bitrev(rest). The pad term
+        // of the slot index is again separable into a per-thread base and a per-i constant.
+        if constexpr (SH == 0) {
+            static_for<0, G>([&](auto G_) {
+                constexpr int g = decltype(G_)::value;
+                uint32_t gid = tid + g * NT, l = gid & TMASK, rest = gid >> LOGT;
+                uint32_t kr = brev_rt(rest, LOGR - D);
+                uint32_t nb = (kr << LOGT) + l + (((LOGR - D >= 4) ? (kr >> 4) : 0u) << LOGT);
+                static_for<0, RD>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    constexpr uint32_t mi = (uint32_t)brev_c(i, D) << (LOGR - D);
+                    constexpr uint32_t off = (mi << LOGT) + ((mi >> 4) << LOGT);
+                    data[nb + off] = v[g * RD + i];
+                });
+            });
+        }
+    }
 }
 
 template <int LOGR, int SH, bool TWIDDLE>
@@ -208,7 +230,8 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
     uint64_t *data = lds;
     uint64_t *tw = lds + LDS_DATA;
     constexpr int R = 1 << LOGR;
-    const uint32_t tid = threadIdx.x, logt = p.logt, T = 1u << logt;
+    constexpr uint32_t logt = LOGE - LOGR, T = 1u << logt;
+    const uint32_t tid = threadIdx.x;
     const uint32_t a = blockIdx.y, b = blockIdx.x, z = blockIdx.z;
 
     // local twiddles w_R^e = w_4096^(e * 4096/R)
