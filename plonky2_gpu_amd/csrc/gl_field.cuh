@@ -188,6 +188,76 @@ __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
     return reduce128((uint64_t)t, (uint64_t)(t >> 64));
 }
 
+// Two radix-2 butterflies at once on arbitrary representatives:
+//   s0 = a0 + c0, d0 = x0 - y0, s1 = a1 + c1, d1 = x1 - y1     (x,y = a,c or c,a when NEG)
+// with the reference's double wrap correction (goldilocks_field.rs:197-256) done on the carry
+// flags. The four carry chains are interleaved instruction by instruction, so every
+// VALU-writes-SGPR -> VALU-reads-it dependency has three independent instructions in between
+// (gfx950 needs two wait states) and no s_nop is spent; 32 VALU instructions for what the
+// compiler's compare/select lowering does in ~48 issue slots.
+#define GL_BFLY2_ASM(X0L, X0H, X1L, X1H)                                                          \
+    /* raw 64-bit sums / differences */                                                            \
+    "v_add_co_u32_e64 %0, %12, %16, %18\n\t"                                                       \
+    "v_sub_co_u32_e64 %2, %13, " X0L "\n\t"                                                        \
+    "v_add_co_u32_e64 %4, %14, %20, %22\n\t"                                                       \
+    "v_sub_co_u32_e64 %6, %15, " X1L "\n\t"                                                        \
+    "v_addc_co_u32_e64 %1, %12, %17, %19, %12\n\t"                                                 \
+    "v_subb_co_u32_e64 %3, %13, " X0H ", %13\n\t"                                                  \
+    "v_addc_co_u32_e64 %5, %14, %21, %23, %14\n\t"                                                 \
+    "v_subb_co_u32_e64 %7, %15, " X1H ", %15\n\t" /* first correction: +/- (2^32 - 1) on carry / borrow */ \
+    "v_cndmask_b32_e64 %8, 0, -1, %12\n\t"                                                         \
+    "v_cndmask_b32_e64 %9, 0, -1, %13\n\t"                                                         \
+    "v_cndmask_b32_e64 %10, 0, -1, %14\n\t"                                                        \
+    "v_cndmask_b32_e64 %11, 0, -1, %15\n\t"                                                        \
+    "v_add_co_u32_e64 %0, %12, %0, %8\n\t"                                                         \
+    "v_sub_co_u32_e64 %2, %13, %2, %9\n\t"                                                         \
+    "v_add_co_u32_e64 %4, %14, %4, %10\n\t"                                                        \
+    "v_sub_co_u32_e64 %6, %15, %6, %11\n\t"                                                        \
+    "v_addc_co_u32_e64 %1, %12, 0, %1, %12\n\t"                                                    \
+    "v_subb_co_u32_e64 %3, %13, %3, 0, %13\n\t"                                                    \
+    "v_addc_co_u32_e64 %5, %14, 0, %5, %14\n\t"                                                    \
+    "v_subb_co_u32_e64 %7, %15, %7, 0, %15\n\t" /* second (rare) correction */                     \
+    "v_cndmask_b32_e64 %8, 0, -1, %12\n\t"                                                         \
+    "v_cndmask_b32_e64 %9, 0, -1, %13\n\t"                                                         \
+    "v_cndmask_b32_e64 %10, 0, -1, %14\n\t"                                                        \
+    "v_cndmask_b32_e64 %11, 0, -1, %15\n\t"                                                        \
+    "v_add_co_u32_e64 %0, %12, %0, %8\n\t"                                                         \
+    "v_sub_co_u32_e64 %2, %13, %2, %9\n\t"                                                         \
+    "v_add_co_u32_e64 %4, %14, %4, %10\n\t"                                                        \
+    "v_sub_co_u32_e64 %6, %15, %6, %11\n\t"                                                        \
+    "v_addc_co_u32_e64 %1, %12, 0, %1, %12\n\t"                                                    \
+    "v_subb_co_u32_e64 %3, %13, %3, 0, %13\n\t"                                                    \
+    "v_addc_co_u32_e64 %5, %14, 0, %5, %14\n\t"                                                    \
+    "v_subb_co_u32_e64 %7, %15, %7, 0, %15"
+
+template <bool NEG0, bool NEG1>
+__device__ __forceinline__ void bfly2(uint64_t a0, uint64_t c0, uint64_t a1, uint64_t c1, uint64_t &s0, uint64_t &d0,
+                                      uint64_t &s1, uint64_t &d1) {
+    uint32_t a0l = (uint32_t)a0, a0h = (uint32_t)(a0 >> 32), c0l = (uint32_t)c0, c0h = (uint32_t)(c0 >> 32);
+    uint32_t a1l = (uint32_t)a1, a1h = (uint32_t)(a1 >> 32), c1l = (uint32_t)c1, c1h = (uint32_t)(c1 >> 32);
+    uint32_t s0l, s0h, d0l, d0h, s1l, s1h, d1l, d1h, e0, e1, e2, e3;
+    uint64_t k0, k1, k2, k3;
+#define GL_BFLY2_OPERANDS                                                                                        \
+    : "=&v"(s0l), "=&v"(s0h), "=&v"(d0l), "=&v"(d0h), "=&v"(s1l), "=&v"(s1h), "=&v"(d1l), "=&v"(d1h), /* 0-7 */  \
+      "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3),                                                     /* 8-11 */ \
+      "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)                                                      /* 12-15 */ \
+    : "v"(a0l), "v"(a0h), "v"(c0l), "v"(c0h), "v"(a1l), "v"(a1h), "v"(c1l), "v"(c1h)                  /* 16-23 */
+    // difference operands: a - c, or c - a when the twiddle's sign is absorbed (NEG)
+    if constexpr (!NEG0 && !NEG1)
+        asm(GL_BFLY2_ASM("%16, %18", "%17, %19", "%20, %22", "%21, %23") GL_BFLY2_OPERANDS);
+    else if constexpr (NEG0 && !NEG1)
+        asm(GL_BFLY2_ASM("%18, %16", "%19, %17", "%20, %22", "%21, %23") GL_BFLY2_OPERANDS);
+    else if constexpr (!NEG0 && NEG1)
+        asm(GL_BFLY2_ASM("%16, %18", "%17, %19", "%22, %20", "%23, %21") GL_BFLY2_OPERANDS);
+    else
+        asm(GL_BFLY2_ASM("%18, %16", "%19, %17", "%22, %20", "%23, %21") GL_BFLY2_OPERANDS);
+#undef GL_BFLY2_OPERANDS
+    s0 = pack64(s0l, s0h);
+    d0 = pack64(d0l, d0h);
+    s1 = pack64(s1l, s1h);
+    d1 = pack64(d1l, d1h);
+}
+
 // canonical-output product (inputs may be any u64)
 __device__ __forceinline__ uint64_t mul_c(uint64_t a, uint64_t b) {
     uint64_t lo, hi;

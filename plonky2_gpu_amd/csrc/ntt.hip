@@ -93,20 +93,28 @@ __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
     static_for<0, D>([&](auto S_) {
         constexpr int s = D - 1 - decltype(S_)::value;
         constexpr int half = 1 << s;
-        static_for<0, (1 << D) / 2>([&](auto B_) {
-            constexpr int bf = decltype(B_)::value;
-            constexpr int blk = bf / half, j = bf % half;
-            constexpr int i0 = BASE + blk * 2 * half + j, i1 = i0 + half;
-            constexpr int K = (39 * j * (32 >> s)) % 192;
-            uint64_t a = v[i0], c = v[i1];
-            v[i0] = gl::add(a, c);
-            // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by
-            // swapping the operands of the subtraction instead of negating the product.
-            if constexpr (K >= 96)
-                v[i1] = gl::mul_pow2<K - 96>(gl::sub(c, a));
-            else
-                v[i1] = gl::mul_pow2<K>(gl::sub(a, c));
-        });
+        constexpr int NB = (1 << D) / 2;
+        if constexpr (NB >= 2) {
+            // butterflies in pairs through the interleaved carry-chain primitive (gl::bfly2)
+            static_for<0, NB / 2>([&](auto B_) {
+                constexpr int b0 = 2 * decltype(B_)::value, b1 = b0 + 1;
+                constexpr int i00 = BASE + (b0 / half) * 2 * half + (b0 % half), i01 = i00 + half;
+                constexpr int i10 = BASE + (b1 / half) * 2 * half + (b1 % half), i11 = i10 + half;
+                constexpr int K0 = (39 * (b0 % half) * (32 >> s)) % 192, K1 = (39 * (b1 % half) * (32 >> s)) % 192;
+                // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by
+                // swapping the operands of the subtraction instead of negating the product.
+                uint64_t s0, d0, s1, d1;
+                gl::bfly2<(K0 >= 96), (K1 >= 96)>(v[i00], v[i01], v[i10], v[i11], s0, d0, s1, d1);
+                v[i00] = s0;
+                v[i10] = s1;
+                v[i01] = gl::mul_pow2<(K0 >= 96 ? K0 - 96 : K0)>(d0);
+                v[i11] = gl::mul_pow2<(K1 >= 96 ? K1 - 96 : K1)>(d1);
+            });
+        } else {
+            uint64_t a = v[BASE], c = v[BASE + 1];
+            v[BASE] = gl::add(a, c);
+            v[BASE + 1] = gl::sub(a, c);
+        }
     });
 }
 
