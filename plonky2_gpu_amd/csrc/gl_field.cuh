@@ -174,10 +174,51 @@ __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, u
     hi = (uint64_t)(x >> 64);
 }
 
+// a * b mod p for arbitrary representatives, result in [0, 2^64): hand-scheduled.
+//
+// hipcc's lowering of (u128)a*b + reduce128 spends ~24 VALU instructions plus hazard padding: six
+// v_mov to build zero-extended register pairs for the v_mad_u64_u32 addends and compare/select
+// corrections built from double-pumped 64-bit ops. Here (18 VALU):
+//   product:  T = al*bl ; U = al*bh + (T>>32) ; V = ah*bl + (U.lo,0) ; W = ah*bh + (U>>32) + V.hi
+//             -> lo = (T.lo, V.lo), hi = W           (no intermediate can overflow 64 bits)
+//   reduce :  t0 = lo - hh (borrow => -= 2^32-1) ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32
+//             whose carry-out drives the last correction (goldilocks_field.rs:345-358).
+// `s_nop 1` = the two wait states between a VALU instruction that writes VCC/an SGPR and the VALU
+// instruction that consumes it as carry-in or select mask.
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
-    uint64_t lo, hi;
-    mul_wide(a, b, lo, hi);
-    return reduce128(lo, hi);
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t rl, rh;
+    // LLVM's AMDGPU inline asm has no sub-register operand modifier, so the 64-bit temporaries
+    // whose halves are needed live in fixed registers v[116:126] (declared clobbered).
+    asm("v_mad_u64_u32 v[116:117], vcc, %2, %4, 0\n\t"          // T = al*bl
+        "v_mov_b32_e32 v125, 0\n\t"
+        "v_mov_b32_e32 v124, v117\n\t"                          // X = (T.hi, 0)
+        "v_mad_u64_u32 v[118:119], vcc, %2, %5, v[124:125]\n\t" // U = al*bh + T.hi
+        "v_mov_b32_e32 v124, v119\n\t"                          // X = (U.hi, 0)
+        "v_mad_u64_u32 v[122:123], vcc, %3, %5, v[124:125]\n\t" // W = ah*bh + U.hi
+        "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
+        "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo = (lo.hi, carry)
+        "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi   -> hi = (hl, hh) = (v122, v123)
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
+        "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh, lo = (v116, v120)
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // borrow: t0 -= 2^32-1
+        "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
+        "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
+        : "=&v"(rl), "=&v"(rh)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+    return pack64(rl, rh);
 }
 
 __device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
