@@ -40,6 +40,7 @@ struct DeviceState {
     bool have_tables = false;
     NttTables tables;
     std::vector<CosetTables> cosets;
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
 std::mutex g_mu;
 DeviceState g_dev[64];
@@ -56,6 +57,23 @@ hipError_t get_tables(const NttTables **out) {
         st.have_tables = true;
     }
     *out = &st.tables;
+    return hipSuccess;
+}
+
+hipError_t get_events(hipEvent_t *a, hipEvent_t *b) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (!st.ev[0]) {
+        for (int i = 0; i < 2; i++) {
+            e = hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    }
+    *a = st.ev[0];
+    *b = st.ev[1];
     return hipSuccess;
 }
 
@@ -146,12 +164,24 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     HIP_TRY(get_tables(&tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
+    (void)sync_stream2_before_leaves;
+    hipEvent_t ev_lde = nullptr, ev_tr = nullptr;
+    if (d_leaves) {
+        // The leaf-major copy is pure HBM traffic and the Poseidon hashing pure integer ALU work:
+        // run the transpose on stream2, concurrently with the tree on stream. It starts after the LDE
+        // (event) and after whatever the caller queued on stream2 before this call — the reference's
+        // caller has its D2H of the coefficients there (oracle.rs:403-407), which is exactly what
+        // must finish before region A is overwritten (plonky2_gpu.cu:586), now by stream order
+        // instead of a host-side stream synchronise.
+        HIP_TRY(get_events(&ev_lde, &ev_tr));
+        HIP_TRY(hipEventRecord(ev_lde, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream2, ev_lde, 0));
+        HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, (uint32_t)(poly_num + salt_size), n_ext, n_ext, s->stream2));
+        HIP_TRY(hipEventRecord(ev_tr, s->stream2));
+    }
     HIP_TRY(merkle_tree_from_columns(d_lde, (uint32_t)(poly_num + salt_size), n_ext, n_ext, cap_height, d_digests, d_cap,
                                      s->stream));
-    if (d_leaves) {
-        if (sync_stream2_before_leaves) HIP_TRY(hipStreamSynchronize(s->stream2));  // plonky2_gpu.cu:586
-        HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, (uint32_t)(poly_num + salt_size), n_ext, n_ext, s->stream));
-    }
+    if (d_leaves) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr, 0));
     return ok();
 }
 

@@ -224,9 +224,45 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
 __device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
 
 // acc + x*y (goldilocks_field.rs:119-123); u64 + u64*u64 cannot overflow 128 bits.
+// Same schedule as mul(): the addend's low word rides on the first v_mad_u64_u32 and its high
+// word joins T.hi before the second one (al*bh + T.hi + c.hi <= 2^64 - 1).
 __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
-    u128 t = (u128)x * (u128)y + (u128)acc;
-    return reduce128((uint64_t)t, (uint64_t)(t >> 64));
+    uint32_t al = (uint32_t)x, ah = (uint32_t)(x >> 32), bl = (uint32_t)y, bh = (uint32_t)(y >> 32);
+    uint32_t cl = (uint32_t)acc, ch = (uint32_t)(acc >> 32);
+    uint32_t rl, rh;
+    asm("v_mov_b32_e32 v125, 0\n\t"
+        "v_mov_b32_e32 v124, %6\n\t"                            // X = (c.lo, 0)
+        "v_mad_u64_u32 v[116:117], vcc, %2, %4, v[124:125]\n\t" // T = al*bl + c.lo
+        "v_add_co_u32_e32 v124, vcc, v117, %7\n\t"              // X = T.hi + c.hi (33 bits)
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 v125, vcc, 0, v125, vcc\n\t"
+        "v_mad_u64_u32 v[118:119], vcc, %2, %5, v[124:125]\n\t" // U = al*bh + X
+        "v_mov_b32_e32 v125, 0\n\t"
+        "v_mov_b32_e32 v124, v119\n\t"                          // X = (U.hi, 0)
+        "v_mad_u64_u32 v[122:123], vcc, %3, %5, v[124:125]\n\t" // W = ah*bh + U.hi
+        "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
+        "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo
+        "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
+        "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+        "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
+        : "=&v"(rl), "=&v"(rh)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh), "v"(cl), "v"(ch)
+        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+    return pack64(rl, rh);
 }
 
 // Two radix-2 butterflies at once on arbitrary representatives:
