@@ -51,6 +51,7 @@ struct PassParams {
     uint64_t in_sa, in_sb, in_sz, in_t, in_m;
     uint64_t out_sa, out_sb, out_sz, out_t, out_m;
     uint64_t scale;      // multiplied into every output (1 = none)
+    uint64_t chain_scale;  // folded into the inter-pass twiddle chain start (1 = none): n^-1 of the inverse
     uint32_t logt;       // log2 T
     uint32_t t_limit;    // valid range of b*T + t
     uint32_t flags;
@@ -58,6 +59,8 @@ struct PassParams {
     uint32_t tw_hi;      // inter-pass twiddle root = w_{2^tw_hi}
     uint32_t cs_hi_len;  // entries per coset in cs_hi
     uint32_t rate_bits;  // F_COSET: blockIdx.z = coset r, written to block bitrev(r)
+    uint32_t row_shift;  // inverse natural-order row pass: rotate the row tile by one so that the
+                         // flipped 64-byte output segments are aligned (t_limit is a power of two)
 };
 
 template <int I, int N, class F>
@@ -174,6 +177,7 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
             uint64_t sl = gl::mul(p.cs_hi[r * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[r * 1024 + (uint32_t)(L & 1023)]);
             c = gl::mul(c, sl);
         }
+        if (p.chain_scale != 1) c = gl::mul(c, p.chain_scale);
         uint64_t step = wpow(p, L << (LOGR - 4));
         static_for<0, 16>([&](auto J_) {
             constexpr int j = decltype(J_)::value;
@@ -274,7 +278,12 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
             uint32_t c = tid + it * NT;
             uint32_t t = c & (T - 1), m = (c >> logt) * 2;
             u64x2 val = {0, 0};
-            if (b * T + t < p.t_limit) val = *reinterpret_cast<const u64x2 *>(p.src + in_base + (uint64_t)t * p.in_t + m);
+            if (p.row_shift) {
+                uint32_t row = (b * T + t + p.row_shift) & (p.t_limit - 1);
+                val = *reinterpret_cast<const u64x2 *>(p.src + a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t + m);
+            } else if (b * T + t < p.t_limit) {
+                val = *reinterpret_cast<const u64x2 *>(p.src + in_base + (uint64_t)t * p.in_t + m);
+            }
             data[phys((m << logt) + t, logt)] = val.x;
             data[phys(((m + 1) << logt) + t, logt)] = val.y;
         }
@@ -310,6 +319,11 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
             uint64_t o = out_base + t + (uint64_t)m * p.out_m;
             if (!inverse) {
                 *reinterpret_cast<u64x2 *>(p.dst + o) = val;
+            } else if (p.row_shift) {
+                uint64_t ob = a * p.out_sa + zo * p.out_sz + (uint64_t)m * p.out_m;
+                uint32_t r0 = (b * T + t + p.row_shift) & (p.t_limit - 1), r1 = (b * T + t + 1 + p.row_shift) & (p.t_limit - 1);
+                p.dst[flip_index(ob + r0, p.log_n)] = val.x;
+                p.dst[flip_index(ob + r1, p.log_n)] = val.y;
             } else {
                 p.dst[flip_index(o, p.log_n)] = val.x;
                 p.dst[flip_index(o + 1, p.log_n)] = val.y;
@@ -390,6 +404,7 @@ static void base_params(PassParams &p, const NttTables &tb) {
     p.twl = tb.twl;
     p.twh = tb.twh;
     p.scale = 1;
+    p.chain_scale = 1;
 }
 
 hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, uint64_t n_polys, uint32_t log_n,
@@ -470,6 +485,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.flags = natural ? F_NATURAL : 0;
             p.log_n = log_n;
             p.tw_hi = log_n;
+            p.chain_scale = n_inv;  // the inverse's n^-1 rides on the twiddle chain (1 multiply per thread)
             hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)cnt, 1), stream);
             if (e != hipSuccess) return e;
             // pass B
@@ -484,12 +500,12 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.in_m = 1;
             p.out_sa = dst_stride;
             p.log_n = log_n;
-            p.scale = n_inv;
             if (natural) {
                 p.out_sb = TB;
                 p.out_t = 1;
                 p.out_m = N1;
                 p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
+                p.row_shift = inverse ? 1 : 0;
             } else {
                 p.out_sb = (uint64_t)TB * N2;
                 p.out_t = N2;
@@ -539,6 +555,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.flags = natural ? F_NATURAL : 0;
             p.log_n = log_n;
             p.tw_hi = log_n;
+            p.chain_scale = n_inv;
             hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N23 / T1), (unsigned)cnt, 1), stream);
             if (e != hipSuccess) return e;
             base_params(p, tb);
@@ -569,8 +586,8 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.in_m = 1;
             p.out_sa = dst_stride;
             p.log_n = log_n;
-            p.scale = n_inv;
             if (natural) {
+                p.row_shift = inverse ? 1 : 0;
                 // tile = T3 rows with consecutive k1 at fixed k2 (blockIdx.z): row (k1, k2) starts at (k1*N2 + k2)*N3
                 p.t_limit = (uint32_t)N1;
                 p.in_sb = (uint64_t)T3 * N23;
