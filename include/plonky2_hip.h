@@ -100,6 +100,43 @@ GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t p
 GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, uint64_t shift, int inverse,
                            void *ctx);
 
+/* Partial products and Z of the permutation argument for every challenge
+ * (wires_permutation_partial_products_and_zs, plonky2/src/plonk/prover.rs:702-786;
+ * quotient_chunk_products / partial_products_and_z_gx, plonky2/src/util/partial_products.rs:13-37).
+ *   d_wires [>= num_routed][2^log_n] column-major, column stride wires_stride (the witness layout)
+ *   d_sigmas [num_routed][2^log_n] column-major (prover_data.sigmas transposed), d_k_is [num_routed]
+ *   h_betas / h_gammas: HOST arrays of num_challenges elements
+ *   d_out [num_challenges * (1 + num_prods)][2^log_n], num_prods = ceil(num_routed / qdf) - 1, in the
+ *   order the prover commits them: every Z first, then the partial products challenge-major
+ *   (prover.rs:112-117) — ready for gl_commit_from_values. */
+GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_stride, const uint64_t *d_sigmas,
+                                        uint64_t sigmas_stride, const uint64_t *d_k_is, const uint64_t *h_betas,
+                                        const uint64_t *h_gammas, uint32_t num_challenges, uint32_t num_routed,
+                                        uint32_t quotient_degree_factor, uint32_t log_n, uint64_t *d_out, void *ctx);
+
+/* compute_quotient_polys (plonky2/src/plonk/prover.rs:790-1034) for any circuit: the permutation
+ * terms, L_0(x)(Z(x)-1), the alpha reduction and the division by Z_H are evaluated here
+ * (plonk/vanishing_poly.rs:100-226, plonk_common.rs:97-114, field/src/zero_poly_coset.rs); the
+ * circuit-specific gate-constraint terms are an INPUT, one row of num_gate_constraints values per
+ * LDE point in natural point order (NULL = no gate constraints). The three *_leaves pointers are the
+ * leaf-major LDE rows of the commitments (d_leaves of gl_commit_*), read at leaf
+ * reverse_bits(i * step) like PolynomialBatch::get_lde_values (fri/oracle.rs:1007-1018).
+ * d_quotient_polys [num_challenges][n << log2_ceil(qdf)] receives the COEFFICIENTS (after coset_ifft,
+ * prover.rs:1009-1021); chunking into degree-n pieces is a reinterpretation (prover.rs:153-166). */
+typedef struct GlQuotientArgs {
+    const uint64_t *d_wires_leaves;
+    const uint64_t *d_constants_sigmas_leaves;
+    const uint64_t *d_zs_partial_products_leaves;
+    uint32_t wires_leaf_len, constants_sigmas_leaf_len, zs_partial_products_leaf_len;
+    const uint64_t *d_k_is;
+    const uint64_t *d_gate_constraint_terms; /* may be NULL */
+    const uint64_t *h_betas, *h_gammas, *h_alphas; /* HOST, num_challenges each */
+    uint32_t num_constants, num_routed_wires, num_challenges, num_gate_constraints;
+    uint32_t degree_bits, rate_bits, quotient_degree_factor;
+    uint64_t coset_shift; /* F::coset_shift() = 7 */
+} GlQuotientArgs;
+GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx);
+
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
 

@@ -100,6 +100,17 @@ def fast_ntt(a, inverse=False):
     return r
 
 
+def coset_idft_fast(values, shift=GENERATOR):
+    """coset_ifft via the O(n log n) transform (for the quotient-polynomial fixtures)."""
+    c = fast_ntt(values, inverse=True)
+    s_inv = pow(shift, P - 2, P)
+    out, r = [], 1
+    for x in c:
+        out.append(x * r % P)
+        r = r * s_inv % P
+    return out
+
+
 # ---------------------------------------------------------------- Poseidon (textbook)
 
 def _load_constants():

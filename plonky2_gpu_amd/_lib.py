@@ -17,6 +17,30 @@ class GlDataSlice(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("len", ctypes.c_int)]
 
 
+class GlQuotientArgs(ctypes.Structure):
+    _fields_ = [
+        ("d_wires_leaves", ctypes.c_void_p),
+        ("d_constants_sigmas_leaves", ctypes.c_void_p),
+        ("d_zs_partial_products_leaves", ctypes.c_void_p),
+        ("wires_leaf_len", ctypes.c_uint32),
+        ("constants_sigmas_leaf_len", ctypes.c_uint32),
+        ("zs_partial_products_leaf_len", ctypes.c_uint32),
+        ("d_k_is", ctypes.c_void_p),
+        ("d_gate_constraint_terms", ctypes.c_void_p),
+        ("h_betas", ctypes.c_void_p),
+        ("h_gammas", ctypes.c_void_p),
+        ("h_alphas", ctypes.c_void_p),
+        ("num_constants", ctypes.c_uint32),
+        ("num_routed_wires", ctypes.c_uint32),
+        ("num_challenges", ctypes.c_uint32),
+        ("num_gate_constraints", ctypes.c_uint32),
+        ("degree_bits", ctypes.c_uint32),
+        ("rate_bits", ctypes.c_uint32),
+        ("quotient_degree_factor", ctypes.c_uint32),
+        ("coset_shift", ctypes.c_uint64),
+    ]
+
+
 class Plonky2HipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"plonky2_hip error {code}: {message}")
@@ -48,6 +72,8 @@ SIGNATURES = {
     "gl_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _i, _i, _vp]),
     "gl_coset_lde_batch": (GlError, [_vp, _vp, _u64, _u32, _u32, _u64, _u64, _u64, _vp]),
     "gl_coset_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _u64, _i, _vp]),
+    "gl_permutation_partial_products": (GlError, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 #include "gl_field.cuh"
 #include "merkle.h"
 #include "ntt.h"
+#include "plonk.h"
 
 using namespace plonky2_hip;
 
@@ -339,6 +340,62 @@ GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n
     HIP_TRY(get_coset_tables(log_n, 0, glh::inv(shift), S(ctx)->stream, &ct));
     HIP_TRY(scale_by_powers(*ct, d_values, poly_num, stride, S(ctx)->stream));
     return ok();
+}
+
+GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_stride, const uint64_t *d_sigmas,
+                                        uint64_t sigmas_stride, const uint64_t *d_k_is, const uint64_t *h_betas,
+                                        const uint64_t *h_gammas, uint32_t num_challenges, uint32_t num_routed,
+                                        uint32_t quotient_degree_factor, uint32_t log_n, uint64_t *d_out, void *ctx) {
+    if (!ctx || !d_wires || !d_sigmas || !d_k_is || !h_betas || !h_gammas || !d_out) return fail(GL_E_INVALID, "null pointer");
+    if (num_challenges == 0 || num_challenges > 4) return fail(GL_E_INVALID, "num_challenges must be 1..4");
+    if (quotient_degree_factor < 2 || num_routed == 0) return fail(GL_E_INVALID, "bad num_routed / quotient_degree_factor");
+    if (quotient_degree_factor >= num_routed)
+        return fail(GL_E_INVALID, "quotient_degree_factor must be smaller than num_routed_wires (prover.rs:102-105)");
+    if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(permutation_partial_products(*tb, d_wires, wires_stride, d_sigmas, sigmas_stride, d_k_is, h_betas, h_gammas,
+                                         num_challenges, num_routed, quotient_degree_factor, log_n, d_out, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx) {
+    if (!ctx || !args || !d_quotient_polys) return fail(GL_E_INVALID, "null pointer");
+    if (!args->d_wires_leaves || !args->d_constants_sigmas_leaves || !args->d_zs_partial_products_leaves || !args->d_k_is ||
+        !args->h_betas || !args->h_gammas || !args->h_alphas)
+        return fail(GL_E_INVALID, "null pointer in GlQuotientArgs");
+    QuotientArgs a = {};
+    a.wires_leaves = args->d_wires_leaves;
+    a.cs_leaves = args->d_constants_sigmas_leaves;
+    a.zpp_leaves = args->d_zs_partial_products_leaves;
+    a.wires_len = args->wires_leaf_len;
+    a.cs_len = args->constants_sigmas_leaf_len;
+    a.zpp_len = args->zs_partial_products_leaf_len;
+    a.k_is = args->d_k_is;
+    a.gate_terms = args->d_gate_constraint_terms;
+    a.betas = args->h_betas;
+    a.gammas = args->h_gammas;
+    a.alphas = args->h_alphas;
+    a.num_constants = args->num_constants;
+    a.num_routed = args->num_routed_wires;
+    a.num_challenges = args->num_challenges;
+    a.num_gate_constraints = args->num_gate_constraints;
+    a.degree_bits = args->degree_bits;
+    a.rate_bits = args->rate_bits;
+    a.quotient_degree_factor = args->quotient_degree_factor;
+    a.shift = args->coset_shift;
+    uint32_t qdb = 0;
+    while ((1u << qdb) < a.quotient_degree_factor) qdb++;
+    if (a.quotient_degree_factor < 2 || qdb > a.rate_bits)
+        return fail(GL_E_INVALID, "constraints of degree higher than the rate are not supported (prover.rs:807-811)");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    hipError_t e = quotient_values(*tb, a, d_quotient_polys, S(ctx)->stream);
+    if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "inconsistent GlQuotientArgs (leaf lengths / counts / sizes)");
+    HIP_TRY(e);
+    // values on the coset -> coefficients: coset_ifft per challenge (prover.rs:1009-1021)
+    const uint32_t log_lde = a.degree_bits + qdb;
+    return gl_coset_ntt_batch(d_quotient_polys, a.num_challenges, log_lde, 1ull << log_lde, a.shift, 1, ctx);
 }
 
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx) {

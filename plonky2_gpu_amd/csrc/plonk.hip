@@ -1,0 +1,291 @@
+// plonk.hip — the permutation-argument stage of the prover on the device:
+//   (1) partial products and Z      wires_permutation_partial_products_and_zs (plonky2/src/plonk/prover.rs:729-786,
+//                                    plonky2/src/util/partial_products.rs:13-37)
+//   (2) quotient values             compute_quotient_polys (prover.rs:790-1034) over eval_vanishing_poly_base_batch
+//                                    (plonky2/src/plonk/vanishing_poly.rs:100-226) with the gate-constraint terms
+//                                    supplied per point by the caller (the circuit-specific part)
+// The reference keeps (1) on the host even in its GPU prover (prover.rs:322-326) — it forces a D2H/H2D
+// round trip of the witness — and hard-wires (2) to one circuit (cuda/plonky2_gpu_impl.cuh:485-878).
+//
+// (1) is data-parallel over rows except for Z, which is a prefix product over the rows: each
+// thread forms its row's chunk quotients (one Fermat inversion per chunk; the reference batches
+// the inversions per row, same values), the running product is a three-kernel block scan.
+// (2) is one thread per LDE point reading its leaf rows; terms are reduced with powers of alpha
+// exactly in the reference's order (plonk_common.rs:97-114).
+#include "plonk.h"
+
+#include "gl_field.cuh"
+
+namespace plonky2_hip {
+
+namespace {
+
+constexpr int MAX_CHALLENGES = 4;
+constexpr int MAX_TERMS = 160;  // num_challenges * (1 + chunks) permutation terms kept per thread
+
+struct Challenges {
+    uint64_t beta[MAX_CHALLENGES], gamma[MAX_CHALLENGES], alpha[MAX_CHALLENGES];
+};
+
+// w_{2^log}^i through the two-level table of w_{2^24}
+__device__ __forceinline__ uint64_t root_pow(const uint64_t *twl, const uint64_t *twh, uint32_t log, uint64_t i) {
+    uint32_t e = (uint32_t)(i << (24 - log)) & 0xFFFFFFu;
+    uint64_t h = twh[e >> 12];
+    uint32_t lo = e & 4095u;
+    return lo ? gl::mul(h, twl[lo]) : h;
+}
+
+__device__ __forceinline__ uint64_t inverse(uint64_t x) { return gl::pow(x, gl::P - 2); }
+
+// One thread per (row i, challenge c): cumulative chunk quotients c_k(i) = prod_{m<=k} q_m(i) written to
+// the partial-product slots (k < num_prods) and the row total r_i to the Z slot.
+__global__ __launch_bounds__(256) void perm_quotients_kernel(const uint64_t *__restrict__ wires, uint64_t wires_stride,
+                                                             const uint64_t *__restrict__ sigmas, uint64_t sigmas_stride,
+                                                             const uint64_t *__restrict__ k_is, Challenges ch,
+                                                             uint32_t num_challenges, uint32_t num_routed, uint32_t degree,
+                                                             uint32_t num_prods, uint32_t log_n, const uint64_t *twl,
+                                                             const uint64_t *twh, uint64_t *__restrict__ out) {
+    const uint64_t n = 1ull << log_n;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * num_challenges) return;
+    uint64_t i = g & (n - 1);
+    uint32_t c = (uint32_t)(g >> log_n);
+    const uint64_t beta = ch.beta[c], gamma = ch.gamma[c];
+    const uint64_t bx = gl::mul(beta, root_pow(twl, twh, log_n, i));  // beta * x, x = w_n^i (prover_data.subgroup)
+    uint64_t *z_slot = out + (uint64_t)c * n;
+    uint64_t *pp_base = out + ((uint64_t)num_challenges + (uint64_t)c * num_prods) * n;
+    uint64_t cum = 1;
+    uint32_t k = 0;
+    for (uint32_t j0 = 0; j0 < num_routed; j0 += degree, k++) {
+        uint64_t num = 1, den = 1;
+        uint32_t j1 = j0 + degree < num_routed ? j0 + degree : num_routed;
+        for (uint32_t j = j0; j < j1; j++) {
+            uint64_t w = wires[j * wires_stride + i];
+            uint64_t wg = gl::add(w, gamma);
+            num = gl::mul(num, gl::add(wg, gl::mul(bx, k_is[j])));                      // w + beta*k_j*x + gamma
+            den = gl::mul(den, gl::add(wg, gl::mul(beta, sigmas[j * sigmas_stride + i])));  // w + beta*sigma + gamma
+        }
+        cum = gl::mul(cum, gl::mul(num, inverse(den)));
+        if (k < num_prods)
+            pp_base[(uint64_t)k * n + i] = gl::canon(cum);
+        else
+            z_slot[i] = gl::canon(cum);
+    }
+}
+
+// ---- exclusive prefix product over rows (three kernels) ---------------------------------------
+constexpr int SCAN_T = 256, SCAN_E = 4, SCAN_B = SCAN_T * SCAN_E;
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *lds, uint64_t *total) {
+    const uint32_t t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+        uint64_t x = (t >= (uint32_t)off) ? gl::mul(lds[t - off], lds[t]) : lds[t];
+        __syncthreads();
+        lds[t] = x;
+        __syncthreads();
+    }
+    uint64_t incl = lds[t];
+    uint64_t excl = t ? lds[t - 1] : 1;
+    if (total && t == SCAN_T - 1) *total = incl;
+    __syncthreads();
+    return excl;
+}
+
+// in place: v[i] <- product of the block's earlier elements; totals[blk] <- product of the block
+__global__ __launch_bounds__(SCAN_T) void scan_blocks_kernel(uint64_t *v, uint64_t n, uint64_t col_stride, uint64_t *totals,
+                                                             uint64_t totals_stride) {
+    __shared__ uint64_t lds[SCAN_T];
+    uint64_t *col = v + (uint64_t)blockIdx.y * col_stride;
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_B + (uint64_t)threadIdx.x * SCAN_E;
+    uint64_t e[SCAN_E];
+    uint64_t p = 1;
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) {
+        e[k] = base + k < n ? col[base + k] : 1;
+        p = gl::mul(p, e[k]);
+    }
+    uint64_t excl = block_exclusive_scan(p, lds, totals + (uint64_t)blockIdx.y * totals_stride + blockIdx.x);
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) {
+        if (base + k < n) col[base + k] = gl::canon(excl);
+        excl = gl::mul(excl, e[k]);
+    }
+}
+
+// exclusive scan of m block totals per column by one workgroup
+__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(uint64_t *totals, uint64_t m, uint64_t totals_stride) {
+    __shared__ uint64_t lds[SCAN_T];
+    uint64_t *t = totals + (uint64_t)blockIdx.x * totals_stride;
+    uint64_t per = (m + SCAN_T - 1) / SCAN_T;
+    uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+    uint64_t p = 1;
+    for (uint64_t i = lo; i < hi; i++) p = gl::mul(p, t[i]);
+    uint64_t excl = block_exclusive_scan(p, lds, nullptr);
+    for (uint64_t i = lo; i < hi; i++) {
+        uint64_t x = t[i];
+        t[i] = excl;
+        excl = gl::mul(excl, x);
+    }
+}
+
+// Z[i] = block prefix * local exclusive; pp_k[i] = Z[i] * c_k(i)
+__global__ __launch_bounds__(256) void perm_finalize_kernel(uint64_t *out, const uint64_t *totals, uint64_t totals_stride,
+                                                            uint32_t num_challenges, uint32_t num_prods, uint32_t log_n) {
+    const uint64_t n = 1ull << log_n;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * num_challenges) return;
+    uint64_t i = g & (n - 1);
+    uint32_t c = (uint32_t)(g >> log_n);
+    uint64_t z = gl::mul(out[(uint64_t)c * n + i], totals[(uint64_t)c * totals_stride + i / SCAN_B]);
+    out[(uint64_t)c * n + i] = gl::canon(z);
+    uint64_t *pp_base = out + ((uint64_t)num_challenges + (uint64_t)c * num_prods) * n;
+    for (uint32_t k = 0; k < num_prods; k++) pp_base[(uint64_t)k * n + i] = gl::canon(gl::mul(z, pp_base[(uint64_t)k * n + i]));
+}
+
+// ---- quotient values ---------------------------------------------------------------------------
+struct QuotientParams {
+    const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves, *k_is, *gate_terms, *twl, *twh;
+    uint64_t *out;  // [num_challenges][lde_size]
+    uint32_t wires_len, cs_len, zpp_len, num_constants, num_routed, num_challenges, degree, num_prods;
+    uint32_t degree_bits, rate_bits, qdb, num_gate_constraints;
+    uint64_t shift, g_pow_n;
+    Challenges ch;
+};
+
+__global__ __launch_bounds__(128) void quotient_values_kernel(const QuotientParams p) {
+    const uint32_t log_lde = p.degree_bits + p.qdb;
+    const uint64_t lde_size = 1ull << log_lde, n = 1ull << p.degree_bits;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lde_size) return;
+    const uint32_t bits = p.degree_bits + p.rate_bits, step_log = p.rate_bits - p.qdb;
+    // get_lde_values(i, step): leaf reverse_bits(i*step) (fri/oracle.rs:1007-1018); next point i + next_step
+    uint64_t leaf = bits ? (__brevll(i << step_log) >> (64 - bits)) : 0;
+    uint64_t i_next = (i + (1ull << p.qdb)) & (lde_size - 1);
+    uint64_t leaf_next = bits ? (__brevll(i_next << step_log) >> (64 - bits)) : 0;
+    const uint64_t *wires = p.wires_leaves + leaf * p.wires_len;
+    const uint64_t *sig = p.cs_leaves + leaf * p.cs_len + p.num_constants;
+    const uint64_t *zpp = p.zpp_leaves + leaf * p.zpp_len;
+    const uint64_t *zpp_next = p.zpp_leaves + leaf_next * p.zpp_len;
+
+    const uint64_t x = gl::mul(p.shift, root_pow(p.twl, p.twh, log_lde, i));  // shifted_x (prover.rs:903)
+    // Z_H(x) = g^n * v^(i mod rate) - 1 (field/src/zero_poly_coset.rs:20-41)
+    const uint64_t v = p.qdb ? root_pow(p.twl, p.twh, p.qdb, i & ((1ull << p.qdb) - 1)) : 1;
+    const uint64_t zh = gl::sub(gl::mul(p.g_pow_n, v), 1);
+    const uint64_t zh_inv = inverse(zh);
+    const uint64_t l0 = gl::mul(zh, inverse(gl::mul(n, gl::sub(x, 1))));  // eval_l_0 (zero_poly_coset.rs:57-60)
+
+    uint64_t terms[MAX_TERMS];
+    uint32_t nt = 0;
+    for (uint32_t c = 0; c < p.num_challenges; c++) terms[nt++] = gl::mul(l0, gl::sub(zpp[c], 1));
+    for (uint32_t c = 0; c < p.num_challenges; c++) {
+        const uint64_t beta = p.ch.beta[c], gamma = p.ch.gamma[c];
+        const uint64_t bx = gl::mul(beta, x);
+        uint64_t prev = zpp[c];
+        uint32_t k = 0;
+        for (uint32_t j0 = 0; j0 < p.num_routed; j0 += p.degree, k++) {
+            uint64_t num = 1, den = 1;
+            uint32_t j1 = j0 + p.degree < p.num_routed ? j0 + p.degree : p.num_routed;
+            for (uint32_t j = j0; j < j1; j++) {
+                uint64_t wg = gl::add(wires[j], gamma);
+                num = gl::mul(num, gl::add(wg, gl::mul(bx, p.k_is[j])));
+                den = gl::mul(den, gl::add(wg, gl::mul(beta, sig[j])));
+            }
+            uint64_t next = (k < p.num_prods) ? zpp[p.num_challenges + c * p.num_prods + k] : zpp_next[c];
+            // check_partial_products (util/partial_products.rs:52-76): prev*num - next*den
+            terms[nt++] = gl::sub(gl::mul(prev, num), gl::mul(next, den));
+            prev = next;
+        }
+    }
+    // reduce_with_powers_multi (plonk_common.rs:97-114): Horner from the LAST term over
+    // [L_0 (Z-1)] | [partial-product checks] | [gate constraints]
+    const uint64_t *gt = p.gate_terms ? p.gate_terms + i * p.num_gate_constraints : nullptr;
+    for (uint32_t c = 0; c < p.num_challenges; c++) {
+        const uint64_t alpha = p.ch.alpha[c];
+        uint64_t cumul = 0;
+        if (gt)
+            for (uint32_t t = p.num_gate_constraints; t-- > 0;) cumul = gl::mac(gt[t], cumul, alpha);
+        for (uint32_t t = nt; t-- > 0;) cumul = gl::mac(terms[t], cumul, alpha);
+        p.out[(uint64_t)c * lde_size + i] = gl::canon(gl::mul(cumul, zh_inv));  // prover.rs:985-991
+    }
+}
+
+unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace
+
+uint32_t num_partial_products(uint32_t num_routed, uint32_t degree) { return (num_routed + degree - 1) / degree - 1; }
+
+hipError_t permutation_partial_products(const NttTables &tb, const uint64_t *wires, uint64_t wires_stride, const uint64_t *sigmas,
+                                        uint64_t sigmas_stride, const uint64_t *k_is, const uint64_t *betas, const uint64_t *gammas,
+                                        uint32_t num_challenges, uint32_t num_routed, uint32_t degree, uint32_t log_n, uint64_t *out,
+                                        hipStream_t stream) {
+    if (num_challenges == 0 || num_challenges > MAX_CHALLENGES || degree < 2 || num_routed == 0 || log_n > 24)
+        return hipErrorInvalidValue;
+    const uint64_t n = 1ull << log_n;
+    const uint32_t num_prods = num_partial_products(num_routed, degree);
+    Challenges ch = {};
+    for (uint32_t c = 0; c < num_challenges; c++) {
+        ch.beta[c] = betas[c] % glh::P;
+        ch.gamma[c] = gammas[c] % glh::P;
+    }
+    hipLaunchKernelGGL(perm_quotients_kernel, dim3(grid_for(n * num_challenges, 256)), dim3(256), 0, stream, wires, wires_stride,
+                       sigmas, sigmas_stride, k_is, ch, num_challenges, num_routed, degree, num_prods, log_n, tb.twl, tb.twh, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // Z(x_i) = prod_{t<i} r_t: exclusive prefix product of the Z slots (Z(1) = 1)
+    const uint64_t blocks = (n + SCAN_B - 1) / SCAN_B;
+    if (!tb.scratch || tb.scratch_elems < blocks * num_challenges) return hipErrorInvalidValue;
+    uint64_t *totals = tb.scratch;
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)blocks, num_challenges), dim3(SCAN_T), 0, stream, out, n, n, totals, blocks);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(num_challenges), dim3(SCAN_T), 0, stream, totals, blocks, blocks);
+    hipLaunchKernelGGL(perm_finalize_kernel, dim3(grid_for(n * num_challenges, 256)), dim3(256), 0, stream, out, totals, blocks,
+                       num_challenges, num_prods, log_n);
+    return hipGetLastError();
+}
+
+hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t *out, hipStream_t stream) {
+    if (a.num_challenges == 0 || a.num_challenges > MAX_CHALLENGES || a.quotient_degree_factor < 2 || a.num_routed == 0)
+        return hipErrorInvalidValue;
+    uint32_t qdb = 0;
+    while ((1u << qdb) < a.quotient_degree_factor) qdb++;  // log2_ceil
+    if (qdb > a.rate_bits || a.degree_bits + qdb > 24) return hipErrorInvalidValue;
+    const uint32_t num_prods = num_partial_products(a.num_routed, a.quotient_degree_factor);
+    if (a.num_challenges * (2 + num_prods) > MAX_TERMS) return hipErrorInvalidValue;
+    if (a.zpp_len < a.num_challenges * (1 + num_prods) || a.cs_len < a.num_constants + a.num_routed || a.wires_len < a.num_routed)
+        return hipErrorInvalidValue;
+    QuotientParams p = {};
+    p.wires_leaves = a.wires_leaves;
+    p.cs_leaves = a.cs_leaves;
+    p.zpp_leaves = a.zpp_leaves;
+    p.k_is = a.k_is;
+    p.gate_terms = a.gate_terms;
+    p.twl = tb.twl;
+    p.twh = tb.twh;
+    p.out = out;
+    p.wires_len = a.wires_len;
+    p.cs_len = a.cs_len;
+    p.zpp_len = a.zpp_len;
+    p.num_constants = a.num_constants;
+    p.num_routed = a.num_routed;
+    p.num_challenges = a.num_challenges;
+    p.degree = a.quotient_degree_factor;
+    p.num_prods = num_prods;
+    p.degree_bits = a.degree_bits;
+    p.rate_bits = a.rate_bits;
+    p.qdb = qdb;
+    p.num_gate_constraints = a.gate_terms ? a.num_gate_constraints : 0;
+    p.shift = a.shift % glh::P;
+    p.g_pow_n = glh::pow(p.shift, 1ull << a.degree_bits);
+    for (uint32_t c = 0; c < a.num_challenges; c++) {
+        p.ch.beta[c] = a.betas[c] % glh::P;
+        p.ch.gamma[c] = a.gammas[c] % glh::P;
+        p.ch.alpha[c] = a.alphas[c] % glh::P;
+    }
+    const uint64_t lde_size = 1ull << (a.degree_bits + qdb);
+    hipLaunchKernelGGL(quotient_values_kernel, dim3(grid_for(lde_size, 128)), dim3(128), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace plonky2_hip

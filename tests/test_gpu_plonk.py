@@ -1,0 +1,104 @@
+"""HIP partial products / Z and quotient polynomials vs oracle/plonk_ref.py (itself pinned by the
+verifier identity in test_oracle_plonk.py). Bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from gpu_util import gpu  # noqa: F401
+from oracle import plonk_ref, pyref
+from plonk_instance import lde_leaves, make_instance, poly_eval
+
+pytestmark = pytest.mark.gpu
+P = pyref.P
+
+
+def cols(a):
+    return np.array(a, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("num_routed,degree_bits,qdf,num_ch", [(10, 4, 8, 2), (17, 3, 8, 2), (16, 5, 8, 1), (80, 6, 8, 2),
+                                                               (9, 11, 4, 3), (12, 13, 8, 2)])
+def test_partial_products_and_zs(gpu, num_routed, degree_bits, qdf, num_ch):
+    import plonky2_gpu_amd as pg
+
+    inst = make_instance(degree_bits=degree_bits, num_wires=num_routed + 3, num_routed=num_routed, num_challenges=num_ch,
+                         seed=num_routed * 7 + degree_bits, valid=(degree_bits <= 6))
+    n = inst["n"]
+    if degree_bits > 8:  # big sizes: random (not copy-consistent) data is enough for kernel-vs-oracle parity
+        rng = np.random.default_rng(degree_bits)
+        for key in ("wires", "sigmas"):
+            inst[key] = [[int(v) % P for v in rng.integers(0, 2**63, size=n)] for _ in inst[key]]
+    exp = plonk_ref.zs_partial_products(inst["wires"], inst["sigmas"], inst["k_is"], inst["betas"], inst["gammas"], qdf,
+                                        inst["subgroup"])
+    d_w = pg.DeviceBuffer.from_host(gpu, cols(inst["wires"]))
+    d_s = pg.DeviceBuffer.from_host(gpu, cols(inst["sigmas"]))
+    d_k = pg.DeviceBuffer.from_host(gpu, cols(inst["k_is"]))
+    out, n_cols = pg.all_wires_permutation_partial_products(gpu, d_w, n, d_s, n, d_k, inst["betas"], inst["gammas"], num_routed,
+                                                            qdf, degree_bits)
+    got = out.download().reshape(n_cols, n)
+    assert n_cols == len(exp)
+    assert (got == cols(exp)).all()
+
+
+def test_partial_products_argument_errors(gpu):
+    import plonky2_gpu_amd as pg
+
+    buf = pg.DeviceBuffer(gpu, 1024)
+    with pytest.raises(pg.Plonky2HipError):  # prover.rs:102-105: degree must be < num_routed_wires
+        pg.all_wires_permutation_partial_products(gpu, buf, 16, buf, 16, buf, [1], [2], 8, 8, 4)
+    with pytest.raises(pg.Plonky2HipError):
+        pg.all_wires_permutation_partial_products(gpu, buf, 16, buf, 16, buf, [1] * 5, [2] * 5, 10, 8, 4)
+
+
+@pytest.mark.parametrize("num_routed,degree_bits,qdf,with_gates", [(10, 4, 8, False), (17, 3, 8, True), (12, 5, 4, True),
+                                                                   (80, 6, 8, False)])
+def test_compute_quotient_polys(gpu, oracle, num_routed, degree_bits, qdf, with_gates):
+    """End to end on the device: commit wires / constants+sigmas, partial products + Z, commit
+    them, quotient polynomials — equal to the oracle's, and (valid instance, no gates) satisfying
+    the verifier identity at a random point."""
+    import plonky2_gpu_amd as pg
+
+    rate_bits, cap_h, num_constants = 3, 2, 2
+    inst = make_instance(degree_bits=degree_bits, num_wires=num_routed + 2, num_routed=num_routed, num_constants=num_constants,
+                         seed=100 + num_routed)
+    n, k_is = inst["n"], inst["k_is"]
+    wires_b = pg.PolynomialBatch.from_values(gpu, cols(inst["wires"]), rate_bits, False, cap_h)
+    cs_b = pg.PolynomialBatch.from_values(gpu, cols(inst["constants"] + inst["sigmas"]), rate_bits, False, cap_h)
+    d_w = pg.DeviceBuffer.from_host(gpu, cols(inst["wires"]))
+    d_s = pg.DeviceBuffer.from_host(gpu, cols(inst["sigmas"]))
+    d_k = pg.DeviceBuffer.from_host(gpu, cols(k_is))
+    d_zpp, n_cols = pg.all_wires_permutation_partial_products(gpu, d_w, n, d_s, n, d_k, inst["betas"], inst["gammas"], num_routed,
+                                                              qdf, degree_bits)
+    zpp_host = d_zpp.download().reshape(n_cols, n)
+    zpp_b = pg.PolynomialBatch.from_values_device(gpu, d_zpp, n_cols, degree_bits, rate_bits, False, cap_h)
+    qdb = (qdf - 1).bit_length()
+    lde_size = n << qdb
+    gate_terms, d_gt, ngc = None, None, 0
+    if with_gates:
+        ngc = 5
+        rng = random.Random(9)
+        gate_terms = [[rng.randrange(P) for _ in range(ngc)] for _ in range(lde_size)]
+        d_gt = pg.DeviceBuffer.from_host(gpu, cols(gate_terms))
+    d_q = pg.compute_quotient_polys(gpu, wires_b, cs_b, zpp_b, num_constants, num_routed, d_k, inst["betas"], inst["gammas"],
+                                    inst["alphas"], qdf, d_gt, ngc)
+    got = d_q.download().reshape(2, lde_size)
+    # oracle on the same leaves (taken from the oracle's own commit of the same values)
+    w_c, w_l = lde_leaves(inst["wires"], rate_bits)
+    cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
+    z_c, z_l = lde_leaves(zpp_host.tolist(), rate_bits)
+    exp = plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, num_constants, k_is, inst["betas"], inst["gammas"], inst["alphas"],
+                                           degree_bits, rate_bits, qdf, gate_terms)
+    assert (got == cols(exp)).all()
+    if not with_gates and qdf == 8:
+        zeta = 0x1234567890ABCDEF % P
+        g = pyref.root_of_unity(degree_bits)
+        zh = (pow(zeta, n, P) - 1) % P
+        l0 = zh * plonk_ref.inv(n * (zeta - 1)) % P
+        terms = plonk_ref.vanishing_terms_at(
+            zeta, l0, [poly_eval(c, zeta) for c in w_c], [poly_eval(c, zeta) for c in cs_c[num_constants:]],
+            [poly_eval(z_c[c], zeta) for c in range(2)], [poly_eval(z_c[c], g * zeta % P) for c in range(2)],
+            [poly_eval(c, zeta) for c in z_c[2:]], k_is, inst["betas"], inst["gammas"], qdf, [])
+        red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
+        for c in range(2):
+            assert red[c] == zh * poly_eval([int(v) for v in got[c]], zeta) % P

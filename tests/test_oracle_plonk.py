@@ -1,0 +1,69 @@
+"""Pins oracle/plonk_ref.py (partial products / Z, permutation terms of the vanishing polynomial,
+compute_quotient_polys) with the verifier's identity vanishing(zeta) = Z_H(zeta) * t(zeta)."""
+import random
+
+import pytest
+
+from oracle import plonk_ref, pyref
+from plonk_instance import lde_leaves, make_instance, poly_eval
+
+P = pyref.P
+
+
+@pytest.mark.parametrize("num_routed,degree_bits", [(10, 4), (17, 3), (16, 3)])
+def test_quotient_satisfies_the_verifier_identity(num_routed, degree_bits):
+    qdf, rate_bits = 8, 3
+    inst = make_instance(degree_bits=degree_bits, num_wires=num_routed + 2, num_routed=num_routed, seed=num_routed)
+    n, k_is = inst["n"], inst["k_is"]
+    zpp = plonk_ref.zs_partial_products(inst["wires"], inst["sigmas"], k_is, inst["betas"], inst["gammas"], qdf, inst["subgroup"])
+    num_prods = plonk_ref.num_partial_products(num_routed, qdf)
+    assert len(zpp) == 2 * (1 + num_prods)
+    # Z(1) = 1 and the grand product closes: Z(g^(n-1)) * (last row's total quotient) = 1
+    for c in range(2):
+        assert zpp[c][0] == 1
+    w_c, w_l = lde_leaves(inst["wires"], rate_bits)
+    cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
+    z_c, z_l = lde_leaves(zpp, rate_bits)
+    t = plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, inst["num_constants"], k_is, inst["betas"], inst["gammas"], inst["alphas"],
+                                         degree_bits, rate_bits, qdf)
+    assert len(t) == 2 and len(t[0]) == n * 8
+    # quotient degree: deg(prev_acc * prod of 8 numerators) - n < 8n - 8
+    for c in range(2):
+        assert all(v == 0 for v in t[c][8 * n - 8:])
+    rng = random.Random(5)
+    g = pyref.root_of_unity(degree_bits)
+    for _ in range(3):
+        zeta = rng.randrange(P)
+        wires_z = [poly_eval(c, zeta) for c in w_c]
+        sig_z = [poly_eval(c, zeta) for c in cs_c[inst["num_constants"]:]]
+        zs_z = [poly_eval(z_c[c], zeta) for c in range(2)]
+        zs_gz = [poly_eval(z_c[c], g * zeta % P) for c in range(2)]
+        pp_z = [poly_eval(c, zeta) for c in z_c[2:]]
+        zh = (pow(zeta, n, P) - 1) % P
+        l0 = zh * plonk_ref.inv(n * (zeta - 1)) % P
+        terms = plonk_ref.vanishing_terms_at(zeta, l0, wires_z, sig_z, zs_z, zs_gz, pp_z, k_is, inst["betas"], inst["gammas"], qdf, [])
+        red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
+        for c in range(2):
+            assert red[c] == zh * poly_eval(t[c], zeta) % P
+
+
+def test_broken_copy_constraint_is_not_divisible():
+    """With one wire changed the vanishing polynomial is no longer a multiple of Z_H: the
+    'quotient' interpolated on the coset fails the identity (so the test above is not vacuous)."""
+    qdf, rate_bits, degree_bits, num_routed = 8, 3, 3, 10
+    inst = make_instance(degree_bits=degree_bits, num_wires=12, num_routed=num_routed, seed=3, valid=False)
+    zpp = plonk_ref.zs_partial_products(inst["wires"], inst["sigmas"], inst["k_is"], inst["betas"], inst["gammas"], qdf, inst["subgroup"])
+    w_c, w_l = lde_leaves(inst["wires"], rate_bits)
+    cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
+    z_c, z_l = lde_leaves(zpp, rate_bits)
+    t = plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, 2, inst["k_is"], inst["betas"], inst["gammas"], inst["alphas"], degree_bits,
+                                         rate_bits, qdf)
+    assert any(v != 0 for v in t[0][8 * inst["n"] - 8:])
+
+
+def test_gate_terms_enter_the_alpha_reduction_last():
+    """Term order [L_0(Z-1)] | [partial-product checks] | [gate constraints] (vanishing_poly.rs:215-219)."""
+    terms = plonk_ref.vanishing_terms_at(5, 7, [1, 2, 3], [4, 5, 6], [9], [10], [], [1, 7, 49], [11], [12], 8, [100, 200])
+    assert terms[-2:] == [100, 200] and len(terms) == 1 + 1 + 2
+    a = 3
+    assert plonk_ref.reduce_with_powers_multi(terms, [a]) == [sum(t * pow(a, k, P) for k, t in enumerate(terms)) % P]
