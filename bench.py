@@ -71,6 +71,16 @@ def cpu_baseline(log_n):
     }
 
 
+def pmc_traffic(log_n, batch):
+    """HBM-side bytes per forward batch transform from the committed PMC summary (measured with
+    rocprofv3 in separate counter passes; bench.py cannot read counters while it runs)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if log_n != 20 or not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d["forward_chunk_total_bytes"] * (batch / 16.0)  # the summary is per 16-column chunk
+
+
 def main():
     args = parse()
     import plonky2_gpu_amd as pg
@@ -129,6 +139,7 @@ def main():
     fwd = float(np.median(fwd_ms))
     alg_bytes = 16.0 * n * batch
     achieved = alg_bytes / (fwd * 1e-3) / 1e9
+    traffic = pmc_traffic(log_n, batch)
 
     out = None
     if dist.rank == 0:
@@ -174,8 +185,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summarised by "
+                                  "tools/pmc_summary.py into profiles/r01_pmc_traffic.json (gfx950 x2 correction on the "
+                                  "row pass's wide reads only); null when that file is absent",
                 "kernel": "forward batch NTT = ntt_pass_kernel<10,true> + ntt_pass_kernel<10,false>",
+                "binding_roof": "integer VALU issue, not HBM: rocprofv3 SQ counters give ~3300 VALU instructions per "
+                                "wave and pass with the SIMDs ~89% busy (DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
             },
