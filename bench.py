@@ -201,6 +201,7 @@ def main():
         print(json.dumps(out))
     buf.free()
     ctx.close()
+    dist.barrier()  # rank 0 runs the extra legs; leave the group together
     dist.close()
 
 
