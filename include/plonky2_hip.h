@@ -137,6 +137,15 @@ typedef struct GlQuotientArgs {
 } GlQuotientArgs;
 GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx);
 
+/* Evaluate poly_num base-field polynomials (coefficients [poly_num][2^log_n], column stride `stride`)
+ * at num_points (<= 4) points of the quadratic extension F_p[X]/(X^2 - 7): what OpeningSet::new does
+ * with every commitment's `polynomials` at zeta and g*zeta (plonky2/src/plonk/proof.rs:305-334;
+ * p.to_extension().eval(z), field/src/polynomial/mod.rs:161-166; extension/quadratic.rs:173-185).
+ * h_points: HOST array of num_points pairs (c0, c1) meaning c0 + c1*X.
+ * d_out[(q*poly_num + i)*2 + {0,1}] = polynomial i at point q, canonical. */
+GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint64_t stride, const uint64_t *h_points,
+                           uint32_t num_points, uint64_t *d_out, void *ctx);
+
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
 

@@ -147,3 +147,33 @@ def compute_quotient_polys(wires_leaves, cs_leaves, zpp_leaves, num_constants, k
         for c in range(num_ch):
             out[c][i] = red[c] * zh_inv % P  # prover.rs:985-991
     return [pyref.coset_idft_fast(col, shift) for col in out]  # prover.rs:1009-1021
+
+
+# ---------------------------------------------------------------- quadratic extension, openings
+W = 7  # Extendable<2>::W, field/src/goldilocks_extensions.rs:19
+
+
+def ext2_mul(x, y):
+    """field/src/extension/quadratic.rs:173-185: (a0 + a1 X)(b0 + b1 X) with X^2 = W."""
+    a0, a1 = x
+    b0, b1 = y
+    return ((a0 * b0 + W * a1 * b1) % P, (a0 * b1 + a1 * b0) % P)
+
+
+def ext2_add(x, y):
+    return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+
+
+def eval_ext2(coeffs, z):
+    """p.to_extension().eval(z): Horner from the top coefficient (field/src/polynomial/mod.rs:161-166)."""
+    acc = (0, 0)
+    for c in reversed(coeffs):
+        acc = ext2_add(ext2_mul(acc, z), (c % P, 0))
+    return acc
+
+
+def opening_evals(polynomials, zeta, g=None):
+    """eval_commitment of OpeningSet::new (plonky2/src/plonk/proof.rs:314-333) at zeta and,
+    when g is given, at g*zeta (plonk_zs_next)."""
+    pts = [zeta] + ([ext2_mul((g % P, 0), zeta)] if g is not None else [])
+    return [[eval_ext2(p, z) for p in polynomials] for z in pts]

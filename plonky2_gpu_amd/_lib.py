@@ -74,6 +74,7 @@ SIGNATURES = {
     "gl_coset_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _u64, _i, _vp]),
     "gl_permutation_partial_products": (GlError, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
+    "gl_eval_polys_ext2": (GlError, [_vp, _u64, _u32, _u64, _vp, _u32, _vp, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),

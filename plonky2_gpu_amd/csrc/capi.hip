@@ -398,6 +398,20 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
     return gl_coset_ntt_batch(d_quotient_polys, a.num_challenges, log_lde, 1ull << log_lde, a.shift, 1, ctx);
 }
 
+GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint64_t stride, const uint64_t *h_points,
+                           uint32_t num_points, uint64_t *d_out, void *ctx) {
+    if (!ctx || !h_points || !d_out || (!d_coeffs && poly_num)) return fail(GL_E_INVALID, "null pointer");
+    if (num_points == 0 || num_points > 4) return fail(GL_E_INVALID, "num_points must be 1..4");
+    if (poly_num > 65535) return fail(GL_E_INVALID, "poly_num > 65535");
+    if (stride < (1ull << log_n)) return fail(GL_E_INVALID, "stride smaller than the polynomial");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    hipError_t e = eval_polys_ext2(*tb, d_coeffs, poly_num, log_n, stride, h_points, num_points, d_out, S(ctx)->stream);
+    if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "unsupported size for gl_eval_polys_ext2");
+    HIP_TRY(e);
+    return ok();
+}
+
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx) {
     if (!ctx || (!d_states && count)) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(poseidon_permute_batch(d_states, count, S(ctx)->stream));

@@ -30,4 +30,8 @@ struct QuotientArgs {
 // out: [num_challenges][n << log2_ceil(quotient_degree_factor)] quotient VALUES on the coset (natural order)
 hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t *out, hipStream_t stream);
 
+// out[(q*n_polys + poly)*2 + {0,1}] = poly(points[q]) in F_{p^2} (points[q] = (points[2q], points[2q+1]), host array)
+hipError_t eval_polys_ext2(const NttTables &tb, const uint64_t *coeffs, uint64_t n_polys, uint32_t log_n, uint64_t stride,
+                           const uint64_t *points, uint32_t n_points, uint64_t *out, hipStream_t stream);
+
 }  // namespace plonky2_hip

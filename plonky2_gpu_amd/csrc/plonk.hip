@@ -289,3 +289,129 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
 }
 
 }  // namespace plonky2_hip
+
+// ---- evaluation of base-field polynomials at points of the quadratic extension ------------------
+// OpeningSet::new (plonky2/src/plonk/proof.rs:305-334): every committed polynomial is evaluated at
+// zeta (and the Z polynomials at g*zeta) in F_{p^2} = F_p[X]/(X^2 - 7) (field/src/goldilocks_extensions.rs:13-26,
+// extension/quadratic.rs:173-185), p.to_extension().eval(z) = Horner (field/src/polynomial/mod.rs:161-166).
+// The reference copies all coefficients back to the host for this (fri/oracle.rs:403-407, 462); here they
+// are read once where they already live. Grid = (segments, polynomials): a workgroup owns one contiguous
+// segment of one polynomial, thread t does Horner with z^256 over coefficients t, t+256, ...; the
+// per-thread values are weighted by z^t, summed in LDS, weighted by z^(segment start) and written as one
+// partial per (point, polynomial, segment); a second tiny kernel adds the segments.
+namespace plonky2_hip {
+namespace {
+
+struct Ext2 {
+    uint64_t a, b;  // a + b*X, X^2 = 7
+};
+
+__device__ __forceinline__ Ext2 ext_mul(Ext2 x, Ext2 y) {
+    // c0 = a0*b0 + 7*a1*b1, c1 = a0*b1 + a1*b0 (quadratic.rs:176-184)
+    uint64_t t = gl::mul(x.b, y.b);
+    uint64_t t7 = gl::sub(gl::mul_pow2<3>(t), t);
+    return Ext2{gl::add(gl::mul(x.a, y.a), t7), gl::mac(gl::mul(x.a, y.b), x.b, y.a)};
+}
+
+__device__ __forceinline__ Ext2 ext_add(Ext2 x, Ext2 y) { return Ext2{gl::add(x.a, y.a), gl::add(x.b, y.b)}; }
+
+__device__ __forceinline__ Ext2 ext_pow(Ext2 base, uint64_t e) {
+    Ext2 acc{1, 0};
+    while (e) {
+        if (e & 1) acc = ext_mul(acc, base);
+        base = ext_mul(base, base);
+        e >>= 1;
+    }
+    return acc;
+}
+
+constexpr int EV_T = 256, EV_MAX_POINTS = 4;
+
+struct EvalPoints {
+    uint64_t z0[EV_MAX_POINTS], z1[EV_MAX_POINTS];
+    uint32_t count;
+};
+
+__global__ __launch_bounds__(EV_T) void eval_ext2_kernel(const uint64_t *__restrict__ coeffs, uint64_t stride, uint32_t log_n,
+                                                         uint32_t log_seg, EvalPoints pts, uint64_t *__restrict__ partials) {
+    __shared__ uint64_t red[2][EV_T];
+    const uint32_t t = threadIdx.x, seg = blockIdx.x, poly = blockIdx.y;
+    const uint64_t seg_len = 1ull << log_seg, seg_start = (uint64_t)seg << log_seg;
+    const uint64_t *c = coeffs + (uint64_t)poly * stride + seg_start;
+    const uint32_t n_seg = 1u << (log_n - log_seg);
+    for (uint32_t q = 0; q < pts.count; q++) {
+        const Ext2 z{pts.z0[q], pts.z1[q]};
+        const Ext2 zs = ext_pow(z, EV_T);  // z^256
+        const uint64_t zs1_7 = gl::sub(gl::mul_pow2<3>(zs.b), zs.b);
+        Ext2 acc{0, 0};
+        // coefficients t + 256k, highest k first: acc = acc * z^256 + c
+        for (int64_t k = (int64_t)(seg_len / EV_T) - 1; k >= 0; k--) {
+            uint64_t cv = (t + (uint64_t)k * EV_T < seg_len) ? c[t + (uint64_t)k * EV_T] : 0;
+            uint64_t n0 = gl::mac(gl::mac(cv, acc.a, zs.a), acc.b, zs1_7);
+            uint64_t n1 = gl::mac(gl::mul(acc.a, zs.b), acc.b, zs.a);
+            acc = Ext2{n0, n1};
+        }
+        if (seg_len < EV_T) {  // tiny polynomials: one coefficient (or none) per thread
+            acc = Ext2{t < seg_len ? c[t] : 0, 0};
+        }
+        Ext2 w = ext_mul(acc, ext_pow(z, t));
+        red[0][t] = w.a;
+        red[1][t] = w.b;
+        __syncthreads();
+        for (int off = EV_T / 2; off > 0; off >>= 1) {
+            if (t < (uint32_t)off) {
+                red[0][t] = gl::add(red[0][t], red[0][t + off]);
+                red[1][t] = gl::add(red[1][t], red[1][t + off]);
+            }
+            __syncthreads();
+        }
+        if (t == 0) {
+            Ext2 r = ext_mul(Ext2{red[0][0], red[1][0]}, ext_pow(z, seg_start));
+            uint64_t *o = partials + (((uint64_t)q * gridDim.y + poly) * n_seg + seg) * 2;
+            o[0] = gl::canon(r.a);
+            o[1] = gl::canon(r.b);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void eval_ext2_sum_kernel(const uint64_t *partials, uint32_t n_seg, uint64_t total, uint64_t *out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint64_t a = 0, b = 0;
+    for (uint32_t s = 0; s < n_seg; s++) {
+        a = gl::add(a, partials[(g * n_seg + s) * 2]);
+        b = gl::add(b, partials[(g * n_seg + s) * 2 + 1]);
+    }
+    out[g * 2] = gl::canon(a);
+    out[g * 2 + 1] = gl::canon(b);
+}
+
+}  // namespace
+
+hipError_t eval_polys_ext2(const NttTables &tb, const uint64_t *coeffs, uint64_t n_polys, uint32_t log_n, uint64_t stride,
+                           const uint64_t *points, uint32_t n_points, uint64_t *out, hipStream_t stream) {
+    if (n_points == 0 || n_points > EV_MAX_POINTS || log_n > 32 || n_polys > 65535) return hipErrorInvalidValue;
+    if (n_polys == 0) return hipSuccess;
+    // enough segments to give the chip >= ~2048 workgroups, each at least 4096 coefficients long
+    uint32_t log_seg = log_n;
+    while (log_seg > 12 && (n_polys << (log_n - log_seg)) < 2048) log_seg--;
+    const uint32_t n_seg = 1u << (log_n - log_seg);
+    const uint64_t need = (uint64_t)n_points * n_polys * n_seg * 2;
+    if (!tb.scratch || tb.scratch_elems < need) return hipErrorInvalidValue;
+    EvalPoints pts = {};
+    pts.count = n_points;
+    for (uint32_t q = 0; q < n_points; q++) {
+        pts.z0[q] = points[2 * q] % glh::P;
+        pts.z1[q] = points[2 * q + 1] % glh::P;
+    }
+    hipLaunchKernelGGL(eval_ext2_kernel, dim3(n_seg, (unsigned)n_polys), dim3(EV_T), 0, stream, coeffs, stride, log_n, log_seg, pts,
+                       tb.scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint64_t total = (uint64_t)n_points * n_polys;
+    hipLaunchKernelGGL(eval_ext2_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, tb.scratch, n_seg, total, out);
+    return hipGetLastError();
+}
+
+}  // namespace plonky2_hip

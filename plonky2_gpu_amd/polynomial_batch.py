@@ -98,3 +98,16 @@ class PolynomialBatch:
         rev = int(f"{index:0{bits}b}"[::-1], 2) if bits else 0
         row = self.merkle_tree.get(rev)
         return row[: len(row) - (SALT_SIZE if self.blinding else 0)]
+
+    def eval_polynomials_ext2(self, points):
+        """`c.polynomials.par_iter().map(|p| p.to_extension().eval(z))` of OpeningSet::new
+        (plonky2/src/plonk/proof.rs:314-319) for each z in `points` (pairs (c0, c1) of F_p[X]/(X^2-7)).
+        Returns an array [len(points), n_polys, 2]; the coefficients never leave HBM."""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 2)
+        out = DeviceBuffer(self.ctx, pts.shape[0] * self.n_polys * 2)
+        n = 1 << self.degree_log
+        _lib.call("gl_eval_polys_ext2", self.d_polynomials.ptr, self.n_polys, self.degree_log, n, pts.ctypes.data, pts.shape[0],
+                  out.ptr, self.ctx.ptr)
+        res = out.download().reshape(pts.shape[0], self.n_polys, 2)
+        out.free()
+        return res

@@ -102,3 +102,23 @@ def test_compute_quotient_polys(gpu, oracle, num_routed, degree_bits, qdf, with_
         red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
         for c in range(2):
             assert red[c] == zh * poly_eval([int(v) for v in got[c]], zeta) % P
+
+
+@pytest.mark.parametrize("n_polys,log_n", [(3, 0), (5, 3), (7, 8), (20, 12), (135, 10), (4, 16), (2, 19)])
+def test_opening_evaluations_in_the_quadratic_extension(gpu, oracle, n_polys, log_n):
+    """OpeningSet::new's eval_commitment (plonk/proof.rs:314-333): every polynomial of a commitment
+    at zeta and g*zeta in F_{p^2}, computed where the coefficients live."""
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    coeffs = oracle.random_field((n_polys, n), seed=n_polys * 31 + log_n)
+    batch = pg.PolynomialBatch.from_coeffs(gpu, coeffs, 1, False, 0, leaf_major=False)
+    rng = random.Random(log_n)
+    zeta = (rng.randrange(P), rng.randrange(P))
+    g = pyref.root_of_unity(max(log_n, 1))
+    pts = [zeta, plonk_ref.ext2_mul((g, 0), zeta), (5, 0)]
+    got = batch.eval_polynomials_ext2(pts)
+    sample = range(n_polys) if n <= 4096 else [0, n_polys - 1]
+    for q, z in enumerate(pts):
+        for i in sample:
+            assert tuple(int(v) for v in got[q, i]) == plonk_ref.eval_ext2([int(c) for c in coeffs[i]], z), (q, i)

@@ -67,3 +67,20 @@ def test_gate_terms_enter_the_alpha_reduction_last():
     assert terms[-2:] == [100, 200] and len(terms) == 1 + 1 + 2
     a = 3
     assert plonk_ref.reduce_with_powers_multi(terms, [a]) == [sum(t * pow(a, k, P) for k, t in enumerate(terms)) % P]
+
+
+def test_ext2_evaluation_against_power_sums():
+    """Horner in F_p[X]/(X^2-7) == sum of c_i * z^i with z^i from repeated multiplication; a base
+    point (z1 = 0) reduces to the base-field evaluation; X*X = 7."""
+    rng = random.Random(2)
+    assert plonk_ref.ext2_mul((0, 1), (0, 1)) == (7, 0)
+    for n in (1, 2, 5, 64):
+        coeffs = [rng.randrange(P) for _ in range(n)]
+        z = (rng.randrange(P), rng.randrange(P))
+        acc, pw = (0, 0), (1, 0)
+        for c in coeffs:
+            acc = plonk_ref.ext2_add(acc, plonk_ref.ext2_mul((c, 0), pw))
+            pw = plonk_ref.ext2_mul(pw, z)
+        assert plonk_ref.eval_ext2(coeffs, z) == acc
+        zb = (rng.randrange(P), 0)
+        assert plonk_ref.eval_ext2(coeffs, zb) == (poly_eval(coeffs, zb[0]), 0)
