@@ -123,6 +123,29 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
  * reverse_bits(i * step) like PolynomialBatch::get_lde_values (fri/oracle.rs:1007-1018).
  * d_quotient_polys [num_challenges][n << log2_ceil(qdf)] receives the COEFFICIENTS (after coset_ifft,
  * prover.rs:1009-1021); chunking into degree-n pieces is a reinterpretation (prover.rs:153-166). */
+/* Table-driven gate constraints for gl_compute_quotient_polys: evaluate_gate_constraints_base_batch
+ * (plonky2/src/plonk/vanishing_poly.rs:267-306) with compute_filter (gates/gate.rs:261-268) for ANY circuit.
+ * Each gate is a register program of GlGateInstr {op, dst, a, b} (u16 each):
+ *   0 LOAD_WIRE dst<-local_wires[a]      1 LOAD_CONST dst<-local_constants[num_selectors+a]
+ *   2 LOAD_PI dst<-public_inputs_hash[a]  3 LOAD_IMM dst<-d_immediates[a]
+ *   4 ADD  5 SUB  6 MUL  dst<-r[a] op r[b]       7 EMIT next constraint of the gate <- r[a]
+ * (64 registers). Gate g is described by GlGateDesc {row = its index in the circuit's gate list,
+ * selector_index, group_start, group_end (selectors_info.groups[selector_index]), prog_start, prog_len}.
+ * Constraint k of every gate accumulates into term k, multiplied by the gate's filter. */
+typedef struct GlGateInstr {
+    uint16_t op, dst, a, b;
+} GlGateInstr;
+typedef struct GlGateDesc {
+    uint32_t row, selector_index, group_start, group_end, prog_start, prog_len;
+} GlGateDesc;
+typedef struct GlGateProgram {
+    const GlGateInstr *d_instrs;  /* device */
+    const GlGateDesc *d_gates;    /* device */
+    const uint64_t *d_immediates; /* device, may be NULL */
+    uint32_t num_gates, num_selectors;
+    uint64_t public_inputs_hash[4];
+} GlGateProgram;
+
 typedef struct GlQuotientArgs {
     const uint64_t *d_wires_leaves;
     const uint64_t *d_constants_sigmas_leaves;
@@ -134,6 +157,7 @@ typedef struct GlQuotientArgs {
     uint32_t num_constants, num_routed_wires, num_challenges, num_gate_constraints;
     uint32_t degree_bits, rate_bits, quotient_degree_factor;
     uint64_t coset_shift; /* F::coset_shift() = 7 */
+    const GlGateProgram *gate_program; /* HOST struct, may be NULL; exclusive with d_gate_constraint_terms */
 } GlQuotientArgs;
 GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx);
 

@@ -177,3 +177,54 @@ def opening_evals(polynomials, zeta, g=None):
     when g is given, at g*zeta (plonk_zs_next)."""
     pts = [zeta] + ([ext2_mul((g % P, 0), zeta)] if g is not None else [])
     return [[eval_ext2(p, z) for p in polynomials] for z in pts]
+
+
+# ---------------------------------------------------------------- gate constraints
+UNUSED_SELECTOR = (1 << 32) - 1  # plonky2/src/gates/selectors.rs:11
+
+
+def compute_filter(row, group_range, s, many_selectors):
+    """plonky2/src/gates/gate.rs:261-268"""
+    f = 1
+    for i in list(range(*group_range)) + ([UNUSED_SELECTOR] if many_selectors else []):
+        if i != row:
+            f = f * ((i - s) % P) % P
+    return f
+
+
+# unfiltered constraints of the gates used by the tests; vars = (local_constants after the selector
+# prefix, local_wires, public_inputs_hash)
+def arithmetic_gate(num_ops):
+    """ArithmeticGate::eval_unfiltered_base_packed (plonky2/src/gates/arithmetic_base.rs:199-216)"""
+    def f(consts, wires, pih):
+        c0, c1 = consts[0], consts[1]
+        return [(wires[4 * i + 3] - (wires[4 * i] * wires[4 * i + 1] % P * c0 + wires[4 * i + 2] * c1)) % P for i in range(num_ops)]
+    return f
+
+
+def constant_gate(num_consts):
+    """ConstantGate (plonky2/src/gates/constant.rs:150-158)"""
+    return lambda consts, wires, pih: [(consts[i] - wires[i]) % P for i in range(num_consts)]
+
+
+def public_input_gate():
+    """PublicInputGate (plonky2/src/gates/public_input.rs:129-139)"""
+    return lambda consts, wires, pih: [(wires[i] - pih[i]) % P for i in range(4)]
+
+
+def noop_gate():
+    """NoopGate (plonky2/src/gates/noop.rs): no constraints"""
+    return lambda consts, wires, pih: []
+
+
+def evaluate_gate_constraints(gates, selector_indices, groups, num_gate_constraints, local_constants, local_wires, pih):
+    """evaluate_gate_constraints_base_batch for one point (plonky2/src/plonk/vanishing_poly.rs:267-306)
+    over Gate::eval_filtered (gates/gate.rs:86-109): constraints[k] += filter_g * c_{g,k}."""
+    num_selectors = len(groups)
+    out = [0] * num_gate_constraints
+    for row, gate in enumerate(gates):
+        si = selector_indices[row]
+        filt = compute_filter(row, groups[si], local_constants[si], num_selectors > 1)
+        for k, c in enumerate(gate(local_constants[num_selectors:], local_wires, pih)):
+            out[k] = (out[k] + filt * c) % P
+    return out

@@ -12,7 +12,7 @@ from .device import Context, DeviceBuffer, Event  # noqa: F401
 from .fft import coset_fft, coset_ifft, coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
 from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401
-from .prover import all_wires_permutation_partial_products, compute_quotient_polys  # noqa: F401
+from .prover import GateProgram, all_wires_permutation_partial_products, compute_quotient_polys  # noqa: F401
 
 P = 0xFFFFFFFF00000001
 COSET_SHIFT = 7  # F::coset_shift(), field/src/types.rs:431-433

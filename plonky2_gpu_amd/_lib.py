@@ -17,6 +17,17 @@ class GlDataSlice(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("len", ctypes.c_int)]
 
 
+class GlGateProgram(ctypes.Structure):
+    _fields_ = [
+        ("d_instrs", ctypes.c_void_p),
+        ("d_gates", ctypes.c_void_p),
+        ("d_immediates", ctypes.c_void_p),
+        ("num_gates", ctypes.c_uint32),
+        ("num_selectors", ctypes.c_uint32),
+        ("public_inputs_hash", ctypes.c_uint64 * 4),
+    ]
+
+
 class GlQuotientArgs(ctypes.Structure):
     _fields_ = [
         ("d_wires_leaves", ctypes.c_void_p),
@@ -38,6 +49,7 @@ class GlQuotientArgs(ctypes.Structure):
         ("rate_bits", ctypes.c_uint32),
         ("quotient_degree_factor", ctypes.c_uint32),
         ("coset_shift", ctypes.c_uint64),
+        ("gate_program", ctypes.POINTER(GlGateProgram)),
     ]
 
 

@@ -384,6 +384,20 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
     a.rate_bits = args->rate_bits;
     a.quotient_degree_factor = args->quotient_degree_factor;
     a.shift = args->coset_shift;
+    GateProgramArgs gpa = {};
+    if (args->gate_program) {
+        const GlGateProgram *g = args->gate_program;
+        if (!g->d_instrs || !g->d_gates) return fail(GL_E_INVALID, "null pointer in GlGateProgram");
+        if (args->d_gate_constraint_terms) return fail(GL_E_INVALID, "give either gate terms or a gate program, not both");
+        if (args->num_gate_constraints > 256) return fail(GL_E_INVALID, "num_gate_constraints > 256");
+        gpa.instrs = reinterpret_cast<const uint16_t *>(g->d_instrs);
+        gpa.gates = reinterpret_cast<const uint32_t *>(g->d_gates);
+        gpa.imms = g->d_immediates;
+        gpa.num_gates = g->num_gates;
+        gpa.num_selectors = g->num_selectors;
+        for (int k = 0; k < 4; k++) gpa.public_inputs_hash[k] = g->public_inputs_hash[k];
+        a.gate_program = &gpa;
+    }
     uint32_t qdb = 0;
     while ((1u << qdb) < a.quotient_degree_factor) qdb++;
     if (a.quotient_degree_factor < 2 || qdb > a.rate_bits)

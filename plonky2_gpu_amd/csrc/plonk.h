@@ -16,7 +16,16 @@ hipError_t permutation_partial_products(const NttTables &tb, const uint64_t *wir
                                         uint32_t num_challenges, uint32_t num_routed, uint32_t degree, uint32_t log_n, uint64_t *out,
                                         hipStream_t stream);
 
+struct GateProgramArgs {
+    const uint16_t *instrs;  // device
+    const uint32_t *gates;   // device
+    const uint64_t *imms;    // device (may be null when no LOAD_IMM is used)
+    uint32_t num_gates, num_selectors;
+    uint64_t public_inputs_hash[4];
+};
+
 struct QuotientArgs {
+    const GateProgramArgs *gate_program = nullptr;  // alternative to gate_terms
     const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves;  // leaf-major LDE rows of the three commitments
     uint32_t wires_len, cs_len, zpp_len;                    // leaf lengths
     const uint64_t *k_is;                                   // device, num_routed

@@ -145,7 +145,58 @@ __global__ __launch_bounds__(256) void perm_finalize_kernel(uint64_t *out, const
 }
 
 // ---- quotient values ---------------------------------------------------------------------------
+// Table-driven gate constraints: evaluate_gate_constraints_base_batch (plonky2/src/plonk/vanishing_poly.rs:267-306)
+// over Gate::eval_filtered (gates/gate.rs:86-109) and compute_filter (gates/gate.rs:261-268). Every gate of
+// the circuit is a small register program (see plonky2_gpu_amd/gate_program.py for the instruction set);
+// all lanes of a wavefront execute the same instruction stream, so the interpreter does not diverge.
+constexpr int GP_MAX_REGS = 64, GP_MAX_CONSTRAINTS = 256;
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT };
+
+struct GateProgramDev {
+    const uint16_t *instrs;  // 4 x u16 per instruction: op, dst, a, b
+    const uint32_t *gates;   // 6 x u32 per gate: row, selector_index, group_start, group_end, prog_start, prog_len
+    const uint64_t *imms;
+    uint32_t num_gates, num_selectors, num_gate_constraints;
+    uint64_t pih[4];
+};
+
+__device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *local_constants, const uint64_t *local_wires,
+                                  uint64_t *acc) {
+    uint64_t regs[GP_MAX_REGS];
+    for (uint32_t k = 0; k < gp.num_gate_constraints; k++) acc[k] = 0;
+    for (uint32_t g = 0; g < gp.num_gates; g++) {
+        const uint32_t *d = gp.gates + 6 * g;
+        const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
+        const uint64_t s = local_constants[si];
+        uint64_t filt = 1;
+        for (uint32_t i = gs; i < ge; i++)
+            if (i != row) filt = gl::mul(filt, gl::sub(i, s));
+        if (gp.num_selectors > 1) filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));  // UNUSED_SELECTOR, selectors.rs:11
+        uint32_t k = 0;
+        for (uint32_t pc = ps; pc < ps + pl; pc++) {
+            const uint16_t *in = gp.instrs + 4 * pc;
+            const uint16_t op = in[0], dst = in[1] & (GP_MAX_REGS - 1), a = in[2], b = in[3];
+            switch (op) {
+                case GP_LOAD_WIRE: regs[dst] = local_wires[a]; break;
+                case GP_LOAD_CONST: regs[dst] = local_constants[gp.num_selectors + a]; break;
+                case GP_LOAD_PI: regs[dst] = gp.pih[a & 3]; break;
+                case GP_LOAD_IMM: regs[dst] = gp.imms[a]; break;
+                case GP_ADD: regs[dst] = gl::add(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
+                case GP_SUB: regs[dst] = gl::sub(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
+                case GP_MUL: regs[dst] = gl::mul(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
+                case GP_EMIT:
+                    if (k < gp.num_gate_constraints) acc[k] = gl::add(acc[k], gl::mul(filt, regs[a & (GP_MAX_REGS - 1)]));
+                    k++;
+                    break;
+                default: break;
+            }
+        }
+    }
+}
+
 struct QuotientParams {
+    GateProgramDev gp;
+    uint32_t has_program;
     const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves, *k_is, *gate_terms, *twl, *twh;
     uint64_t *out;  // [num_challenges][lde_size]
     uint32_t wires_len, cs_len, zpp_len, num_constants, num_routed, num_challenges, degree, num_prods;
@@ -201,6 +252,11 @@ __global__ __launch_bounds__(128) void quotient_values_kernel(const QuotientPara
     // reduce_with_powers_multi (plonk_common.rs:97-114): Horner from the LAST term over
     // [L_0 (Z-1)] | [partial-product checks] | [gate constraints]
     const uint64_t *gt = p.gate_terms ? p.gate_terms + i * p.num_gate_constraints : nullptr;
+    uint64_t gate_acc[GP_MAX_CONSTRAINTS];
+    if (p.has_program) {
+        eval_gate_program(p.gp, p.cs_leaves + leaf * p.cs_len, wires, gate_acc);
+        gt = gate_acc;
+    }
     for (uint32_t c = 0; c < p.num_challenges; c++) {
         const uint64_t alpha = p.ch.alpha[c];
         uint64_t cumul = 0;
@@ -275,7 +331,20 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
     p.degree_bits = a.degree_bits;
     p.rate_bits = a.rate_bits;
     p.qdb = qdb;
-    p.num_gate_constraints = a.gate_terms ? a.num_gate_constraints : 0;
+    p.num_gate_constraints = (a.gate_terms || a.gate_program) ? a.num_gate_constraints : 0;
+    if (a.gate_program) {
+        if (a.gate_terms || a.num_gate_constraints > GP_MAX_CONSTRAINTS) return hipErrorInvalidValue;
+        const GateProgramArgs &g = *a.gate_program;
+        if (g.num_selectors > a.num_constants) return hipErrorInvalidValue;
+        p.has_program = 1;
+        p.gp.instrs = g.instrs;
+        p.gp.gates = g.gates;
+        p.gp.imms = g.imms;
+        p.gp.num_gates = g.num_gates;
+        p.gp.num_selectors = g.num_selectors;
+        p.gp.num_gate_constraints = a.num_gate_constraints;
+        for (int k = 0; k < 4; k++) p.gp.pih[k] = g.public_inputs_hash[k] % glh::P;
+    }
     p.shift = a.shift % glh::P;
     p.g_pow_n = glh::pow(p.shift, 1ull << a.degree_bits);
     for (uint32_t c = 0; c < a.num_challenges; c++) {

@@ -34,7 +34,7 @@ def all_wires_permutation_partial_products(ctx, d_wires, wires_stride, d_sigmas,
 
 def compute_quotient_polys(ctx, wires_commitment, constants_sigmas_commitment, zs_partial_products_commitment, num_constants,
                            num_routed, d_k_is, betas, gammas, alphas, quotient_degree_factor, d_gate_terms=None,
-                           num_gate_constraints=0):
+                           num_gate_constraints=0, gate_program=None):
     """compute_quotient_polys (prover.rs:790-1034) over three PolynomialBatch commitments (leaf-major
     leaves resident in HBM). Returns a DeviceBuffer of coefficients [num_challenges][n << qdb]."""
     b, g, a = _host_u64(betas), _host_u64(gammas), _host_u64(alphas)
@@ -47,7 +47,27 @@ def compute_quotient_polys(ctx, wires_commitment, constants_sigmas_commitment, z
         b.ctypes.data, g.ctypes.data, a.ctypes.data,
         num_constants, num_routed, b.size, num_gate_constraints,
         wc.degree_log, wc.rate_bits, quotient_degree_factor, COSET_SHIFT,
+        ctypes.pointer(gate_program.struct) if gate_program is not None else None,
     )
     out = DeviceBuffer(ctx, b.size << (wc.degree_log + qdb))
     _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, ctx.ptr)
     return out
+
+
+class GateProgram:
+    """Device-resident gate programs of a circuit (see gate_program.py): the table-driven replacement
+    of the reference's hard-wired gate list (cuda/plonky2_gpu_impl.cuh:600-685)."""
+
+    def __init__(self, ctx, gate_instrs, selector_indices, groups, public_inputs_hash, immediates=None):
+        from . import gate_program as gp
+
+        instrs, descs = gp.pack_program(gate_instrs, selector_indices, groups)
+        self.d_instrs = DeviceBuffer.from_host(ctx, np.frombuffer(np.ascontiguousarray(instrs).tobytes(), dtype=np.uint64))
+        d32 = np.ascontiguousarray(descs).tobytes()
+        d32 += b"\0" * (-len(d32) % 8)
+        self.d_gates = DeviceBuffer.from_host(ctx, np.frombuffer(d32, dtype=np.uint64))
+        self.d_imms = DeviceBuffer.from_host(ctx, _host_u64(immediates)) if immediates is not None else None
+        self.struct = _lib.GlGateProgram(
+            self.d_instrs.ptr, self.d_gates.ptr, self.d_imms.ptr if self.d_imms else None, len(gate_instrs), len(groups),
+            (ctypes.c_uint64 * 4)(*[int(v) for v in public_inputs_hash]),
+        )

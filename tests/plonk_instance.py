@@ -56,3 +56,60 @@ def make_instance(degree_bits=4, num_wires=12, num_routed=10, num_constants=2, n
     alphas = [rng.randrange(P) for _ in range(num_challenges)]
     return dict(n=n, degree_bits=degree_bits, subgroup=subgroup, k_is=k_is, wires=wires, sigmas=sigmas, constants=constants,
                 betas=betas, gammas=gammas, alphas=alphas, num_routed=num_routed, num_constants=num_constants)
+
+
+def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenges=2):
+    """A tiny real circuit: rows of NoopGate / ConstantGate{2} / PublicInputGate / ArithmeticGate{3}
+    (plonky2/src/gates/{noop,constant,public_input,arithmetic_base}.rs) with a satisfying witness and
+    copy constraints between arithmetic inputs. 12 wires, all routed."""
+    from oracle import plonk_ref
+
+    rng = random.Random(seed)
+    n = 1 << degree_bits
+    num_wires = num_routed = 12
+    w = pyref.root_of_unity(degree_bits)
+    subgroup = [pow(w, i, P) for i in range(n)]
+    k_is = [pow(pyref.GENERATOR, j, P) for j in range(num_routed)]
+    gates = [plonk_ref.noop_gate(), plonk_ref.constant_gate(2), plonk_ref.public_input_gate(), plonk_ref.arithmetic_gate(3)]
+    if two_groups:
+        groups, selector_indices = [(0, 2), (2, 4)], [0, 0, 1, 1]
+    else:
+        groups, selector_indices = [(0, 4)], [0, 0, 0, 0]
+    num_selectors = len(groups)
+    pih = [rng.randrange(P) for _ in range(4)]
+    row_gate = [rng.choice([0, 1, 3, 3, 3]) for _ in range(n)]
+    row_gate[0] = 2  # the public-input gate sits in the first row
+    # constants: selector columns, then the two gate constants
+    sel = [[(row_gate[r] if selector_indices[row_gate[r]] == g else plonk_ref.UNUSED_SELECTOR) for r in range(n)]
+           for g in range(num_selectors)]
+    c0 = [rng.randrange(P) for _ in range(n)]
+    c1 = [rng.randrange(P) for _ in range(n)]
+    wires = [[rng.randrange(P) for _ in range(n)] for _ in range(num_wires)]
+    # copy cycles among arithmetic inputs
+    inputs = [(r, 4 * i + k) for r in range(n) if row_gate[r] == 3 for i in range(3) for k in range(3)]
+    rng.shuffle(inputs)
+    sigma = {(r, j): (r, j) for j in range(num_routed) for r in range(n)}
+    pos = 0
+    while pos + 1 < len(inputs):
+        size = min(rng.choice([2, 2, 3]), len(inputs) - pos)
+        cyc = inputs[pos : pos + size]
+        pos += size
+        v = rng.randrange(P)
+        for t, cell in enumerate(cyc):
+            wires[cell[1]][cell[0]] = v
+            sigma[cell] = cyc[(t + 1) % size]
+    for r in range(n):
+        g = row_gate[r]
+        if g == 3:
+            for i in range(3):
+                wires[4 * i + 3][r] = (wires[4 * i][r] * wires[4 * i + 1][r] % P * c0[r] + wires[4 * i + 2][r] * c1[r]) % P
+        elif g == 1:
+            wires[0][r], wires[1][r] = c0[r], c1[r]
+        elif g == 2:
+            for i in range(4):
+                wires[i][r] = pih[i]
+    sigmas = [[k_is[sigma[(i, j)][1]] * subgroup[sigma[(i, j)][0]] % P for i in range(n)] for j in range(num_routed)]
+    return dict(n=n, degree_bits=degree_bits, subgroup=subgroup, k_is=k_is, wires=wires, sigmas=sigmas, constants=sel + [c0, c1],
+                betas=[rng.randrange(P) for _ in range(num_challenges)], gammas=[rng.randrange(P) for _ in range(num_challenges)],
+                alphas=[rng.randrange(P) for _ in range(num_challenges)], num_routed=num_routed, num_constants=num_selectors + 2,
+                gates=gates, groups=groups, selector_indices=selector_indices, pih=pih, num_gate_constraints=4, row_gate=row_gate)

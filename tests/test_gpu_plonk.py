@@ -7,7 +7,7 @@ import pytest
 
 from gpu_util import gpu  # noqa: F401
 from oracle import plonk_ref, pyref
-from plonk_instance import lde_leaves, make_instance, poly_eval
+from plonk_instance import lde_leaves, make_circuit_instance, make_instance, poly_eval
 
 pytestmark = pytest.mark.gpu
 P = pyref.P
@@ -122,3 +122,55 @@ def test_opening_evaluations_in_the_quadratic_extension(gpu, oracle, n_polys, lo
     for q, z in enumerate(pts):
         for i in sample:
             assert tuple(int(v) for v in got[q, i]) == plonk_ref.eval_ext2([int(c) for c in coeffs[i]], z), (q, i)
+
+
+@pytest.mark.parametrize("two_groups,degree_bits", [(False, 4), (True, 4), (True, 7)])
+def test_quotient_with_table_driven_gates(gpu, two_groups, degree_bits):
+    """compute_quotient_polys for a circuit described by gate programs (Noop / Constant / PublicInput /
+    Arithmetic): equals the oracle's evaluate_gate_constraints path and satisfies the verifier
+    identity with the gate constraints included."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import gate_program as gp
+
+    qdf, rate_bits, cap_h = 8, 3, 2
+    inst = make_circuit_instance(degree_bits=degree_bits, seed=21 + two_groups, two_groups=two_groups)
+    n, k_is, nc = inst["n"], inst["k_is"], inst["num_constants"]
+    wires_b = pg.PolynomialBatch.from_values(gpu, cols(inst["wires"]), rate_bits, False, cap_h)
+    cs_b = pg.PolynomialBatch.from_values(gpu, cols(inst["constants"] + inst["sigmas"]), rate_bits, False, cap_h)
+    d_w = pg.DeviceBuffer.from_host(gpu, cols(inst["wires"]))
+    d_s = pg.DeviceBuffer.from_host(gpu, cols(inst["sigmas"]))
+    d_k = pg.DeviceBuffer.from_host(gpu, cols(k_is))
+    d_zpp, n_cols = pg.all_wires_permutation_partial_products(gpu, d_w, n, d_s, n, d_k, inst["betas"], inst["gammas"], 12, qdf,
+                                                              degree_bits)
+    zpp_host = d_zpp.download().reshape(n_cols, n)
+    zpp_b = pg.PolynomialBatch.from_values_device(gpu, d_zpp, n_cols, degree_bits, rate_bits, False, cap_h)
+    prog = pg.GateProgram(gpu, [gp.noop_gate(), gp.constant_gate(2), gp.public_input_gate(), gp.arithmetic_gate(3)],
+                          inst["selector_indices"], inst["groups"], inst["pih"])
+    d_q = pg.compute_quotient_polys(gpu, wires_b, cs_b, zpp_b, nc, 12, d_k, inst["betas"], inst["gammas"], inst["alphas"], qdf,
+                                    None, inst["num_gate_constraints"], prog)
+    got = d_q.download().reshape(2, n * 8)
+    w_c, w_l = lde_leaves(inst["wires"], rate_bits)
+    cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
+    z_c, z_l = lde_leaves(zpp_host.tolist(), rate_bits)
+    bits = degree_bits + rate_bits
+    if degree_bits <= 4:
+        gate_terms = [plonk_ref.evaluate_gate_constraints(inst["gates"], inst["selector_indices"], inst["groups"], 4,
+                                                          cs_l[pyref.reverse_bits(i, bits)][:nc], w_l[pyref.reverse_bits(i, bits)],
+                                                          inst["pih"]) for i in range(n * 8)]
+        exp = plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, nc, k_is, inst["betas"], inst["gammas"], inst["alphas"], degree_bits,
+                                               rate_bits, qdf, gate_terms)
+        assert (got == cols(exp)).all()
+    # verifier identity with gate constraints at a random point
+    zeta = 0xFEDCBA9876543210 % P
+    g = pyref.root_of_unity(degree_bits)
+    wires_z = [poly_eval(c, zeta) for c in w_c]
+    consts_z = [poly_eval(c, zeta) for c in cs_c[:nc]]
+    gt = plonk_ref.evaluate_gate_constraints(inst["gates"], inst["selector_indices"], inst["groups"], 4, consts_z, wires_z, inst["pih"])
+    zh = (pow(zeta, n, P) - 1) % P
+    l0 = zh * plonk_ref.inv(n * (zeta - 1)) % P
+    terms = plonk_ref.vanishing_terms_at(zeta, l0, wires_z, [poly_eval(c, zeta) for c in cs_c[nc:]],
+                                         [poly_eval(z_c[c], zeta) for c in range(2)], [poly_eval(z_c[c], g * zeta % P) for c in range(2)],
+                                         [poly_eval(c, zeta) for c in z_c[2:]], k_is, inst["betas"], inst["gammas"], qdf, gt)
+    red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
+    for c in range(2):
+        assert red[c] == zh * poly_eval([int(v) for v in got[c]], zeta) % P

@@ -5,7 +5,7 @@ import random
 import pytest
 
 from oracle import plonk_ref, pyref
-from plonk_instance import lde_leaves, make_instance, poly_eval
+from plonk_instance import lde_leaves, make_circuit_instance, make_instance, poly_eval
 
 P = pyref.P
 
@@ -84,3 +84,45 @@ def test_ext2_evaluation_against_power_sums():
         assert plonk_ref.eval_ext2(coeffs, z) == acc
         zb = (rng.randrange(P), 0)
         assert plonk_ref.eval_ext2(coeffs, zb) == (poly_eval(coeffs, zb[0]), 0)
+
+
+@pytest.mark.parametrize("two_groups", [False, True])
+def test_mini_circuit_with_gates_satisfies_the_verifier_identity(two_groups):
+    """Gate constraints (filters from selector polynomials) + permutation argument on a tiny real
+    circuit: the quotient built from the LDE equals vanishing(zeta) / Z_H(zeta) at random zeta."""
+    qdf, rate_bits, degree_bits = 8, 3, 4
+    inst = make_circuit_instance(degree_bits=degree_bits, seed=11 + two_groups, two_groups=two_groups)
+    n, k_is, nc = inst["n"], inst["k_is"], inst["num_constants"]
+    # the witness satisfies every gate on every row
+    for r in range(n):
+        lc = [col[r] for col in inst["constants"]]
+        lw = [col[r] for col in inst["wires"]]
+        assert plonk_ref.evaluate_gate_constraints(inst["gates"], inst["selector_indices"], inst["groups"], 4, lc, lw, inst["pih"]) == [0] * 4
+    zpp = plonk_ref.zs_partial_products(inst["wires"], inst["sigmas"], k_is, inst["betas"], inst["gammas"], qdf, inst["subgroup"])
+    w_c, w_l = lde_leaves(inst["wires"], rate_bits)
+    cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
+    z_c, z_l = lde_leaves(zpp, rate_bits)
+    bits = degree_bits + rate_bits
+    gate_terms = []
+    for i in range(n * 8):
+        leaf = pyref.reverse_bits(i, bits)
+        gate_terms.append(plonk_ref.evaluate_gate_constraints(inst["gates"], inst["selector_indices"], inst["groups"], 4,
+                                                              cs_l[leaf][:nc], w_l[leaf], inst["pih"]))
+    t = plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, nc, k_is, inst["betas"], inst["gammas"], inst["alphas"], degree_bits,
+                                         rate_bits, qdf, gate_terms)
+    rng = random.Random(6)
+    g = pyref.root_of_unity(degree_bits)
+    for _ in range(2):
+        zeta = rng.randrange(P)
+        wires_z = [poly_eval(c, zeta) for c in w_c]
+        consts_z = [poly_eval(c, zeta) for c in cs_c[:nc]]
+        gt = plonk_ref.evaluate_gate_constraints(inst["gates"], inst["selector_indices"], inst["groups"], 4, consts_z, wires_z, inst["pih"])
+        zh = (pow(zeta, n, P) - 1) % P
+        l0 = zh * plonk_ref.inv(n * (zeta - 1)) % P
+        terms = plonk_ref.vanishing_terms_at(zeta, l0, wires_z, [poly_eval(c, zeta) for c in cs_c[nc:]],
+                                             [poly_eval(z_c[c], zeta) for c in range(2)],
+                                             [poly_eval(z_c[c], g * zeta % P) for c in range(2)],
+                                             [poly_eval(c, zeta) for c in z_c[2:]], k_is, inst["betas"], inst["gammas"], qdf, gt)
+        red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
+        for c in range(2):
+            assert red[c] == zh * poly_eval(t[c], zeta) % P
