@@ -170,6 +170,35 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
 GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint64_t stride, const uint64_t *h_points,
                            uint32_t num_points, uint64_t *d_out, void *ctx);
 
+/* ---- FRI opening pipeline primitives (PolynomialBatch::prove_openings, plonky2/src/fri/oracle.rs:1047-1112;
+ * fri_proof, plonky2/src/fri/prover.rs). Extension-field vectors (F_p[X]/(X^2-7)) are PLANAR on the
+ * device: v[0..len) first components, v[len..2len) second components, so that every transform of an
+ * extension polynomial is two columns of gl_ntt_batch / gl_coset_lde_batch. Host-side scalars
+ * (h_alpha, h_point, h_scale, h_beta) are pairs (c0, c1).
+ *
+ * gl_fri_reduce_polys_base: d_out = sum_j alpha^j * poly_j (ReducingFactor::reduce_polys_base,
+ *   util/reducing.rs:83-95); d_poly_ptrs is a DEVICE array of num_polys device pointers to base
+ *   polynomials of n coefficients each.
+ * gl_fri_divide_by_linear: q = (p(X) - p(z))/(X - z) (polynomial/division.rs:75-88) of the composition
+ *   polynomial (destroyed), written shifted by one: final[0] = 0, final[i+1] = (accumulate ?
+ *   final[i+1]*scale : 0) + q_i  — the update `alpha.shift_poly(&mut final_poly); final_poly += quotient`
+ *   plus the multiplication by X of oracle.rs:1069-1087.
+ * gl_fri_fold: out[k] = sum_{i < 2^arity_bits} c[k*2^arity_bits + i] * beta^i (prover.rs:103-111).
+ * gl_ext2_interleave: rows[2i + c] = plane_c[i] (flatten(), prover.rs:90-95): consecutive groups of
+ *   `arity` extension values become the Merkle leaves of a commit-phase tree (gl_merkle_tree_from_leaves
+ *   with leaf_len = 2*arity).
+ * gl_fri_proof_of_work (SYNCHRONOUS): h_state = the challenger's sponge state with its buffered inputs
+ *   already written, witness_pos = input_buffer.len(); returns the SMALLEST witness w such that
+ *   permute(state with state[witness_pos] = w)[7] has >= min_leading_zeros leading zero bits
+ *   (prover.rs:122-171; the reference's rayon find_any returns an arbitrary one). */
+GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t num_polys, uint64_t n, const uint64_t *h_alpha,
+                                 uint64_t *d_out, void *ctx);
+GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint64_t *h_point, const uint64_t *h_scale, int accumulate,
+                                uint64_t *d_final, void *ctx);
+GlError gl_fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *h_beta, uint64_t *d_out, void *ctx);
+GlError gl_ext2_interleave(const uint64_t *d_planes, uint64_t len, uint64_t *d_rows, void *ctx);
+GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint32_t min_leading_zeros, uint64_t *h_witness, void *ctx);
+
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
 

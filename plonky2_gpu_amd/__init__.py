@@ -5,13 +5,16 @@ The product is the HIP library `libplonky2_hip.so` (C ABI: include/plonky2_hip.h
 the thin host-side mirror of the reference's operator interface for this path
 (`fft_with_options` / `ifft_with_options`, `MerkleTree::new/prove`,
 `PolynomialBatch::from_values/from_coeffs/get_lde_values`) used by the tests and the bench.
-Nothing here computes field arithmetic on the CPU; without the HIP library it raises.
+No bulk field arithmetic happens on the CPU (only scalar transcript glue such as powers of a
+challenge); without the HIP library it raises.
 """
 from ._lib import GL_E_INVALID, GL_E_UNSUPPORTED, Plonky2HipError, load  # noqa: F401
 from .device import Context, DeviceBuffer, Event  # noqa: F401
 from .fft import coset_fft, coset_ifft, coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
 from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401
+from .challenger import Challenger  # noqa: F401
+from .fri import prove_openings  # noqa: F401
 from .prover import GateProgram, all_wires_permutation_partial_products, compute_quotient_polys  # noqa: F401
 
 P = 0xFFFFFFFF00000001

@@ -87,6 +87,11 @@ SIGNATURES = {
     "gl_permutation_partial_products": (GlError, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
     "gl_eval_polys_ext2": (GlError, [_vp, _u64, _u32, _u64, _vp, _u32, _vp, _vp]),
+    "gl_fri_reduce_polys_base": (GlError, [_vp, _u32, _u64, _vp, _vp, _vp]),
+    "gl_fri_divide_by_linear": (GlError, [_vp, _u64, _vp, _vp, _i, _vp, _vp]),
+    "gl_fri_fold": (GlError, [_vp, _u64, _u32, _vp, _vp, _vp]),
+    "gl_ext2_interleave": (GlError, [_vp, _u64, _vp, _vp]),
+    "gl_fri_proof_of_work": (GlError, [_vp, _u32, _u32, _vp, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),
@@ -137,4 +142,8 @@ def check(err):
 
 
 def call(name, *args):
-    check(getattr(load(), name)(*args))
+    """numpy arrays may be passed directly for host-pointer arguments (they stay alive for the call)."""
+    import numpy as np
+
+    conv = [a.ctypes.data if isinstance(a, np.ndarray) else a for a in args]
+    check(getattr(load(), name)(*conv))

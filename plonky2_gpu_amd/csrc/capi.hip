@@ -12,6 +12,7 @@
 #include "merkle.h"
 #include "ntt.h"
 #include "plonk.h"
+#include "fri.h"
 
 using namespace plonky2_hip;
 
@@ -423,6 +424,51 @@ GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t
     hipError_t e = eval_polys_ext2(*tb, d_coeffs, poly_num, log_n, stride, h_points, num_points, d_out, S(ctx)->stream);
     if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "unsupported size for gl_eval_polys_ext2");
     HIP_TRY(e);
+    return ok();
+}
+
+GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t num_polys, uint64_t n, const uint64_t *h_alpha,
+                                 uint64_t *d_out, void *ctx) {
+    if (!ctx || !d_poly_ptrs || !h_alpha || !d_out) return fail(GL_E_INVALID, "null pointer");
+    if (num_polys == 0 || num_polys > (1u << 20) || n == 0) return fail(GL_E_INVALID, "bad sizes");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(fri_reduce_polys_base(*tb, d_poly_ptrs, num_polys, n, h_alpha, d_out, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint64_t *h_point, const uint64_t *h_scale, int accumulate,
+                                uint64_t *d_final, void *ctx) {
+    if (!ctx || !d_composition || !h_point || !h_scale || !d_final) return fail(GL_E_INVALID, "null pointer");
+    if (n < 2 || n > (1ull << 30)) return fail(GL_E_INVALID, "bad length");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    hipError_t e = fri_divide_by_linear_accumulate(*tb, d_composition, n, h_point, h_scale, accumulate, d_final, S(ctx)->stream);
+    if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "point has no inverse / workspace too small");
+    HIP_TRY(e);
+    return ok();
+}
+
+GlError gl_fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *h_beta, uint64_t *d_out, void *ctx) {
+    if (!ctx || !d_coeffs || !h_beta || !d_out) return fail(GL_E_INVALID, "null pointer");
+    hipError_t e = fri_fold(d_coeffs, len, arity_bits, h_beta, d_out, S(ctx)->stream);
+    if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "bad arity / length");
+    HIP_TRY(e);
+    return ok();
+}
+
+GlError gl_ext2_interleave(const uint64_t *d_planes, uint64_t len, uint64_t *d_rows, void *ctx) {
+    if (!ctx || !d_planes || !d_rows) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(fri_interleave(d_planes, len, d_rows, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint32_t min_leading_zeros, uint64_t *h_witness, void *ctx) {
+    if (!ctx || !h_state || !h_witness) return fail(GL_E_INVALID, "null pointer");
+    if (witness_pos >= 8 || min_leading_zeros > 40) return fail(GL_E_INVALID, "bad witness position / difficulty");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    HIP_TRY(fri_proof_of_work(*tb, h_state, witness_pos, min_leading_zeros, h_witness, S(ctx)->stream));
     return ok();
 }
 

@@ -62,13 +62,15 @@ class MerkleTree:
         """MerkleTree::prove (merkle_tree.rs:392-440): sibling digests from the leaf up to the cap."""
         num_layers = _log2_strict(self.n_leaves) - self.cap_height
         assert leaf_index >> (self.cap_height + num_layers) == 0
-        tree_len = self.digests.shape[0] >> self.cap_height
-        tree = self.digests[tree_len * (leaf_index >> num_layers) : tree_len * ((leaf_index >> num_layers) + 1)]
+        tree_len = 2 * (self.n_leaves - (1 << self.cap_height)) >> self.cap_height
+        base = tree_len * (leaf_index >> num_layers)
         pair_index = leaf_index & ((1 << num_layers) - 1)
         siblings = []
         for i in range(num_layers):
             parity = pair_index & 1
             pair_index >>= 1
             siblings_index = (pair_index << (i + 1)) + (1 << i) - 1
-            siblings.append(tree[2 * siblings_index + (1 - parity)])
+            slot = base + 2 * siblings_index + (1 - parity)
+            # one 32-byte read per layer straight from HBM unless the whole array is already on the host
+            siblings.append(self._digests[slot] if self._digests is not None else self.d_digests.download(4 * slot, 4))
         return np.array(siblings, dtype=np.uint64).reshape(num_layers, 4)
