@@ -15,7 +15,7 @@ from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401
 from .challenger import Challenger  # noqa: F401
 from .fri import prove_openings  # noqa: F401
-from .prover import GateProgram, all_wires_permutation_partial_products, compute_quotient_polys  # noqa: F401
+from .prover import CircuitData, GateProgram, all_wires_permutation_partial_products, compute_quotient_polys, prove  # noqa: F401
 
 P = 0xFFFFFFFF00000001
 COSET_SHIFT = 7  # F::coset_shift(), field/src/types.rs:431-433

@@ -38,6 +38,9 @@ class Challenger:
             self.observe_element(a)
             self.observe_element(b)
 
+    def observe_hash(self, h):
+        self.observe_elements(h)
+
     def observe_cap(self, cap):  # challenger.rs:81-85
         for h in cap:
             self.observe_elements(h)
@@ -60,3 +63,16 @@ class Challenger:
         self.input_buffer = []
         self.sponge_state = self._permute(self.sponge_state)
         self.output_buffer = list(self.sponge_state[:SPONGE_RATE])
+
+
+def hash_no_pad(ctx, inputs):
+    """hash_n_to_hash_no_pad (plonky2/src/hash/hashing.rs:81-108) of a short host vector (public
+    inputs, circuit digest parts); the permutation runs on the device."""
+    c = Challenger(ctx)
+    state = [0] * SPONGE_WIDTH
+    inputs = [int(x) % P for x in inputs]
+    for off in range(0, len(inputs), SPONGE_RATE):
+        chunk = inputs[off : off + SPONGE_RATE]
+        state[: len(chunk)] = chunk
+        state = c._permute(state)
+    return state[:4]

@@ -80,6 +80,11 @@ class PolynomialBatch:
         """Same as from_values for a trace already resident in HBM (transformed in place)."""
         return cls._commit(ctx, d_values, True, n_polys, log_n, rate_bits, blinding, cap_height, salt, leaf_major)
 
+    @classmethod
+    def from_coeffs_device(cls, ctx, d_coeffs, n_polys, log_n, rate_bits, blinding, cap_height, salt=None, leaf_major=True):
+        """Same as from_coeffs for coefficients already resident in HBM (kept as `d_polynomials`)."""
+        return cls._commit(ctx, d_coeffs, False, n_polys, log_n, rate_bits, blinding, cap_height, salt, leaf_major)
+
     # -- accessors --------------------------------------------------------------------------
     @property
     def polynomials(self):

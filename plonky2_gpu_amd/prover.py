@@ -1,4 +1,4 @@
-"""Host-side mirror of the permutation-argument steps of plonky2/src/plonk/prover.rs."""
+"""Host-side mirror of plonky2/src/plonk/prover.rs: prove() and the stages it calls."""
 import ctypes
 
 import numpy as np
@@ -71,3 +71,133 @@ class GateProgram:
             self.d_instrs.ptr, self.d_gates.ptr, self.d_imms.ptr if self.d_imms else None, len(gate_instrs), len(groups),
             (ctypes.c_uint64 * 4)(*[int(v) for v in public_inputs_hash]),
         )
+
+    def set_public_inputs_hash(self, pih):
+        """the hash is per proof (prover.rs:52), the programs per circuit"""
+        self.struct.public_inputs_hash = (ctypes.c_uint64 * 4)(*[int(v) for v in pih])
+
+
+class CircuitData:
+    """What prove() needs of CommonCircuitData + ProverOnlyCircuitData (plonk/circuit_data.rs), resident
+    in HBM: the preprocessed constants_sigmas commitment, the sigma value columns, k_is and the gate
+    programs. `circuit` is the plain dict described in INTEGRATION.md section 7."""
+
+    def __init__(self, ctx, circuit):
+        from . import gate_program as gp
+        from .polynomial_batch import PolynomialBatch
+
+        self.ctx = ctx
+        for k in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges", "quotient_degree_factor",
+                  "num_gate_constraints", "fri_params", "circuit_digest"):
+            setattr(self, k, circuit[k])
+        fp = self.fri_params
+        cs = np.ascontiguousarray(list(circuit["constants"]) + list(circuit["sigmas"]), dtype=np.uint64)
+        self.constants_sigmas_commitment = PolynomialBatch.from_values(ctx, cs, fp["rate_bits"], False, fp["cap_height"])
+        self.d_sigmas = DeviceBuffer.from_host(ctx, _host_u64(circuit["sigmas"]))
+        self.d_k_is = DeviceBuffer.from_host(ctx, _host_u64(circuit["k_is"]))
+        mk = dict(noop=lambda p: gp.noop_gate(), constant=gp.constant_gate, public_input=lambda p: gp.public_input_gate(),
+                  arithmetic=gp.arithmetic_gate)
+        self.gate_program = GateProgram(ctx, [mk[kind](param) for kind, param in circuit["gates"]], circuit["selector_indices"],
+                                        circuit["groups"], [0, 0, 0, 0])
+
+    def fri_instance(self, zeta):
+        """get_fri_instance (plonk/circuit_data.rs:351-371)"""
+        from .fri import ext_mul
+
+        nc = self.num_challenges
+        counts = [self.num_constants + self.num_routed_wires, self.num_wires,
+                  nc * (1 + num_partial_products(self.num_routed_wires, self.quotient_degree_factor)), nc * self.quotient_degree_factor]
+        all_polys = [(oi, pi) for oi, k in enumerate(counts) for pi in range(k)]
+        g = pow(ROOT_OF_UNITY_2_32, 1 << (32 - self.degree_bits), P)
+        return dict(batches=[(zeta, all_polys), (ext_mul((g, 0), zeta), [(2, i) for i in range(nc)])])
+
+
+P = 0xFFFFFFFF00000001
+ROOT_OF_UNITY_2_32 = 1753635133440165772  # field/src/goldilocks_field.rs:89
+
+
+def _pairs(a):
+    return [(int(x[0]), int(x[1])) for x in a]
+
+
+def prove(ctx, cd, wires, public_inputs, timing=None):
+    """prove() (plonk/prover.rs:40-233) from the full witness on: `wires` is the [num_wires][n] matrix of
+    wire values (host array, or a DeviceBuffer that is left untouched). Every polynomial, LDE and tree
+    stays in HBM; the host sees caps, challenges, openings and the FRI proof."""
+    import time
+
+    from . import fri
+    from .challenger import Challenger, hash_no_pad
+    from .polynomial_batch import PolynomialBatch
+
+    def stage(name, t0):
+        if timing is not None:
+            ctx.synchronize()
+            timing[name] = timing.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
+    fp = cd.fri_params
+    rate_bits, cap_height = fp["rate_bits"], fp["cap_height"]
+    db, n = cd.degree_bits, 1 << cd.degree_bits
+    nch, qdf, num_routed = cd.num_challenges, cd.quotient_degree_factor, cd.num_routed_wires
+    t = time.perf_counter()
+    pih = hash_no_pad(ctx, public_inputs)
+    d_wire_values = wires if isinstance(wires, DeviceBuffer) else DeviceBuffer.from_host(ctx, _host_u64(wires))
+    d_w = DeviceBuffer(ctx, cd.num_wires * n)
+    _lib.call("gl_memcpy_d2d", d_w.ptr, d_wire_values.ptr, cd.num_wires * n * 8, ctx.ptr)
+    t = stage("upload witness", t)
+    wires_c = PolynomialBatch.from_values_device(ctx, d_w, cd.num_wires, db, rate_bits, False, cap_height)
+    t = stage("wires commitment", t)
+    ch = Challenger(ctx)
+    ch.observe_hash(cd.circuit_digest)
+    ch.observe_hash(pih)
+    ch.observe_cap(wires_c.merkle_tree.cap.tolist())
+    betas, gammas = ch.get_n_challenges(nch), ch.get_n_challenges(nch)
+    if not qdf < num_routed:
+        raise ValueError("When the number of routed wires is smaller that the degree, we should change the logic to avoid "
+                         "computing partial products.")
+    d_zpp, n_cols = all_wires_permutation_partial_products(ctx, d_wire_values, n, cd.d_sigmas, n, cd.d_k_is, betas, gammas, num_routed,
+                                                           qdf, db)
+    t = stage("partial products", t)
+    zs_c = PolynomialBatch.from_values_device(ctx, d_zpp, n_cols, db, rate_bits, False, cap_height)
+    t = stage("zs partial products commitment", t)
+    ch.observe_cap(zs_c.merkle_tree.cap.tolist())
+    alphas = ch.get_n_challenges(nch)
+    cd.gate_program.set_public_inputs_hash(pih)
+    d_q = compute_quotient_polys(ctx, wires_c, cd.constants_sigmas_commitment, zs_c, cd.num_constants, num_routed, cd.d_k_is, betas,
+                                 gammas, alphas, qdf, None, cd.num_gate_constraints, cd.gate_program)
+    t = stage("quotient polys", t)
+    qdb = (qdf - 1).bit_length()
+    if qdf == 1 << qdb:
+        d_chunks = d_q  # [nch][n << qdb] read flat is already [nch * qdf][n]
+    else:
+        d_chunks = DeviceBuffer(ctx, nch * qdf * n)
+        for c in range(nch):
+            tail = d_q.download((c << (db + qdb)) + qdf * n, (n << qdb) - qdf * n)
+            if tail.any():
+                raise ValueError("Quotient has failed, the vanishing polynomial is not divisible by Z_H")
+            _lib.call("gl_memcpy_d2d", d_chunks.ptr + 8 * c * qdf * n, d_q.ptr + 8 * (c << (db + qdb)), 8 * qdf * n, ctx.ptr)
+    quot_c = PolynomialBatch.from_coeffs_device(ctx, d_chunks, nch * qdf, db, rate_bits, False, cap_height)
+    t = stage("quotient commitment", t)
+    ch.observe_cap(quot_c.merkle_tree.cap.tolist())
+    zeta = ch.get_extension_challenge()
+    if fri.ext_pow(zeta, n) == (1, 0):
+        raise ValueError("Opening point is in the subgroup.")
+    g = pow(ROOT_OF_UNITY_2_32, 1 << (32 - db), P)
+    g_zeta = fri.ext_mul((g, 0), zeta)
+    cs_eval = _pairs(cd.constants_sigmas_commitment.eval_polynomials_ext2([zeta])[0])
+    zs_evals = zs_c.eval_polynomials_ext2([zeta, g_zeta])
+    zs_eval, zs_next = _pairs(zs_evals[0]), _pairs(zs_evals[1])
+    openings = dict(constants=cs_eval[: cd.num_constants], plonk_sigmas=cs_eval[cd.num_constants :],
+                    wires=_pairs(wires_c.eval_polynomials_ext2([zeta])[0]), plonk_zs=zs_eval[:nch], plonk_zs_next=zs_next[:nch],
+                    partial_products=zs_eval[nch:], quotient_polys=_pairs(quot_c.eval_polynomials_ext2([zeta])[0]))
+    t = stage("opening set", t)
+    # OpeningSet::to_fri_openings (plonk/proof.rs:336-356)
+    ch.observe_extension_elements(openings["constants"] + openings["plonk_sigmas"] + openings["wires"] + openings["plonk_zs"]
+                                  + openings["partial_products"] + openings["quotient_polys"])
+    ch.observe_extension_elements(openings["plonk_zs_next"])
+    opening_proof = fri.prove_openings(ctx, cd.fri_instance(zeta), [cd.constants_sigmas_commitment, wires_c, zs_c, quot_c], ch, fp)
+    stage("opening proof (FRI)", t)
+    return dict(wires_cap=wires_c.merkle_tree.cap.tolist(), plonk_zs_partial_products_cap=zs_c.merkle_tree.cap.tolist(),
+                quotient_polys_cap=quot_c.merkle_tree.cap.tolist(), openings=openings, opening_proof=opening_proof,
+                public_inputs=[int(x) for x in public_inputs])

@@ -58,7 +58,7 @@ def make_instance(degree_bits=4, num_wires=12, num_routed=10, num_constants=2, n
                 betas=betas, gammas=gammas, alphas=alphas, num_routed=num_routed, num_constants=num_constants)
 
 
-def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenges=2):
+def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenges=2, public_inputs=None):
     """A tiny real circuit: rows of NoopGate / ConstantGate{2} / PublicInputGate / ArithmeticGate{3}
     (plonky2/src/gates/{noop,constant,public_input,arithmetic_base}.rs) with a satisfying witness and
     copy constraints between arithmetic inputs. 12 wires, all routed."""
@@ -76,7 +76,7 @@ def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenge
     else:
         groups, selector_indices = [(0, 4)], [0, 0, 0, 0]
     num_selectors = len(groups)
-    pih = [rng.randrange(P) for _ in range(4)]
+    pih = [rng.randrange(P) for _ in range(4)] if public_inputs is None else pyref.hash_no_pad(public_inputs)
     row_gate = [rng.choice([0, 1, 3, 3, 3]) for _ in range(n)]
     row_gate[0] = 2  # the public-input gate sits in the first row
     # constants: selector columns, then the two gate constants
@@ -113,3 +113,23 @@ def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenge
                 betas=[rng.randrange(P) for _ in range(num_challenges)], gammas=[rng.randrange(P) for _ in range(num_challenges)],
                 alphas=[rng.randrange(P) for _ in range(num_challenges)], num_routed=num_routed, num_constants=num_selectors + 2,
                 gates=gates, groups=groups, selector_indices=selector_indices, pih=pih, num_gate_constraints=4, row_gate=row_gate)
+
+
+def make_circuit(degree_bits=4, seed=1, two_groups=False, arity_bits=(2, 1), rate_bits=3, cap_height=1, pow_bits=3, num_queries=3):
+    """The tiny circuit above as the dict oracle/prove_ref.py and plonky2_gpu_amd.prove() take
+    (CommonCircuitData + ProverOnlyCircuitData of plonk/circuit_data.rs), plus its witness."""
+    from oracle import prove_ref
+
+    rng = random.Random(seed * 7919)
+    public_inputs = [rng.randrange(P) for _ in range(3)]
+    inst = make_circuit_instance(degree_bits, seed, two_groups, public_inputs=public_inputs)
+    cs = prove_ref.commit_from_values(inst["constants"] + inst["sigmas"], rate_bits, cap_height)
+    circuit = dict(degree_bits=degree_bits, num_wires=12, num_routed_wires=12, num_constants=inst["num_constants"], num_challenges=2,
+                   quotient_degree_factor=8, k_is=inst["k_is"],
+                   gates=[("noop", None), ("constant", 2), ("public_input", None), ("arithmetic", 3)],
+                   selector_indices=inst["selector_indices"], groups=inst["groups"], num_gate_constraints=4,
+                   constants=inst["constants"], sigmas=inst["sigmas"],
+                   fri_params=dict(rate_bits=rate_bits, cap_height=cap_height, reduction_arity_bits=list(arity_bits),
+                                   proof_of_work_bits=pow_bits, num_query_rounds=num_queries),
+                   constants_sigmas=cs, circuit_digest=prove_ref.circuit_digest(cs["cap"], degree_bits))
+    return circuit, inst["wires"], public_inputs

@@ -1,0 +1,38 @@
+"""prove() on the device vs oracle/prove_ref.py: the proof is identical element for element and the
+oracle's verifier (which recomputes all challenges from the proof) accepts it."""
+import pytest
+
+from gpu_util import gpu  # noqa: F401
+from oracle import prove_ref
+from plonk_instance import make_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("degree_bits,two_groups,arity_bits", [(4, False, (2, 1)), (4, True, (1, 2)), (5, True, (3,)), (6, False, (4,))])
+def test_prove_equals_oracle_and_verifies(gpu, degree_bits, two_groups, arity_bits):
+    import plonky2_gpu_amd as pg
+
+    circuit, wires, pis = make_circuit(degree_bits, seed=3 + degree_bits, two_groups=two_groups, arity_bits=arity_bits)
+    cd = pg.CircuitData(gpu, circuit)
+    assert cd.constants_sigmas_commitment.merkle_tree.cap.tolist() == circuit["constants_sigmas"]["cap"]
+    timing = {}
+    proof = pg.prove(gpu, cd, wires, pis, timing)
+    assert prove_ref.verify(circuit, proof)
+    if degree_bits <= 5:
+        exp = prove_ref.prove(circuit, wires, pis)
+        for k in ("wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap", "openings", "public_inputs"):
+            assert proof[k] == exp[k], k
+        assert proof["opening_proof"] == exp["opening_proof"]
+    assert set(timing) >= {"wires commitment", "quotient polys", "opening proof (FRI)"}
+
+
+def test_unsatisfied_witness_is_rejected_by_the_verifier(gpu):
+    import plonky2_gpu_amd as pg
+
+    circuit, wires, pis = make_circuit(4, seed=5)
+    wires = [list(c) for c in wires]
+    wires[3] = [(v + 1) % prove_ref.P for v in wires[3]]
+    proof = pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)
+    with pytest.raises(AssertionError):
+        prove_ref.verify(circuit, proof)

@@ -1,0 +1,51 @@
+"""Pins oracle/prove_ref.py the way the reference pins its prover: prove -> verify, and the verifier
+rejects anything tampered with (plonky2/src/plonk/prover.rs + verifier.rs)."""
+import copy
+
+import pytest
+
+from oracle import prove_ref, pyref
+from plonk_instance import make_circuit
+
+P = pyref.P
+
+
+@pytest.mark.parametrize("degree_bits,two_groups,arity_bits", [(4, False, (2, 1)), (4, True, (1, 2)), (5, True, (3,))])
+def test_prove_then_verify(degree_bits, two_groups, arity_bits):
+    circuit, wires, pis = make_circuit(degree_bits, seed=3 + degree_bits, two_groups=two_groups, arity_bits=arity_bits)
+    proof = prove_ref.prove(circuit, wires, pis)
+    assert prove_ref.verify(circuit, proof)
+
+
+def test_verifier_rejects_tampering():
+    circuit, wires, pis = make_circuit(4, seed=11)
+    proof = prove_ref.prove(circuit, wires, pis)
+    assert prove_ref.verify(circuit, proof)
+
+    def bump(pair):
+        return ((pair[0] + 1) % P, pair[1])
+
+    for mutate in (
+        lambda p: p["openings"]["wires"].__setitem__(3, bump(p["openings"]["wires"][3])),
+        lambda p: p["openings"]["quotient_polys"].__setitem__(0, bump(p["openings"]["quotient_polys"][0])),
+        lambda p: p["openings"]["plonk_zs_next"].__setitem__(1, bump(p["openings"]["plonk_zs_next"][1])),
+        lambda p: p["opening_proof"]["final_poly"].__setitem__(0, bump(p["opening_proof"]["final_poly"][0])),
+        lambda p: p["public_inputs"].__setitem__(0, (p["public_inputs"][0] + 1) % P),
+        lambda p: p["wires_cap"][0].__setitem__(0, (p["wires_cap"][0][0] + 1) % P),
+        lambda p: p["opening_proof"].__setitem__("pow_witness", p["opening_proof"]["pow_witness"] + 1),
+    ):
+        bad = copy.deepcopy(proof)
+        mutate(bad)
+        with pytest.raises(AssertionError):
+            prove_ref.verify(circuit, bad)
+
+
+def test_unsatisfied_witness_does_not_verify():
+    """quotient_degree_factor 8 is a power of two, so nothing is trimmed and the prover itself cannot
+    notice (prover.rs:161-165 only checks the trimmed tail); the verifier does."""
+    circuit, wires, pis = make_circuit(4, seed=5)
+    wires = [list(c) for c in wires]
+    wires[3] = [(v + 1) % P for v in wires[3]]  # breaks every arithmetic row's first output
+    proof = prove_ref.prove(circuit, wires, pis)
+    with pytest.raises(AssertionError):
+        prove_ref.verify(circuit, proof)
