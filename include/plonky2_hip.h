@@ -202,6 +202,20 @@ GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
 
+/* The transcript's sponge: h_state[12] (in/out, host) absorbs n_blocks full rate-8 blocks of h_inputs in
+ * overwrite mode, one permutation per block — Challenger::duplexing (plonky2/src/iop/challenger.rs:131-149)
+ * repeated, and hash_n_to_hash_no_pad (hash/hashing.rs:81-108) for whole blocks. SYNCHRONOUS. */
+GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n_blocks, void *ctx);
+
+/* MerkleTree::prove (plonky2/src/hash/merkle_tree.rs:392-440) and the leaf itself for `count` leaf
+ * indices in one launch and one copy — what fri_prover_query_round (fri/prover.rs:199-260) does per
+ * query and tree. Element j of leaf i is read at d_leaves[i*row_stride + j*elem_stride] (leaf-major rows:
+ * (leaf_len, 1); the LDE's columns: (1, n_leaves)). Host outputs: h_out_leaves[count][leaf_len],
+ * h_out_siblings[count][log2(n_leaves) - cap_height][4]. SYNCHRONOUS. */
+GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                             uint32_t cap_height, const uint64_t *d_digests, const uint64_t *h_indices, uint32_t count,
+                             uint64_t *h_out_leaves, uint64_t *h_out_siblings, void *ctx);
+
 /* MerkleTree::new (plonky2/src/hash/merkle_tree.rs:283-319) over n_leaves (power of two) leaves of
  * leaf_len elements; leaf hash = hash_or_noop (plonk/config.rs:56-67).
  *   _columns: d_cols[j*col_stride + i] = element j of leaf i   (the NTT's output layout)

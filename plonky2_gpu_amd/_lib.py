@@ -93,6 +93,8 @@ SIGNATURES = {
     "gl_ext2_interleave": (GlError, [_vp, _u64, _vp, _vp]),
     "gl_fri_proof_of_work": (GlError, [_vp, _u32, _u32, _vp, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
+    "gl_sponge_absorb": (GlError, [_vp, _vp, _u32, _vp]),
+    "gl_merkle_open_batch": (GlError, [_vp, _u64, _u64, _u32, _u64, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),
     "gl_transpose": (GlError, [_vp, _vp, _u32, _u64, _u64, _vp]),

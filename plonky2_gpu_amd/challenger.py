@@ -4,7 +4,6 @@ glue — buffers, overwrite-mode duplexing — is host logic exactly like the re
 import numpy as np
 
 from . import _lib
-from .device import DeviceBuffer
 
 SPONGE_RATE, SPONGE_WIDTH = 8, 12
 P = 0xFFFFFFFF00000001
@@ -16,34 +15,44 @@ class Challenger:
         self.sponge_state = [0] * SPONGE_WIDTH
         self.input_buffer = []
         self.output_buffer = []
-        self._buf = DeviceBuffer(ctx, SPONGE_WIDTH)
+
+    def _absorb(self, state, blocks):
+        """state after absorbing len(blocks)/8 full rate blocks (overwrite mode), one device call"""
+        st = np.array(state, dtype=np.uint64)
+        inp = np.array(blocks, dtype=np.uint64)
+        _lib.call("gl_sponge_absorb", st, inp, inp.size // SPONGE_RATE, self.ctx.ptr)
+        return [int(v) for v in st]
 
     def _permute(self, state):
-        self._buf.upload(np.array(state, dtype=np.uint64))
-        _lib.call("gl_poseidon_permute_batch", self._buf.ptr, 1, self.ctx.ptr)
-        return [int(v) for v in self._buf.download()]
+        return self._absorb(state, state[:SPONGE_RATE])
 
     def observe_element(self, e):  # challenger.rs:43-53
-        self.output_buffer = []
-        self.input_buffer.append(int(e) % P)
-        if len(self.input_buffer) == SPONGE_RATE:
-            self.duplexing()
+        self.observe_elements([e])
 
     def observe_elements(self, es):
-        for e in es:
-            self.observe_element(e)
+        """observe_element for each e (challenger.rs:43-59). Every time the input buffer fills the
+        reference duplexes; the outputs of all but the last of those duplexings are discarded by the
+        next observe, so all full blocks are absorbed by a single device call."""
+        es = [int(e) % P for e in es]
+        if not es:
+            return
+        buf = self.input_buffer + es
+        full = len(buf) // SPONGE_RATE * SPONGE_RATE
+        self.output_buffer = []
+        if full:
+            self.sponge_state = self._absorb(self.sponge_state, buf[:full])
+            if full == len(buf):  # the last observe triggered the duplexing: its output is live
+                self.output_buffer = list(self.sponge_state[:SPONGE_RATE])
+        self.input_buffer = buf[full:]
 
     def observe_extension_elements(self, es):
-        for a, b in es:
-            self.observe_element(a)
-            self.observe_element(b)
+        self.observe_elements([x for e in es for x in e])
 
     def observe_hash(self, h):
         self.observe_elements(h)
 
     def observe_cap(self, cap):  # challenger.rs:81-85
-        for h in cap:
-            self.observe_elements(h)
+        self.observe_elements([x for h in cap for x in h])
 
     def get_challenge(self):  # challenger.rs:87-97
         if self.input_buffer or not self.output_buffer:
@@ -71,8 +80,10 @@ def hash_no_pad(ctx, inputs):
     c = Challenger(ctx)
     state = [0] * SPONGE_WIDTH
     inputs = [int(x) % P for x in inputs]
-    for off in range(0, len(inputs), SPONGE_RATE):
-        chunk = inputs[off : off + SPONGE_RATE]
-        state[: len(chunk)] = chunk
+    full = len(inputs) // SPONGE_RATE * SPONGE_RATE
+    if full:
+        state = c._absorb(state, inputs[:full])
+    if full < len(inputs):  # a short last chunk leaves the old lanes in place
+        state[: len(inputs) - full] = inputs[full:]
         state = c._permute(state)
     return state[:4]

@@ -478,6 +478,48 @@ GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx)
     return ok();
 }
 
+GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n_blocks, void *ctx) {
+    if (!ctx || !h_state || (!h_inputs && n_blocks)) return fail(GL_E_INVALID, "null pointer");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    if (12 + 8ull * n_blocks > tb->scratch_elems) return fail(GL_E_INVALID, "too many blocks");
+    hipStream_t st = S(ctx)->stream;
+    uint64_t *d_state = tb->scratch, *d_in = tb->scratch + 12;
+    HIP_TRY(hipMemcpyAsync(d_state, h_state, 96, hipMemcpyHostToDevice, st));
+    if (n_blocks) HIP_TRY(hipMemcpyAsync(d_in, h_inputs, 64ull * n_blocks, hipMemcpyHostToDevice, st));
+    HIP_TRY(sponge_absorb(d_state, d_in, n_blocks, st));
+    HIP_TRY(hipMemcpyAsync(h_state, d_state, 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ok();
+}
+
+GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                             uint32_t cap_height, const uint64_t *d_digests, const uint64_t *h_indices, uint32_t count,
+                             uint64_t *h_out_leaves, uint64_t *h_out_siblings, void *ctx) {
+    if (!ctx || !d_leaves || !h_indices || !h_out_leaves || (!h_out_siblings && (n_leaves >> cap_height) > 1))
+        return fail(GL_E_INVALID, "null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || cap_height > 63 || (1ull << cap_height) > n_leaves)
+        return fail(GL_E_INVALID, "bad tree shape");
+    if (count == 0) return ok();
+    for (uint32_t q = 0; q < count; q++)
+        if (h_indices[q] >= n_leaves) return fail(GL_E_INVALID, "leaf index out of range");
+    uint32_t lg = 0;
+    while ((1ull << lg) < n_leaves) lg++;
+    const uint64_t layers = lg - cap_height, need = (uint64_t)count * (1 + leaf_len + 4 * layers);
+    if (layers && !d_digests) return fail(GL_E_INVALID, "null pointer");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));
+    if (need > tb->scratch_elems) return fail(GL_E_INVALID, "too many openings for the workspace");
+    hipStream_t st = S(ctx)->stream;
+    uint64_t *d_idx = tb->scratch, *d_ol = d_idx + count, *d_os = d_ol + (uint64_t)count * leaf_len;
+    HIP_TRY(hipMemcpyAsync(d_idx, h_indices, 8ull * count, hipMemcpyHostToDevice, st));
+    HIP_TRY(merkle_open_batch(d_leaves, row_stride, elem_stride, leaf_len, n_leaves, cap_height, d_digests, d_idx, count, d_ol, d_os, st));
+    HIP_TRY(hipMemcpyAsync(h_out_leaves, d_ol, 8ull * count * leaf_len, hipMemcpyDeviceToHost, st));
+    if (layers) HIP_TRY(hipMemcpyAsync(h_out_siblings, d_os, 32ull * count * layers, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ok();
+}
+
 GlError gl_merkle_tree_from_columns(const uint64_t *d_cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
                                     uint32_t cap_height, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
     if (!ctx || !d_cols || !d_cap) return fail(GL_E_INVALID, "null pointer");

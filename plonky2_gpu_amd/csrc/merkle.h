@@ -14,6 +14,12 @@ hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64
                                  uint64_t *digests, uint64_t *cap, hipStream_t stream);
 // states[count][12] permuted in place, canonical output.
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t stream);
+// state[12] <- overwrite-mode sponge over n_blocks full rate blocks of inputs (one lane, serial).
+hipError_t sponge_absorb(uint64_t *d_state, const uint64_t *d_inputs, uint32_t n_blocks, hipStream_t stream);
+// leaves + Merkle paths of `count` leaf indices: element j of leaf i at leaves[i*row_stride + j*elem_stride].
+hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                             uint32_t cap_height, const uint64_t *digests, const uint64_t *d_idx, uint32_t count, uint64_t *out_leaves,
+                             uint64_t *out_sib, hipStream_t stream);
 // cols[c*col_stride + r] -> rows[r*n_cols + c]
 hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
                                    uint64_t col_stride, hipStream_t stream);

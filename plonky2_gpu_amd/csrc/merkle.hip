@@ -151,6 +151,39 @@ __global__ __launch_bounds__(256) void permute_batch_kernel(uint64_t *states, ui
     for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
 }
 
+// The transcript's sponge (iop/challenger.rs:131-149 run over several full rate blocks): serial by
+// definition, so one lane walks the blocks; state[0..8) is overwritten by each block, then permuted.
+__global__ void sponge_absorb_kernel(uint64_t *state, const uint64_t *inputs, uint32_t n_blocks) {
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = state[k];
+    for (uint32_t b = 0; b < n_blocks; b++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = inputs[8 * b + k];
+        poseidon::permute(s);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) state[k] = gl::canon(s[k]);
+}
+
+// MerkleTree::prove (merkle_tree.rs:392-440) + the leaf itself for `count` leaf indices at once:
+// block q copies leaf idx[q] (leaf-major rows or column-major columns) and its sibling digests.
+__global__ __launch_bounds__(64) void merkle_open_kernel(const uint64_t *__restrict__ leaves, uint64_t row_stride, uint64_t elem_stride,
+                                                         uint32_t leaf_len, const uint64_t *__restrict__ digests, uint32_t num_layers,
+                                                         uint64_t subtree_digests, const uint64_t *__restrict__ idx,
+                                                         uint64_t *__restrict__ out_leaves, uint64_t *__restrict__ out_sib) {
+    const uint64_t q = blockIdx.x, leaf = idx[q];
+    for (uint32_t j = threadIdx.x; j < leaf_len; j += blockDim.x) out_leaves[q * leaf_len + j] = leaves[leaf * row_stride + j * elem_stride];
+    const uint64_t base = subtree_digests * (leaf >> num_layers);
+    for (uint32_t t = threadIdx.x; t < 4 * num_layers; t += blockDim.x) {
+        uint32_t l = t >> 2, k = t & 3;
+        uint64_t node = (leaf & ((1ull << num_layers) - 1)) >> l;  // this path's node in layer l
+        uint64_t slot = base + digest_slot(node ^ 1, l);
+        out_sib[(q * num_layers + l) * 4 + k] = digests[4 * slot + k];
+    }
+}
+
 // [n_cols][col_stride] column-major -> [n_rows][n_cols] leaf-major through a 64x64 LDS tile
 // (+1 pad): both the global read (along rows of a column) and the global write (along columns of
 // a row) are 512 B contiguous per wavefront.
@@ -223,6 +256,24 @@ hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(permute_batch_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, states, count);
+    return hipGetLastError();
+}
+
+hipError_t sponge_absorb(uint64_t *d_state, const uint64_t *d_inputs, uint32_t n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(sponge_absorb_kernel, dim3(1), dim3(64), 0, stream, d_state, d_inputs, n_blocks);
+    return hipGetLastError();
+}
+
+hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                             uint32_t cap_height, const uint64_t *digests, const uint64_t *d_idx, uint32_t count, uint64_t *out_leaves,
+                             uint64_t *out_sib, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    uint32_t lg = 0;
+    while ((1ull << lg) < n_leaves) lg++;
+    const uint32_t num_layers = lg - cap_height;
+    const uint64_t subtree_digests = 2 * ((n_leaves >> cap_height) - 1);
+    hipLaunchKernelGGL(merkle_open_kernel, dim3(count), dim3(64), 0, stream, leaves, row_stride, elem_stride, leaf_len, digests, num_layers,
+                       subtree_digests, d_idx, out_leaves, out_sib);
     return hipGetLastError();
 }
 

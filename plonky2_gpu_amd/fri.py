@@ -93,25 +93,34 @@ def fri_proof_of_work(ctx, challenger, params):
 
 def fri_prover_query_rounds(initial_trees, trees, challenger, n, params):
     """fri/prover.rs:173-260: leaves and Merkle paths fetched from HBM per query."""
+    indices = [rand % n for rand in challenger.get_n_challenges(params["num_query_rounds"])]
+    # one gather per tree for all queries instead of a leaf read and log(n) digest reads per query
+    initial = [t.open_batch(indices) for t in initial_trees]
+    steps, cur = [], list(indices)
+    for i, t in enumerate(trees):
+        cur = [x >> params["reduction_arity_bits"][i] for x in cur]
+        steps.append(t.open_batch(cur))
     rounds = []
-    for rand in challenger.get_n_challenges(params["num_query_rounds"]):
-        x_index = rand % n
-        initial = [([int(v) for v in t.get(x_index)], t.prove(x_index).tolist()) for t in initial_trees]
-        steps = []
-        for i, t in enumerate(trees):
-            ab = params["reduction_arity_bits"][i]
-            leaf = [int(v) for v in t.get(x_index >> ab)]
-            steps.append(dict(evals=[(leaf[2 * k], leaf[2 * k + 1]) for k in range(len(leaf) // 2)],
-                              merkle_proof=t.prove(x_index >> ab).tolist()))
-            x_index >>= ab
-        rounds.append(dict(initial_trees_proof=initial, steps=steps))
+    for q in range(len(indices)):
+        rounds.append(dict(
+            initial_trees_proof=[(lv[q].tolist(), sib[q].tolist()) for lv, sib in initial],
+            steps=[dict(evals=[(int(a), int(b)) for a, b in lv[q].reshape(-1, 2)], merkle_proof=sib[q].tolist()) for lv, sib in steps]))
     return rounds
 
 
-def prove_openings(ctx, instance, oracles, challenger, params):
+def prove_openings(ctx, instance, oracles, challenger, params, timing=None):
     """PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params) (fri/oracle.rs:1047-1112).
     instance["batches"] = [(point, [(oracle_index, polynomial_index), ...]), ...]; oracles are
     PolynomialBatch objects committed with leaf_major=True."""
+    import time
+
+    def stage(name, t0):
+        if timing is not None:
+            ctx.synchronize()
+            timing[name] = timing.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
+    t = time.perf_counter()
     alpha = challenger.get_extension_challenge()
     n = 1 << oracles[0].degree_log
     d_final = DeviceBuffer(ctx, 2 * n)
@@ -129,8 +138,12 @@ def prove_openings(ctx, instance, oracles, challenger, params):
         d_comp.free()
         first = False
     n_lde = n << params["rate_bits"]
+    t = stage("fri: combine + divide", t)
     trees, final_coeffs = fri_committed_trees(ctx, d_final, n, challenger, params)
+    t = stage("fri: commit phase", t)
     pow_witness = fri_proof_of_work(ctx, challenger, params)
+    t = stage("fri: proof of work", t)
     rounds = fri_prover_query_rounds([o.merkle_tree for o in oracles], trees, challenger, n_lde, params)
+    stage("fri: query rounds", t)
     return dict(commit_phase_merkle_caps=[t.cap.tolist() for t in trees], query_round_proofs=rounds, final_poly=final_coeffs,
                 pow_witness=pow_witness)

@@ -74,3 +74,17 @@ class MerkleTree:
             # one 32-byte read per layer straight from HBM unless the whole array is already on the host
             siblings.append(self._digests[slot] if self._digests is not None else self.d_digests.download(4 * slot, 4))
         return np.array(siblings, dtype=np.uint64).reshape(num_layers, 4)
+
+    def open_batch(self, indices):
+        """get(i) and prove(i) for many leaves with one launch and one copy (what
+        fri_prover_query_round, fri/prover.rs:199-260, asks of every tree for every query).
+        Returns (leaves [count, leaf_len], siblings [count, num_layers, 4])."""
+        if self.d_leaves is None:
+            raise ValueError("leaf-major copy was not requested")
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        layers = _log2_strict(self.n_leaves) - self.cap_height
+        leaves = np.empty((idx.size, self.leaf_len), dtype=np.uint64)
+        sib = np.empty((idx.size, layers, 4), dtype=np.uint64)
+        _lib.call("gl_merkle_open_batch", self.d_leaves.ptr, self.leaf_len, 1, self.leaf_len, self.n_leaves, self.cap_height,
+                  self.d_digests.ptr if layers else None, idx, idx.size, leaves, sib if layers else None, self.ctx.ptr)
+        return leaves, sib

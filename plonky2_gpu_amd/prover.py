@@ -196,7 +196,7 @@ def prove(ctx, cd, wires, public_inputs, timing=None):
     ch.observe_extension_elements(openings["constants"] + openings["plonk_sigmas"] + openings["wires"] + openings["plonk_zs"]
                                   + openings["partial_products"] + openings["quotient_polys"])
     ch.observe_extension_elements(openings["plonk_zs_next"])
-    opening_proof = fri.prove_openings(ctx, cd.fri_instance(zeta), [cd.constants_sigmas_commitment, wires_c, zs_c, quot_c], ch, fp)
+    opening_proof = fri.prove_openings(ctx, cd.fri_instance(zeta), [cd.constants_sigmas_commitment, wires_c, zs_c, quot_c], ch, fp, timing)
     stage("opening proof (FRI)", t)
     return dict(wires_cap=wires_c.merkle_tree.cap.tolist(), plonk_zs_partial_products_cap=zs_c.merkle_tree.cap.tolist(),
                 quotient_polys_cap=quot_c.merkle_tree.cap.tolist(), openings=openings, opening_proof=opening_proof,

@@ -171,3 +171,27 @@ def test_reference_abi_entry_points(gpu, oracle):
     with pytest.raises(pg.Plonky2HipError) as e:
         _lib.call("compute_quotient_polys", None, 0, 0, 0, None, None, 0, 0, *([None] * 12))
     assert e.value.code == pg.GL_E_UNSUPPORTED
+
+
+def test_open_batch_equals_get_and_prove(gpu, oracle):
+    import plonky2_gpu_amd as pg
+
+    rng = np.random.default_rng(5)
+    for n, ll, cap_h in ((64, 7, 2), (256, 135, 0), (16, 3, 4), (32, 20, 1)):
+        leaves = rng.integers(0, P, size=(n, ll), dtype=np.uint64)
+        tree = pg.MerkleTree.new(gpu, leaves, cap_h)
+        idx = [0, n - 1, 5 % n, 5 % n, n // 2]
+        lv, sib = tree.open_batch(idx)
+        for q, i in enumerate(idx):
+            assert (lv[q] == leaves[i]).all()
+            assert (sib[q] == tree.prove(i)).all()
+            assert oracle.merkle_verify(leaves[i], i, tree.cap, sib[q])
+
+
+def test_sponge_absorb_matches_hash_no_pad(gpu):
+    from oracle import pyref
+    from plonky2_gpu_amd.challenger import hash_no_pad
+
+    for k in (1, 3, 8, 9, 16, 23, 135):
+        inp = [(i * 0x9E3779B97F4A7C15 + 7) % P for i in range(k)]
+        assert hash_no_pad(gpu, inp) == pyref.hash_no_pad(inp)

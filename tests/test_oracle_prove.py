@@ -49,3 +49,22 @@ def test_unsatisfied_witness_does_not_verify():
     proof = prove_ref.prove(circuit, wires, pis)
     with pytest.raises(AssertionError):
         prove_ref.verify(circuit, proof)
+
+
+def test_synthetic_circuit_generator_gives_a_provable_circuit():
+    """tools/synth_circuit.py (numpy witness generator used at bench sizes) against the oracle prover."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import synth_circuit
+
+    fp = dict(rate_bits=3, cap_height=1, reduction_arity_bits=[2, 1], proof_of_work_bits=2, num_query_rounds=2)
+    circuit, wires, pis = synth_circuit.make(4, num_wires=14, num_routed=12, num_constants=4, seed=3, fri_params=fp)
+    synth_circuit.set_public_input_row(wires, pyref.hash_no_pad(pis))
+    circuit["constants"] = [[int(v) for v in c] for c in circuit["constants"]]
+    circuit["sigmas"] = [[int(v) for v in c] for c in circuit["sigmas"]]
+    wires = [[int(v) for v in c] for c in wires]
+    circuit["constants_sigmas"] = prove_ref.commit_from_values(circuit["constants"] + circuit["sigmas"], 3, 1)
+    circuit["circuit_digest"] = prove_ref.circuit_digest(circuit["constants_sigmas"]["cap"], 4)
+    assert prove_ref.verify(circuit, prove_ref.prove(circuit, wires, pis))

@@ -1,0 +1,67 @@
+"""Time prove() on the device for a synthetic circuit of the ed25519 proof's SHAPE (BASELINE.json
+config 4: n = 2^18, 234 wires / 80 routed, 88 preprocessed polynomials, 2 challenges, rate 8,
+cap_height 4, FRI arities [4,4,4,4], 28 queries, 16 PoW bits) and check the proof with the oracle's
+verifier. The ed25519 circuit itself needs the Rust toolchain; the gate set here is
+Noop/Constant/PublicInput/Arithmetic{20}, so the gate-constraint part of the quotient stage is lighter
+than ed25519's 231-constraint gate list — every other stage runs at the real shape.
+usage: python tools/bench_prove.py [degree_bits=18] [num_wires=234] [reps=3] [verify=1]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
+
+import plonky2_gpu_amd as pg  # noqa: E402
+import synth_circuit  # noqa: E402
+from plonky2_gpu_amd.challenger import hash_no_pad  # noqa: E402
+
+
+def main():
+    degree_bits = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+    num_wires = int(sys.argv[2]) if len(sys.argv) > 2 else 234
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    verify = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    ctx = pg.Context(0)
+    t = time.perf_counter()
+    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=num_wires, num_routed=80, num_constants=8, seed=1)
+    synth_circuit.set_public_input_row(wires, hash_no_pad(ctx, pis))
+    gen_s = time.perf_counter() - t
+    t = time.perf_counter()
+    cd = pg.CircuitData(ctx, dict(circuit, circuit_digest=[0, 0, 0, 0]))
+    cap = cd.constants_sigmas_commitment.merkle_tree.cap.tolist()
+    flat = [x for h in cap for x in h]
+    pad = [1] + [0] * 10 + [1]  # hash_pad of the empty domain separator (plonk/config.rs:44-52)
+    cd.circuit_digest = hash_no_pad(ctx, flat + hash_no_pad(ctx, pad) + [degree_bits])  # circuit_builder.rs:915-927
+    ctx.synchronize()
+    build_s = time.perf_counter() - t
+    d_wires = pg.DeviceBuffer.from_host(ctx, np.ascontiguousarray(wires))
+    runs = []
+    for r in range(reps + 1):
+        timing = {}
+        ctx.synchronize()
+        t = time.perf_counter()
+        proof = pg.prove(ctx, cd, d_wires, pis, timing)
+        ctx.synchronize()
+        timing["total"] = (time.perf_counter() - t) * 1e3
+        if r:  # first run warms up (table builds, allocator)
+            runs.append(timing)
+    best = min(runs, key=lambda d: d["total"])
+    out = dict(workload=f"prove() synthetic circuit n=2^{degree_bits} wires={num_wires} routed=80 preprocessed=88 gates=noop/const/pi/arith20",
+               reps=reps, witness_gen_s=round(gen_s, 2), circuit_build_s=round(build_s, 2),
+               best_ms={k: round(v, 3) for k, v in best.items()},
+               mean_total_ms=round(sum(d["total"] for d in runs) / len(runs), 3), pow_witness=proof["opening_proof"]["pow_witness"])
+    if verify:
+        from oracle import prove_ref
+
+        t = time.perf_counter()
+        vc = dict(circuit, circuit_digest=cd.circuit_digest, constants_sigmas=dict(cap=cap))
+        out["oracle_verifier_accepts"] = bool(prove_ref.verify(vc, proof))
+        out["verify_s"] = round(time.perf_counter() - t, 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
