@@ -17,7 +17,10 @@ Also reported in the same JSON line:
   cpu_baseline  the C oracle (a restatement of the reference's fft_classic, "port") on this
                 host's cores, bounded sample.
   extra         PolynomialBatch::from_values on BASELINE configs[2] (2^20 rows x 135 columns,
-                rate 8, cap 4): ms per commit and Merkle leaves hashed/s (skipped with --no-commit).
+                rate 8, cap 4): ms per commit and Merkle leaves hashed/s (skipped with --no-commit);
+                prove() wall-clock on a synthetic circuit of configs[3]'s shape (n = 2^18, 234 wires,
+                88 preprocessed polynomials, FRI as standard_recursion_config), one independent proof
+                per GPU and step as in configs[4] (skipped with --no-prove).
 """
 import argparse
 import json
@@ -45,6 +48,10 @@ def parse():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-commit", action="store_true", help="skip the configs[2] commit measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-prove", action="store_true", help="skip the configs[3]/[4]-shaped prove() measurement")
+    ap.add_argument("--prove-degree-bits", type=int, default=18)
+    ap.add_argument("--prove-wires", type=int, default=234)
+    ap.add_argument("--prove-reps", type=int, default=3)
     ap.add_argument("--commit-cols", type=int, default=135)
     ap.add_argument("--commit-log-n", type=int, default=20)
     return ap.parse_args()
@@ -157,6 +164,11 @@ def main():
     if not args.no_commit and dist.rank == 0:
         extra = bench_commit(pg, _lib, ctx, args.commit_cols, args.commit_log_n)
 
+    if not args.no_prove:
+        pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
+        if dist.rank == 0:
+            extra["prove"] = pr
+
     if dist.rank == 0:
         ntts = 2 * batch * args.steps * dist.world
         out = {
@@ -203,6 +215,52 @@ def main():
     ctx.close()
     dist.barrier()  # rank 0 runs the extra legs; leave the group together
     dist.close()
+
+
+def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
+    """prove() (plonk/prover.rs:40-233) per rank on its own synthetic circuit instance of the ed25519
+    proof's shape; every rank proves `reps` independent proofs (configs[4]: one proof per GPU, no
+    collective). The witness and the preprocessed commitment are resident before the timed region.
+    Rank 0's last proof is checked by the oracle's verifier outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_circuit
+    from plonky2_gpu_amd.challenger import hash_no_pad
+
+    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=num_wires, num_routed=80, num_constants=8, seed=1 + dist.rank)
+    synth_circuit.set_public_input_row(wires, hash_no_pad(ctx, pis))
+    cd = pg.CircuitData(ctx, dict(circuit, circuit_digest=[0, 0, 0, 0]))
+    cap = cd.constants_sigmas_commitment.merkle_tree.cap.tolist()
+    pad = [1] + [0] * 10 + [1]  # hash_pad of the empty domain separator (plonk/config.rs:44-52)
+    cd.circuit_digest = hash_no_pad(ctx, [x for h in cap for x in h] + hash_no_pad(ctx, pad) + [degree_bits])
+    d_wires = pg.DeviceBuffer.from_host(ctx, np.ascontiguousarray(wires))
+    pg.prove(ctx, cd, d_wires, pis)  # warm-up: table builds, allocator
+    ctx.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof = pg.prove(ctx, cd, d_wires, pis)
+    ctx.synchronize()
+    dist.barrier()
+    elapsed = dist.max(time.perf_counter() - t0)
+    timing = {}
+    pg.prove(ctx, cd, d_wires, pis, timing)  # one more with per-stage synchronisation for the breakdown
+    res = None
+    if dist.rank == 0:
+        from oracle import prove_ref
+
+        ok = bool(prove_ref.verify(dict(circuit, circuit_digest=cd.circuit_digest, constants_sigmas=dict(cap=cap)), proof))
+        res = {
+            "workload": f"configs[3] shape, synthetic circuit: n=2^{degree_bits}, {num_wires} wires (80 routed), 88 preprocessed polys, "
+                        f"2 challenges, rate 8, cap_height 4, FRI arities {circuit['fri_params']['reduction_arity_bits']}, 28 queries, "
+                        f"16 PoW bits; gates Noop/Constant/PublicInput/Arithmetic(20) (ed25519's own gate list needs the Rust "
+                        f"circuit builder); witness + preprocessed commitment resident",
+            "prove_ms": elapsed / reps * 1e3,
+            "proofs_per_s_all_gpus": dist.world * reps / elapsed,
+            "stage_ms": {k: round(v, 3) for k, v in timing.items()},
+            "oracle_verifier_accepts": ok,
+        }
+    d_wires.free()
+    return res
 
 
 def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3):
