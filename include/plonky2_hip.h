@@ -146,6 +146,17 @@ typedef struct GlGateProgram {
     uint64_t public_inputs_hash[4];
 } GlGateProgram;
 
+/* The same gate programs compiled at run time (hiprtc, gfx950) into a kernel specialised to the circuit:
+ * one device function per gate, registers in VGPRs, immediates as literals. Built once per circuit
+ * (seconds), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.
+ * On failure the GlError message carries the compiler log. */
+GlError gl_gate_kernel_build(const GlGateInstr *h_instrs, uint32_t num_instrs, const GlGateDesc *h_gates, uint32_t num_gates,
+                             const uint64_t *h_immediates, uint32_t num_immediates, uint32_t num_selectors,
+                             uint32_t num_gate_constraints, uint32_t num_challenges, void **kernel);
+void gl_gate_kernel_destroy(void *kernel);
+/* the generated HIP source (owned by the kernel object) — for inspection and tests */
+const char *gl_gate_kernel_source(const void *kernel);
+
 typedef struct GlQuotientArgs {
     const uint64_t *d_wires_leaves;
     const uint64_t *d_constants_sigmas_leaves;
@@ -158,6 +169,16 @@ typedef struct GlQuotientArgs {
     uint32_t degree_bits, rate_bits, quotient_degree_factor;
     uint64_t coset_shift; /* F::coset_shift() = 7 */
     const GlGateProgram *gate_program; /* HOST struct, may be NULL; exclusive with d_gate_constraint_terms */
+    /* 0: the three d_*_leaves are leaf-major rows [n_ext][leaf_len] (d_leaves of gl_commit_*);
+     * otherwise they are the column-major LDE [leaf_len][column_stride] in bit-reversed row order
+     * (d_lde of gl_commit_*) — coalesced reads, and no leaf-major copy has to exist at all. */
+    uint64_t column_stride;
+    /* Gates compiled by gl_gate_kernel_build (may be NULL; exclusive with the two other sources of gate
+     * constraints). Needs h_public_inputs_hash (4, host) and d_gate_workspace
+     * [num_challenges][n << log2_ceil(qdf)] (device scratch). */
+    const void *gate_kernel;
+    const uint64_t *h_public_inputs_hash;
+    uint64_t *d_gate_workspace;
 } GlQuotientArgs;
 GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx);
 

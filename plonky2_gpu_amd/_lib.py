@@ -50,6 +50,10 @@ class GlQuotientArgs(ctypes.Structure):
         ("quotient_degree_factor", ctypes.c_uint32),
         ("coset_shift", ctypes.c_uint64),
         ("gate_program", ctypes.POINTER(GlGateProgram)),
+        ("column_stride", ctypes.c_uint64),
+        ("gate_kernel", ctypes.c_void_p),
+        ("h_public_inputs_hash", ctypes.c_void_p),
+        ("d_gate_workspace", ctypes.c_void_p),
     ]
 
 
@@ -85,6 +89,9 @@ SIGNATURES = {
     "gl_coset_lde_batch": (GlError, [_vp, _vp, _u64, _u32, _u32, _u64, _u64, _u64, _vp]),
     "gl_coset_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _u64, _i, _vp]),
     "gl_permutation_partial_products": (GlError, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "gl_gate_kernel_build": (GlError, [_vp, _u32, _vp, _u32, _vp, _u32, _u32, _u32, _u32, ctypes.POINTER(_vp)]),
+    "gl_gate_kernel_destroy": (None, [_vp]),
+    "gl_gate_kernel_source": (ctypes.c_char_p, [_vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
     "gl_eval_polys_ext2": (GlError, [_vp, _u64, _u32, _u64, _vp, _u32, _vp, _vp]),
     "gl_fri_reduce_polys_base": (GlError, [_vp, _u32, _u64, _vp, _vp, _vp]),

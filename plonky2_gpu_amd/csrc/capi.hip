@@ -360,6 +360,25 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
     return ok();
 }
 
+GlError gl_gate_kernel_build(const GlGateInstr *h_instrs, uint32_t num_instrs, const GlGateDesc *h_gates, uint32_t num_gates,
+                             const uint64_t *h_immediates, uint32_t num_immediates, uint32_t num_selectors,
+                             uint32_t num_gate_constraints, uint32_t num_challenges, void **kernel) {
+    if (!h_instrs || !h_gates || !kernel || (num_immediates && !h_immediates)) return fail(GL_E_INVALID, "null pointer");
+    if (num_gate_constraints > 256) return fail(GL_E_INVALID, "num_gate_constraints > 256");
+    const NttTables *tb;
+    HIP_TRY(get_tables(&tb));  // binds the device before the module is loaded
+    std::string err;
+    GateKernel *k = gate_kernel_build(reinterpret_cast<const uint16_t *>(h_instrs), num_instrs, reinterpret_cast<const uint32_t *>(h_gates),
+                                      num_gates, h_immediates, num_immediates, num_selectors, num_gate_constraints, num_challenges, &err);
+    if (!k) return fail(GL_E_INVALID, err.c_str());
+    *kernel = k;
+    return ok();
+}
+
+void gl_gate_kernel_destroy(void *kernel) { gate_kernel_destroy(static_cast<GateKernel *>(kernel)); }
+
+const char *gl_gate_kernel_source(const void *kernel) { return kernel ? gate_kernel_source(static_cast<const GateKernel *>(kernel)) : ""; }
+
 GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx) {
     if (!ctx || !args || !d_quotient_polys) return fail(GL_E_INVALID, "null pointer");
     if (!args->d_wires_leaves || !args->d_constants_sigmas_leaves || !args->d_zs_partial_products_leaves || !args->d_k_is ||
@@ -385,6 +404,17 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
     a.rate_bits = args->rate_bits;
     a.quotient_degree_factor = args->quotient_degree_factor;
     a.shift = args->coset_shift;
+    a.column_stride = args->column_stride;
+    if (args->gate_kernel) {
+        if (args->gate_program || args->d_gate_constraint_terms)
+            return fail(GL_E_INVALID, "give one source of gate constraints: terms, a gate program or a gate kernel");
+        if (!args->h_public_inputs_hash || !args->d_gate_workspace) return fail(GL_E_INVALID, "gate_kernel needs h_public_inputs_hash and d_gate_workspace");
+        a.gate_kernel = static_cast<const GateKernel *>(args->gate_kernel);
+        if (gate_kernel_num_constraints(a.gate_kernel) != args->num_gate_constraints || gate_kernel_num_challenges(a.gate_kernel) != args->num_challenges)
+            return fail(GL_E_INVALID, "gate kernel was built for other num_gate_constraints / num_challenges");
+        a.public_inputs_hash = args->h_public_inputs_hash;
+        a.gate_partial_workspace = args->d_gate_workspace;
+    }
     GateProgramArgs gpa = {};
     if (args->gate_program) {
         const GlGateProgram *g = args->gate_program;

@@ -1,0 +1,211 @@
+// gate_jit.hip — the circuit-specific part of compute_quotient_polys as a RUN-TIME COMPILED kernel.
+//
+// The reference hard-wires the 25 gates of one circuit into its quotient kernel
+// (cuda/plonky2_gpu_impl.cuh:600-685). Here a circuit's gates arrive as register programs
+// (GlGateInstr, include/plonky2_hip.h) and are turned into straight-line HIP source — one
+// __noinline__ device function per gate, registers as local variables, immediates as literals —
+// compiled for gfx950 with hiprtc when the circuit is built, and launched as an ordinary kernel:
+// the program's registers live in VGPRs and the instruction stream is real machine code, instead of
+// an interpreter that keeps 64 registers in scratch memory and decodes an opcode per operation.
+//
+// What the kernel computes for the LDE point held by leaf t
+// (evaluate_gate_constraints_base_batch, plonky2/src/plonk/vanishing_poly.rs:267-306; Gate::eval_filtered,
+// gates/gate.rs:86-109; compute_filter, gates/gate.rs:261-268):
+//     G_c(t) = sum_k alpha_c^k * sum_g filter_g(t) * constraint_{g,k}(t)
+// i.e. the gate-constraint tail of reduce_with_powers_multi (plonk_common.rs:97-114), which
+// quotient_values_kernel then continues through the permutation terms. Powers of alpha come from a
+// small device table read with wave-uniform (scalar) loads.
+#include "gate_jit.h"
+
+#include <hip/hiprtc.h>
+
+#include <sstream>
+#include <vector>
+
+#include "gl_field.cuh"
+
+namespace plonky2_hip {
+
+namespace {
+const char *const GL_FIELD_SRC =
+#include "build/gl_field_src.inc"
+    ;
+
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT };
+constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
+}  // namespace
+
+struct GateKernel {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    uint64_t *d_apow = nullptr;  // [num_challenges][num_constraints]
+    uint32_t num_challenges = 0, num_constraints = 0;
+    std::string source;
+};
+
+static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
+                                   const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
+                                   std::string *error) {
+    std::ostringstream o;
+    o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n";
+    o << "#define NCH " << nch << "\n#define NGC " << ngc << "\n";
+    o << "struct GateSum { uint64_t v[NCH]; };\n";
+    o << "struct Pih { uint64_t v[4]; };\n";
+    for (uint32_t g = 0; g < num_gates; g++) {
+        const uint32_t *d = gates + 6 * g;
+        const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
+        if (ps + pl > num_instrs || si >= num_selectors || gs > ge) {
+            *error = "gate descriptor out of range";
+            return "";
+        }
+        o << "static __device__ __noinline__ GateSum gate_" << g
+          << "(const uint64_t* __restrict__ W, uint64_t wes, const uint64_t* __restrict__ C, uint64_t ces, "
+             "const uint64_t* __restrict__ apow, Pih pih) {\n";
+        // compute_filter (gates/gate.rs:261-268)
+        o << "  const uint64_t s = C[" << si << " * ces];\n  uint64_t filt = 1;\n";
+        for (uint32_t i = gs; i < ge; i++)
+            if (i != row) o << "  filt = gl::mul(filt, gl::sub(" << i << "ull, s));\n";
+        if (num_selectors > 1) o << "  filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));\n";  // UNUSED_SELECTOR (selectors.rs:11)
+        o << "  uint64_t ga[NCH];\n  for (int c = 0; c < NCH; c++) ga[c] = 0;\n";
+        bool used[MAX_REGS] = {};
+        for (uint32_t pc = ps; pc < ps + pl; pc++) used[instrs[4 * pc + 1] & (MAX_REGS - 1)] = true;
+        for (uint32_t r = 0; r < MAX_REGS; r++)
+            if (used[r]) o << "  uint64_t r" << r << " = 0;\n";
+        uint32_t k = 0;
+        for (uint32_t pc = ps; pc < ps + pl; pc++) {
+            const uint16_t op = instrs[4 * pc], dst = instrs[4 * pc + 1] & (MAX_REGS - 1), a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
+            const uint32_t ra = a & (MAX_REGS - 1), rb = b & (MAX_REGS - 1);
+            switch (op) {
+                case GP_LOAD_WIRE: o << "  r" << dst << " = W[" << a << " * wes];\n"; break;
+                case GP_LOAD_CONST: o << "  r" << dst << " = C[" << (num_selectors + a) << " * ces];\n"; break;
+                case GP_LOAD_PI: o << "  r" << dst << " = pih.v[" << (a & 3) << "];\n"; break;
+                case GP_LOAD_IMM:
+                    if (a >= num_imms) {
+                        *error = "LOAD_IMM index out of range";
+                        return "";
+                    }
+                    o << "  r" << dst << " = 0x" << std::hex << (imms[a] % glh::P) << std::dec << "ull;\n";
+                    break;
+                case GP_ADD:
+                case GP_SUB:
+                case GP_MUL:
+                    if (!used[ra] || !used[rb]) {
+                        *error = "register read before any write";
+                        return "";
+                    }
+                    o << "  r" << dst << " = gl::" << (op == GP_ADD ? "add" : op == GP_SUB ? "sub" : "mul") << "(r" << ra << ", r" << rb
+                      << ");\n";
+                    break;
+                case GP_EMIT:
+                    if (!used[ra]) {
+                        *error = "register read before any write";
+                        return "";
+                    }
+                    if (k < ngc) o << "  for (int c = 0; c < NCH; c++) ga[c] = gl::mac(ga[c], r" << ra << ", apow[c * NGC + " << k << "]);\n";
+                    k++;
+                    break;
+                default: *error = "unknown opcode"; return "";
+            }
+        }
+        o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, ga[c]);\n  return out;\n}\n";
+    }
+    o << "extern \"C\" __global__ __launch_bounds__(128) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
+         "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, const uint64_t* __restrict__ apow, Pih pih, "
+         "uint64_t lde_size, uint64_t* __restrict__ out) {\n"
+         "  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;\n  if (t >= lde_size) return;\n"
+         "  const uint64_t* W = wires + t * wrs;\n  const uint64_t* C = cs + t * crs;\n"
+         "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = 0;\n";
+    for (uint32_t g = 0; g < num_gates; g++)
+        o << "  { GateSum s = gate_" << g << "(W, wes, C, ces, apow, pih); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
+    o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t] = gl::canon(acc[c]);\n}\n";
+    return o.str();
+}
+
+GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
+                              const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t num_gate_constraints,
+                              uint32_t num_challenges, std::string *error) {
+    if (num_challenges == 0 || num_challenges > MAX_CH || num_gates == 0 || num_gate_constraints == 0) {
+        *error = "bad gate kernel shape";
+        return nullptr;
+    }
+    GateKernel *k = new GateKernel();
+    k->num_challenges = num_challenges;
+    k->num_constraints = num_gate_constraints;
+    k->source = generate_source(instrs, num_instrs, gates, num_gates, imms, num_imms, num_selectors, num_gate_constraints,
+                                num_challenges, error);
+    if (k->source.empty()) {
+        delete k;
+        return nullptr;
+    }
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, k->source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) {
+        *error = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+        delete k;
+        return nullptr;
+    }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        *error = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000);
+        hiprtcDestroyProgram(&prog);
+        delete k;
+        return nullptr;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    hipError_t e = hipModuleLoadData(&k->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "gate_constraints_kernel");
+    if (e == hipSuccess) e = hipMalloc(&k->d_apow, sizeof(uint64_t) * num_challenges * num_gate_constraints);
+    if (e != hipSuccess) {
+        *error = std::string("loading the compiled gate kernel: ") + hipGetErrorString(e);
+        gate_kernel_destroy(k);
+        return nullptr;
+    }
+    return k;
+}
+
+void gate_kernel_destroy(GateKernel *k) {
+    if (!k) return;
+    if (k->d_apow) (void)hipFree(k->d_apow);
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+}
+
+uint32_t gate_kernel_num_challenges(const GateKernel *k) { return k->num_challenges; }
+uint32_t gate_kernel_num_constraints(const GateKernel *k) { return k->num_constraints; }
+const char *gate_kernel_source(const GateKernel *k) { return k->source.c_str(); }
+
+hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64_t w_rs, uint64_t w_es, const uint64_t *cs,
+                              uint64_t c_rs, uint64_t c_es, const uint64_t *alphas, const uint64_t pih[4], uint64_t lde_size,
+                              uint64_t *out, hipStream_t stream) {
+    std::vector<uint64_t> apow((size_t)k->num_challenges * k->num_constraints);
+    for (uint32_t c = 0; c < k->num_challenges; c++) {
+        uint64_t a = alphas[c] % glh::P, p = 1;
+        for (uint32_t j = 0; j < k->num_constraints; j++) {
+            apow[(size_t)c * k->num_constraints + j] = p;
+            p = glh::mul(p, a);
+        }
+    }
+    // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
+    hipError_t e = hipMemcpyAsync(k->d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    struct {
+        uint64_t v[4];
+    } pi = {{pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P}};
+    const uint64_t *apow_d = k->d_apow;
+    void *args[] = {&wires, &w_rs, &w_es, &cs, &c_rs, &c_es, &apow_d, &pi, &lde_size, &out};
+    const unsigned grid = (unsigned)((lde_size + 127) / 128);
+    return hipModuleLaunchKernel(k->fn, grid, 1, 1, 128, 1, 1, 0, stream, args, nullptr);
+}
+
+}  // namespace plonky2_hip

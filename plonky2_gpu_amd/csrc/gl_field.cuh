@@ -11,8 +11,17 @@
 // (32x32+64->64). 64-bit adds are single v_lshl_add_u64 instructions. Everything here is
 // branch-free (v_cndmask) — a wavefront cannot profit from the "rare branch" the CPU code uses.
 #pragma once
+#ifdef GL_JIT
+// compiled at run time by hiprtc (gate_jit.hip): no system headers there, the HIP builtins are implicit
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned short uint16_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace gl {
 
@@ -405,6 +414,7 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
 
 }  // namespace gl
 
+#ifndef GL_JIT
 // ---- host-side twins (table construction, n_inv, ...) -------------------------------------
 namespace glh {
 typedef unsigned __int128 u128;
@@ -424,3 +434,4 @@ inline uint64_t inv(uint64_t a) { return pow(a, P - 2); }
 // Field::primitive_root_of_unity (field/src/types.rs:268-272)
 inline uint64_t root_of_unity(unsigned n_log) { return pow(1753635133440165772ULL, 1ULL << (32 - n_log)); }
 }  // namespace glh
+#endif  // GL_JIT

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gate_jit.h"
 #include "ntt.h"
 
 namespace plonky2_hip {
@@ -26,7 +27,11 @@ struct GateProgramArgs {
 
 struct QuotientArgs {
     const GateProgramArgs *gate_program = nullptr;  // alternative to gate_terms
-    const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves;  // leaf-major LDE rows of the three commitments
+    const GateKernel *gate_kernel = nullptr;        // alternative to both: run-time compiled gates (gate_jit.h)
+    uint64_t *gate_partial_workspace = nullptr;     // device [num_challenges][lde_size], needed with gate_kernel
+    const uint64_t *public_inputs_hash = nullptr;   // host, 4, needed with gate_kernel
+    uint64_t column_stride = 0;                     // 0: leaf-major rows; else column-major with this column stride
+    const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves;  // LDE of the three commitments in either layout
     uint32_t wires_len, cs_len, zpp_len;                    // leaf lengths
     const uint64_t *k_is;                                   // device, num_routed
     const uint64_t *gate_terms;                             // device [lde_size][num_gate_constraints] or null

@@ -160,14 +160,14 @@ struct GateProgramDev {
     uint64_t pih[4];
 };
 
-__device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *local_constants, const uint64_t *local_wires,
-                                  uint64_t *acc) {
+__device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *local_constants, uint64_t c_es,
+                                  const uint64_t *local_wires, uint64_t w_es, uint64_t *acc) {
     uint64_t regs[GP_MAX_REGS];
     for (uint32_t k = 0; k < gp.num_gate_constraints; k++) acc[k] = 0;
     for (uint32_t g = 0; g < gp.num_gates; g++) {
         const uint32_t *d = gp.gates + 6 * g;
         const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
-        const uint64_t s = local_constants[si];
+        const uint64_t s = local_constants[si * c_es];
         uint64_t filt = 1;
         for (uint32_t i = gs; i < ge; i++)
             if (i != row) filt = gl::mul(filt, gl::sub(i, s));
@@ -177,8 +177,8 @@ __device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *loca
             const uint16_t *in = gp.instrs + 4 * pc;
             const uint16_t op = in[0], dst = in[1] & (GP_MAX_REGS - 1), a = in[2], b = in[3];
             switch (op) {
-                case GP_LOAD_WIRE: regs[dst] = local_wires[a]; break;
-                case GP_LOAD_CONST: regs[dst] = local_constants[gp.num_selectors + a]; break;
+                case GP_LOAD_WIRE: regs[dst] = local_wires[a * w_es]; break;
+                case GP_LOAD_CONST: regs[dst] = local_constants[(gp.num_selectors + a) * c_es]; break;
                 case GP_LOAD_PI: regs[dst] = gp.pih[a & 3]; break;
                 case GP_LOAD_IMM: regs[dst] = gp.imms[a]; break;
                 case GP_ADD: regs[dst] = gl::add(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
@@ -197,7 +197,8 @@ __device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *loca
 struct QuotientParams {
     GateProgramDev gp;
     uint32_t has_program;
-    const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves, *k_is, *gate_terms, *twl, *twh;
+    const uint64_t *wires_leaves, *cs_leaves, *zpp_leaves, *k_is, *gate_terms, *gate_partial, *twl, *twh;
+    uint64_t w_rs, w_es, c_rs, c_es, z_rs, z_es;  // element j of leaf t at base[t*rs + j*es]
     uint64_t *out;  // [num_challenges][lde_size]
     uint32_t wires_len, cs_len, zpp_len, num_constants, num_routed, num_challenges, degree, num_prods;
     uint32_t degree_bits, rate_bits, qdb, num_gate_constraints;
@@ -205,20 +206,24 @@ struct QuotientParams {
     Challenges ch;
 };
 
+// One thread per LEAF t < lde_size. get_lde_values(i, step) reads leaf reverse_bits(i*step, bits)
+// (fri/oracle.rs:1007-1018), and reverse_bits(i << step_log, log_lde + step_log) == reverse_bits(i, log_lde),
+// so the points of the quotient domain are exactly the first lde_size leaves and leaf t holds point
+// i = reverse_bits(t, log_lde): consecutive threads read consecutive leaves — contiguous in every column
+// of the column-major LDE — and only the 8-byte result is scattered.
 __global__ __launch_bounds__(128) void quotient_values_kernel(const QuotientParams p) {
     const uint32_t log_lde = p.degree_bits + p.qdb;
     const uint64_t lde_size = 1ull << log_lde, n = 1ull << p.degree_bits;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= lde_size) return;
-    const uint32_t bits = p.degree_bits + p.rate_bits, step_log = p.rate_bits - p.qdb;
-    // get_lde_values(i, step): leaf reverse_bits(i*step) (fri/oracle.rs:1007-1018); next point i + next_step
-    uint64_t leaf = bits ? (__brevll(i << step_log) >> (64 - bits)) : 0;
-    uint64_t i_next = (i + (1ull << p.qdb)) & (lde_size - 1);
-    uint64_t leaf_next = bits ? (__brevll(i_next << step_log) >> (64 - bits)) : 0;
-    const uint64_t *wires = p.wires_leaves + leaf * p.wires_len;
-    const uint64_t *sig = p.cs_leaves + leaf * p.cs_len + p.num_constants;
-    const uint64_t *zpp = p.zpp_leaves + leaf * p.zpp_len;
-    const uint64_t *zpp_next = p.zpp_leaves + leaf_next * p.zpp_len;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lde_size) return;
+    const uint64_t i = log_lde ? (__brevll(t) >> (64 - log_lde)) : 0;
+    const uint64_t i_next = (i + (1ull << p.qdb)) & (lde_size - 1);  // the point g*x
+    const uint64_t t_next = log_lde ? (__brevll(i_next) >> (64 - log_lde)) : 0;
+    const uint64_t *wires = p.wires_leaves + t * p.w_rs;
+    const uint64_t *cs = p.cs_leaves + t * p.c_rs;
+    const uint64_t *sig = cs + p.num_constants * p.c_es;
+    const uint64_t *zpp = p.zpp_leaves + t * p.z_rs;
+    const uint64_t *zpp_next = p.zpp_leaves + t_next * p.z_rs;
 
     const uint64_t x = gl::mul(p.shift, root_pow(p.twl, p.twh, log_lde, i));  // shifted_x (prover.rs:903)
     // Z_H(x) = g^n * v^(i mod rate) - 1 (field/src/zero_poly_coset.rs:20-41)
@@ -229,21 +234,21 @@ __global__ __launch_bounds__(128) void quotient_values_kernel(const QuotientPara
 
     uint64_t terms[MAX_TERMS];
     uint32_t nt = 0;
-    for (uint32_t c = 0; c < p.num_challenges; c++) terms[nt++] = gl::mul(l0, gl::sub(zpp[c], 1));
+    for (uint32_t c = 0; c < p.num_challenges; c++) terms[nt++] = gl::mul(l0, gl::sub(zpp[c * p.z_es], 1));
     for (uint32_t c = 0; c < p.num_challenges; c++) {
         const uint64_t beta = p.ch.beta[c], gamma = p.ch.gamma[c];
         const uint64_t bx = gl::mul(beta, x);
-        uint64_t prev = zpp[c];
+        uint64_t prev = zpp[c * p.z_es];
         uint32_t k = 0;
         for (uint32_t j0 = 0; j0 < p.num_routed; j0 += p.degree, k++) {
             uint64_t num = 1, den = 1;
             uint32_t j1 = j0 + p.degree < p.num_routed ? j0 + p.degree : p.num_routed;
             for (uint32_t j = j0; j < j1; j++) {
-                uint64_t wg = gl::add(wires[j], gamma);
+                uint64_t wg = gl::add(wires[j * p.w_es], gamma);
                 num = gl::mul(num, gl::add(wg, gl::mul(bx, p.k_is[j])));
-                den = gl::mul(den, gl::add(wg, gl::mul(beta, sig[j])));
+                den = gl::mul(den, gl::add(wg, gl::mul(beta, sig[j * p.c_es])));
             }
-            uint64_t next = (k < p.num_prods) ? zpp[p.num_challenges + c * p.num_prods + k] : zpp_next[c];
+            uint64_t next = (k < p.num_prods) ? zpp[(p.num_challenges + c * p.num_prods + k) * p.z_es] : zpp_next[c * p.z_es];
             // check_partial_products (util/partial_products.rs:52-76): prev*num - next*den
             terms[nt++] = gl::sub(gl::mul(prev, num), gl::mul(next, den));
             prev = next;
@@ -254,15 +259,16 @@ __global__ __launch_bounds__(128) void quotient_values_kernel(const QuotientPara
     const uint64_t *gt = p.gate_terms ? p.gate_terms + i * p.num_gate_constraints : nullptr;
     uint64_t gate_acc[GP_MAX_CONSTRAINTS];
     if (p.has_program) {
-        eval_gate_program(p.gp, p.cs_leaves + leaf * p.cs_len, wires, gate_acc);
+        eval_gate_program(p.gp, cs, p.c_es, wires, p.w_es, gate_acc);
         gt = gate_acc;
     }
     for (uint32_t c = 0; c < p.num_challenges; c++) {
         const uint64_t alpha = p.ch.alpha[c];
-        uint64_t cumul = 0;
+        // the gate-constraint tail of the Horner sum, already reduced by the compiled gate kernel
+        uint64_t cumul = p.gate_partial ? p.gate_partial[(uint64_t)c * lde_size + t] : 0;
         if (gt)
-            for (uint32_t t = p.num_gate_constraints; t-- > 0;) cumul = gl::mac(gt[t], cumul, alpha);
-        for (uint32_t t = nt; t-- > 0;) cumul = gl::mac(terms[t], cumul, alpha);
+            for (uint32_t q = p.num_gate_constraints; q-- > 0;) cumul = gl::mac(gt[q], cumul, alpha);
+        for (uint32_t q = nt; q-- > 0;) cumul = gl::mac(terms[q], cumul, alpha);
         p.out[(uint64_t)c * lde_size + i] = gl::canon(gl::mul(cumul, zh_inv));  // prover.rs:985-991
     }
 }
@@ -323,6 +329,14 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
     p.wires_len = a.wires_len;
     p.cs_len = a.cs_len;
     p.zpp_len = a.zpp_len;
+    if (a.column_stride) {  // the column-major LDE [leaf_len][column_stride]
+        if (a.column_stride < (1ull << (a.degree_bits + qdb))) return hipErrorInvalidValue;
+        p.w_rs = p.c_rs = p.z_rs = 1;
+        p.w_es = p.c_es = p.z_es = a.column_stride;
+    } else {  // leaf-major rows [n_ext][leaf_len]
+        p.w_rs = a.wires_len, p.c_rs = a.cs_len, p.z_rs = a.zpp_len;
+        p.w_es = p.c_es = p.z_es = 1;
+    }
     p.num_constants = a.num_constants;
     p.num_routed = a.num_routed;
     p.num_challenges = a.num_challenges;
@@ -332,6 +346,14 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
     p.rate_bits = a.rate_bits;
     p.qdb = qdb;
     p.num_gate_constraints = (a.gate_terms || a.gate_program) ? a.num_gate_constraints : 0;
+    if (a.gate_kernel) {
+        if (a.gate_terms || a.gate_program || !a.gate_partial_workspace || !a.public_inputs_hash) return hipErrorInvalidValue;
+        if (gate_kernel_num_challenges(a.gate_kernel) != a.num_challenges) return hipErrorInvalidValue;
+        hipError_t ge = gate_kernel_launch(a.gate_kernel, a.wires_leaves, p.w_rs, p.w_es, a.cs_leaves, p.c_rs, p.c_es, a.alphas,
+                                           a.public_inputs_hash, 1ull << (a.degree_bits + qdb), a.gate_partial_workspace, stream);
+        if (ge != hipSuccess) return ge;
+        p.gate_partial = a.gate_partial_workspace;
+    }
     if (a.gate_program) {
         if (a.gate_terms || a.num_gate_constraints > GP_MAX_CONSTRAINTS) return hipErrorInvalidValue;
         const GateProgramArgs &g = *a.gate_program;

@@ -34,23 +34,38 @@ def all_wires_permutation_partial_products(ctx, d_wires, wires_stride, d_sigmas,
 
 def compute_quotient_polys(ctx, wires_commitment, constants_sigmas_commitment, zs_partial_products_commitment, num_constants,
                            num_routed, d_k_is, betas, gammas, alphas, quotient_degree_factor, d_gate_terms=None,
-                           num_gate_constraints=0, gate_program=None):
-    """compute_quotient_polys (prover.rs:790-1034) over three PolynomialBatch commitments (leaf-major
-    leaves resident in HBM). Returns a DeviceBuffer of coefficients [num_challenges][n << qdb]."""
+                           num_gate_constraints=0, gate_program=None, column_major=True, public_inputs_hash=None):
+    """compute_quotient_polys (prover.rs:790-1034) over three PolynomialBatch commitments resident in
+    HBM, read from their column-major LDE (coalesced; `column_major=False` reads the leaf-major rows
+    like get_lde_values). Gate constraints: `d_gate_terms` (a term array), or `gate_program` — run by
+    its run-time compiled kernel when `gate_program.compile()` has been called, else by the
+    interpreter. Returns a DeviceBuffer of coefficients [num_challenges][n << qdb]."""
     b, g, a = _host_u64(betas), _host_u64(gammas), _host_u64(alphas)
     wc, cc, zc = wires_commitment, constants_sigmas_commitment, zs_partial_products_commitment
     qdb = (quotient_degree_factor - 1).bit_length()
+    n_ext = 1 << (wc.degree_log + wc.rate_bits)
+    if column_major:
+        ptrs = (wc.d_lde.ptr, cc.d_lde.ptr, zc.d_lde.ptr)
+    else:
+        ptrs = (wc.merkle_tree.d_leaves.ptr, cc.merkle_tree.d_leaves.ptr, zc.merkle_tree.d_leaves.ptr)
+    kernel = gate_program.kernel if gate_program is not None else None
+    pih = _host_u64(public_inputs_hash if public_inputs_hash is not None else (gate_program.public_inputs_hash if gate_program else [0] * 4))
+    work = DeviceBuffer(ctx, b.size << (wc.degree_log + qdb)) if kernel else None
     args = _lib.GlQuotientArgs(
-        wc.merkle_tree.d_leaves.ptr, cc.merkle_tree.d_leaves.ptr, zc.merkle_tree.d_leaves.ptr,
+        ptrs[0], ptrs[1], ptrs[2],
         wc.merkle_tree.leaf_len, cc.merkle_tree.leaf_len, zc.merkle_tree.leaf_len,
         d_k_is.ptr, d_gate_terms.ptr if d_gate_terms is not None else None,
         b.ctypes.data, g.ctypes.data, a.ctypes.data,
         num_constants, num_routed, b.size, num_gate_constraints,
         wc.degree_log, wc.rate_bits, quotient_degree_factor, COSET_SHIFT,
-        ctypes.pointer(gate_program.struct) if gate_program is not None else None,
+        ctypes.pointer(gate_program.struct) if (gate_program is not None and not kernel) else None,
+        n_ext if column_major else 0, kernel, pih.ctypes.data if kernel else None, work.ptr if kernel else None,
     )
     out = DeviceBuffer(ctx, b.size << (wc.degree_log + qdb))
     _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, ctx.ptr)
+    if work is not None:
+        ctx.synchronize()
+        work.free()
     return out
 
 
@@ -62,6 +77,11 @@ class GateProgram:
         from . import gate_program as gp
 
         instrs, descs = gp.pack_program(gate_instrs, selector_indices, groups)
+        self._instrs, self._descs = np.ascontiguousarray(instrs), np.ascontiguousarray(descs)
+        self._imms = _host_u64(immediates) if immediates is not None else None
+        self.num_selectors = len(groups)
+        self.kernel = None
+        self.public_inputs_hash = [int(v) for v in public_inputs_hash]
         self.d_instrs = DeviceBuffer.from_host(ctx, np.frombuffer(np.ascontiguousarray(instrs).tobytes(), dtype=np.uint64))
         d32 = np.ascontiguousarray(descs).tobytes()
         d32 += b"\0" * (-len(d32) % 8)
@@ -74,7 +94,28 @@ class GateProgram:
 
     def set_public_inputs_hash(self, pih):
         """the hash is per proof (prover.rs:52), the programs per circuit"""
-        self.struct.public_inputs_hash = (ctypes.c_uint64 * 4)(*[int(v) for v in pih])
+        self.public_inputs_hash = [int(v) for v in pih]
+        self.struct.public_inputs_hash = (ctypes.c_uint64 * 4)(*self.public_inputs_hash)
+
+    def compile(self, num_gate_constraints, num_challenges):
+        """Turn the programs into a kernel specialised to this circuit (hiprtc, once per circuit)."""
+        k = ctypes.c_void_p()
+        n_instr = self._instrs.size // 4
+        _lib.call("gl_gate_kernel_build", self._instrs, n_instr, self._descs, self._descs.size // 6, self._imms,
+                  0 if self._imms is None else self._imms.size, self.num_selectors, num_gate_constraints, num_challenges, ctypes.byref(k))
+        self.kernel = k.value
+        return self
+
+    def kernel_source(self):
+        return _lib.load().gl_gate_kernel_source(self.kernel).decode() if self.kernel else ""
+
+    def __del__(self):
+        try:
+            if self.kernel:
+                _lib.load().gl_gate_kernel_destroy(self.kernel)
+                self.kernel = None
+        except Exception:
+            pass
 
 
 class CircuitData:
@@ -82,7 +123,7 @@ class CircuitData:
     in HBM: the preprocessed constants_sigmas commitment, the sigma value columns, k_is and the gate
     programs. `circuit` is the plain dict described in INTEGRATION.md section 7."""
 
-    def __init__(self, ctx, circuit):
+    def __init__(self, ctx, circuit, compile_gates=True):
         from . import gate_program as gp
         from .polynomial_batch import PolynomialBatch
 
@@ -99,6 +140,8 @@ class CircuitData:
                   arithmetic=gp.arithmetic_gate)
         self.gate_program = GateProgram(ctx, [mk[kind](param) for kind, param in circuit["gates"]], circuit["selector_indices"],
                                         circuit["groups"], [0, 0, 0, 0])
+        if compile_gates:
+            self.gate_program.compile(self.num_gate_constraints, self.num_challenges)
 
     def fri_instance(self, zeta):
         """get_fri_instance (plonk/circuit_data.rs:351-371)"""

@@ -149,6 +149,16 @@ def test_quotient_with_table_driven_gates(gpu, two_groups, degree_bits):
     d_q = pg.compute_quotient_polys(gpu, wires_b, cs_b, zpp_b, nc, 12, d_k, inst["betas"], inst["gammas"], inst["alphas"], qdf,
                                     None, inst["num_gate_constraints"], prog)
     got = d_q.download().reshape(2, n * 8)
+    # the four ways of running the same thing agree: interpreter / run-time compiled gates x leaf-major / column-major
+    alt = pg.compute_quotient_polys(gpu, wires_b, cs_b, zpp_b, nc, 12, d_k, inst["betas"], inst["gammas"], inst["alphas"], qdf,
+                                    None, inst["num_gate_constraints"], prog, column_major=False)
+    assert (alt.download().reshape(2, n * 8) == got).all()
+    prog.compile(inst["num_gate_constraints"], 2)
+    assert "gate_3" in prog.kernel_source() and "gl::mul" in prog.kernel_source()
+    for cm in (True, False):
+        alt = pg.compute_quotient_polys(gpu, wires_b, cs_b, zpp_b, nc, 12, d_k, inst["betas"], inst["gammas"], inst["alphas"], qdf,
+                                        None, inst["num_gate_constraints"], prog, column_major=cm)
+        assert (alt.download().reshape(2, n * 8) == got).all()
     w_c, w_l = lde_leaves(inst["wires"], rate_bits)
     cs_c, cs_l = lde_leaves(inst["constants"] + inst["sigmas"], rate_bits)
     z_c, z_l = lde_leaves(zpp_host.tolist(), rate_bits)
