@@ -15,7 +15,7 @@ class MerkleTree:
     """MerkleTree<F, PoseidonHash> (merkle_tree.rs:41-70): `digests` in the reference layout,
     `cap` = 2^cap_height subtree roots. Leaves stay in HBM."""
 
-    def __init__(self, ctx, n_leaves, leaf_len, cap_height, digests_buf, cap_buf, leaves_buf=None):
+    def __init__(self, ctx, n_leaves, leaf_len, cap_height, digests_buf, cap_buf, leaves_buf=None, cols_buf=None, col_stride=None):
         self.ctx = ctx
         self.n_leaves = n_leaves
         self.leaf_len = leaf_len
@@ -23,6 +23,8 @@ class MerkleTree:
         self.d_digests = digests_buf
         self.d_cap = cap_buf
         self.d_leaves = leaves_buf  # leaf-major [n_leaves][leaf_len] or None
+        self.d_cols = cols_buf  # column-major [leaf_len][col_stride] (the LDE the tree was built from) or None
+        self.col_stride = col_stride
         self._digests = None
         self._cap = None
 
@@ -55,7 +57,7 @@ class MerkleTree:
     def get(self, i):
         """MerkleTree::get (merkle_tree.rs:385-391): leaf i, fetched from HBM."""
         if self.d_leaves is None:
-            raise ValueError("leaf-major copy was not requested")
+            return self.open_batch([i])[0][0]
         return self.d_leaves.download(i * self.leaf_len, self.leaf_len)
 
     def prove(self, leaf_index):
@@ -79,12 +81,16 @@ class MerkleTree:
         """get(i) and prove(i) for many leaves with one launch and one copy (what
         fri_prover_query_round, fri/prover.rs:199-260, asks of every tree for every query).
         Returns (leaves [count, leaf_len], siblings [count, num_layers, 4])."""
-        if self.d_leaves is None:
-            raise ValueError("leaf-major copy was not requested")
+        if self.d_leaves is not None:
+            base, rs, es = self.d_leaves.ptr, self.leaf_len, 1
+        elif self.d_cols is not None:
+            base, rs, es = self.d_cols.ptr, 1, self.col_stride
+        else:
+            raise ValueError("the tree holds neither leaf-major rows nor the column-major matrix")
         idx = np.ascontiguousarray(indices, dtype=np.uint64)
         layers = _log2_strict(self.n_leaves) - self.cap_height
         leaves = np.empty((idx.size, self.leaf_len), dtype=np.uint64)
         sib = np.empty((idx.size, layers, 4), dtype=np.uint64)
-        _lib.call("gl_merkle_open_batch", self.d_leaves.ptr, self.leaf_len, 1, self.leaf_len, self.n_leaves, self.cap_height,
+        _lib.call("gl_merkle_open_batch", base, rs, es, self.leaf_len, self.n_leaves, self.cap_height,
                   self.d_digests.ptr if layers else None, idx, idx.size, leaves, sib if layers else None, self.ctx.ptr)
         return leaves, sib

@@ -49,7 +49,7 @@ class PolynomialBatch:
             d_poly.ptr, n_polys, log_n, rate_bits, cap_height, salt_size, COSET_SHIFT,
             d_lde.ptr, d_leaves.ptr if d_leaves else None, d_dig.ptr, d_cap.ptr, ctx.ptr,
         )
-        tree = MerkleTree(ctx, n_ext, cols, cap_height, d_dig, d_cap, d_leaves)
+        tree = MerkleTree(ctx, n_ext, cols, cap_height, d_dig, d_cap, d_leaves, d_lde, n_ext)
         return cls(ctx, d_poly, d_lde, tree, n_polys, log_n, rate_bits, blinding)
 
     @classmethod

@@ -133,7 +133,7 @@ class CircuitData:
             setattr(self, k, circuit[k])
         fp = self.fri_params
         cs = np.ascontiguousarray(list(circuit["constants"]) + list(circuit["sigmas"]), dtype=np.uint64)
-        self.constants_sigmas_commitment = PolynomialBatch.from_values(ctx, cs, fp["rate_bits"], False, fp["cap_height"])
+        self.constants_sigmas_commitment = PolynomialBatch.from_values(ctx, cs, fp["rate_bits"], False, fp["cap_height"], leaf_major=False)
         self.d_sigmas = DeviceBuffer.from_host(ctx, _host_u64(circuit["sigmas"]))
         self.d_k_is = DeviceBuffer.from_host(ctx, _host_u64(circuit["k_is"]))
         mk = dict(noop=lambda p: gp.noop_gate(), constant=gp.constant_gate, public_input=lambda p: gp.public_input_gate(),
@@ -189,7 +189,7 @@ def prove(ctx, cd, wires, public_inputs, timing=None):
     d_w = DeviceBuffer(ctx, cd.num_wires * n)
     _lib.call("gl_memcpy_d2d", d_w.ptr, d_wire_values.ptr, cd.num_wires * n * 8, ctx.ptr)
     t = stage("upload witness", t)
-    wires_c = PolynomialBatch.from_values_device(ctx, d_w, cd.num_wires, db, rate_bits, False, cap_height)
+    wires_c = PolynomialBatch.from_values_device(ctx, d_w, cd.num_wires, db, rate_bits, False, cap_height, leaf_major=False)
     t = stage("wires commitment", t)
     ch = Challenger(ctx)
     ch.observe_hash(cd.circuit_digest)
@@ -202,7 +202,7 @@ def prove(ctx, cd, wires, public_inputs, timing=None):
     d_zpp, n_cols = all_wires_permutation_partial_products(ctx, d_wire_values, n, cd.d_sigmas, n, cd.d_k_is, betas, gammas, num_routed,
                                                            qdf, db)
     t = stage("partial products", t)
-    zs_c = PolynomialBatch.from_values_device(ctx, d_zpp, n_cols, db, rate_bits, False, cap_height)
+    zs_c = PolynomialBatch.from_values_device(ctx, d_zpp, n_cols, db, rate_bits, False, cap_height, leaf_major=False)
     t = stage("zs partial products commitment", t)
     ch.observe_cap(zs_c.merkle_tree.cap.tolist())
     alphas = ch.get_n_challenges(nch)
@@ -220,7 +220,7 @@ def prove(ctx, cd, wires, public_inputs, timing=None):
             if tail.any():
                 raise ValueError("Quotient has failed, the vanishing polynomial is not divisible by Z_H")
             _lib.call("gl_memcpy_d2d", d_chunks.ptr + 8 * c * qdf * n, d_q.ptr + 8 * (c << (db + qdb)), 8 * qdf * n, ctx.ptr)
-    quot_c = PolynomialBatch.from_coeffs_device(ctx, d_chunks, nch * qdf, db, rate_bits, False, cap_height)
+    quot_c = PolynomialBatch.from_coeffs_device(ctx, d_chunks, nch * qdf, db, rate_bits, False, cap_height, leaf_major=False)
     t = stage("quotient commitment", t)
     ch.observe_cap(quot_c.merkle_tree.cap.tolist())
     zeta = ch.get_extension_challenge()

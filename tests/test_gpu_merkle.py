@@ -195,3 +195,19 @@ def test_sponge_absorb_matches_hash_no_pad(gpu):
     for k in (1, 3, 8, 9, 16, 23, 135):
         inp = [(i * 0x9E3779B97F4A7C15 + 7) % P for i in range(k)]
         assert hash_no_pad(gpu, inp) == pyref.hash_no_pad(inp)
+
+
+def test_open_batch_from_the_column_major_lde(gpu):
+    """a commitment built without the leaf-major copy still opens leaves + paths (strided gather)"""
+    import plonky2_gpu_amd as pg
+
+    rng = np.random.default_rng(8)
+    vals = rng.integers(0, P, size=(9, 64), dtype=np.uint64)
+    a = pg.PolynomialBatch.from_values(gpu, vals, 3, False, 2, leaf_major=True)
+    b = pg.PolynomialBatch.from_values(gpu, vals, 3, False, 2, leaf_major=False)
+    assert b.merkle_tree.d_leaves is None and (a.merkle_tree.cap == b.merkle_tree.cap).all()
+    idx = [0, 511, 37, 256]
+    la, sa = a.merkle_tree.open_batch(idx)
+    lb, sb = b.merkle_tree.open_batch(idx)
+    assert (la == lb).all() and (sa == sb).all()
+    assert (b.get_lde_values(5) == a.get_lde_values(5)).all()
