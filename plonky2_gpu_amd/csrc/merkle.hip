@@ -18,7 +18,10 @@
 // fully coalesced without materialising the leaf-major matrix first.
 #include "merkle.h"
 
+#include <mutex>
+
 #include "poseidon.cuh"
+#include "poseidon_coop.cuh"
 
 namespace plonky2_hip {
 
@@ -152,19 +155,35 @@ __global__ __launch_bounds__(256) void permute_batch_kernel(uint64_t *states, ui
 }
 
 // The transcript's sponge (iop/challenger.rs:131-149 run over several full rate blocks): serial by
-// definition, so one lane walks the blocks; state[0..8) is overwritten by each block, then permuted.
-__global__ void sponge_absorb_kernel(uint64_t *state, const uint64_t *inputs, uint32_t n_blocks) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint64_t s[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = state[k];
+// definition, so ONE wavefront computes each permutation cooperatively (poseidon_coop.cuh); state[0..8)
+// is overwritten by each block, then permuted.
+__global__ __launch_bounds__(64) void sponge_absorb_kernel(uint64_t *state, const uint64_t *inputs, uint32_t n_blocks,
+                                                           poseidon_coop::Tables tb) {
+    __shared__ uint64_t lds[12];
+    const int lane = threadIdx.x;
+    uint64_t x = lane < 12 ? state[lane] : 0;
     for (uint32_t b = 0; b < n_blocks; b++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = inputs[8 * b + k];
-        poseidon::permute(s);
+        if (lane < 8) x = inputs[8 * b + lane];
+        x = poseidon_coop::permute(x, tb, lds);
     }
-#pragma unroll
-    for (int k = 0; k < 12; k++) state[k] = gl::canon(s[k]);
+    if (lane < 12) state[lane] = gl::canon(x);
+}
+
+// A tree layer with few nodes: one wavefront per node (latency ~6x shorter than a lane per node).
+__global__ __launch_bounds__(64) void tree_layer_coop_kernel(uint64_t *__restrict__ digests, uint64_t *__restrict__ cap, uint32_t L,
+                                                             uint32_t log_sub_leaves, poseidon_coop::Tables tb) {
+    __shared__ uint64_t lds[12];
+    const int lane = threadIdx.x;
+    const uint64_t g = blockIdx.x;
+    const uint32_t log_pairs = log_sub_leaves - L - 1;
+    const uint64_t sub = g >> log_pairs, q = g & ((1ull << log_pairs) - 1);
+    const uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+    uint64_t *tree = digests + 4 * sub * sub_digests;
+    const uint64_t *pair = tree + 4 * digest_slot(2 * q, L);  // left digest | right digest, contiguous
+    uint64_t x = lane < 8 ? pair[lane] : 0;
+    x = poseidon_coop::permute(x, tb, lds);
+    uint64_t *dst = log_pairs == 0 ? cap + 4 * sub : tree + 4 * digest_slot(q, L + 1);
+    if (lane < 4) dst[lane] = gl::canon(x);
 }
 
 // MerkleTree::prove (merkle_tree.rs:392-440) + the leaf itself for `count` leaf indices at once:
@@ -211,12 +230,55 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint64_t *__restri
 
 unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// per-device tables of the cooperative permutation, built on first use
+constexpr int MAX_DEVICES = 64;
+std::mutex g_coop_mutex;
+uint64_t *g_coop_tables[MAX_DEVICES] = {};
+
+hipError_t coop_tables(poseidon_coop::Tables *tb, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_coop_mutex);
+    if (!g_coop_tables[dev]) {
+        uint64_t *p = nullptr;
+        const size_t elems = (size_t)(poseidon_coop::T0_ROWS + poseidon_coop::T_ROWS) * poseidon_coop::LANES;
+        e = hipMalloc(&p, elems * sizeof(uint64_t));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(poseidon_coop::build_tables_kernel, dim3(1), dim3(64), 0, stream, p,
+                           p + poseidon_coop::T0_ROWS * poseidon_coop::LANES);
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return e;
+        }
+        g_coop_tables[dev] = p;
+    }
+    tb->t0 = g_coop_tables[dev];
+    tb->t = g_coop_tables[dev] + poseidon_coop::T0_ROWS * poseidon_coop::LANES;
+    return hipSuccess;
+}
+
+// layers with fewer nodes than this cannot fill the chip with one lane per node: they are latency
+// bound, and a wavefront per node shortens the latency
+constexpr uint64_t COOP_LAYER_MAX_NODES = 4096;
+
 hipError_t tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t log_sub_leaves, hipStream_t stream) {
     uint64_t n_sub = n_leaves >> log_sub_leaves;
+    poseidon_coop::Tables tb = {};
     for (uint32_t L = 0; L < log_sub_leaves; L++) {
         uint64_t total = n_sub << (log_sub_leaves - L - 1);
-        hipLaunchKernelGGL(tree_layer_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L,
-                           log_sub_leaves, total);
+        if (total <= COOP_LAYER_MAX_NODES) {
+            if (!tb.t) {
+                hipError_t e = coop_tables(&tb, stream);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(tree_layer_coop_kernel, dim3((unsigned)total), dim3(64), 0, stream, digests, cap, L, log_sub_leaves, tb);
+        } else {
+            hipLaunchKernelGGL(tree_layer_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L,
+                               log_sub_leaves, total);
+        }
     }
     return hipGetLastError();
 }
@@ -260,7 +322,10 @@ hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t 
 }
 
 hipError_t sponge_absorb(uint64_t *d_state, const uint64_t *d_inputs, uint32_t n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(sponge_absorb_kernel, dim3(1), dim3(64), 0, stream, d_state, d_inputs, n_blocks);
+    poseidon_coop::Tables tb;
+    hipError_t e = coop_tables(&tb, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sponge_absorb_kernel, dim3(1), dim3(64), 0, stream, d_state, d_inputs, n_blocks, tb);
     return hipGetLastError();
 }
 
