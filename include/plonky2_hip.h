@@ -65,6 +65,10 @@ GlError gl_ctx_synchronize(void *ctx); /* waits for both streams */
 /* Thin device-memory helpers for hosts without a HIP binding (synchronous). */
 GlError gl_malloc(void **d_ptr, uint64_t bytes);
 GlError gl_free(void *d_ptr);
+/* Page-locked host staging memory — the reference's MyAllocator (plonky2/src/fri/oracle.rs:49-73,
+ * cudaHostAlloc): transfers from it run at link speed and do not stage through a bounce buffer. */
+GlError gl_malloc_host(void **h_ptr, uint64_t bytes);
+GlError gl_free_host(void *h_ptr);
 GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx);
 GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx);
 GlError gl_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes, void *ctx);

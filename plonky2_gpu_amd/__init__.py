@@ -9,7 +9,7 @@ No bulk field arithmetic happens on the CPU (only scalar transcript glue such as
 challenge); without the HIP library it raises.
 """
 from ._lib import GL_E_INVALID, GL_E_UNSUPPORTED, Plonky2HipError, load  # noqa: F401
-from .device import Context, DeviceBuffer, Event  # noqa: F401
+from .device import Context, DeviceBuffer, Event, PinnedArray  # noqa: F401
 from .fft import coset_fft, coset_ifft, coset_lde_bit_reversed, fft_with_options, ifft_with_options  # noqa: F401
 from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401

@@ -77,6 +77,8 @@ SIGNATURES = {
     "gl_ctx_synchronize": (GlError, [_vp]),
     "gl_malloc": (GlError, [ctypes.POINTER(_vp), _u64]),
     "gl_free": (GlError, [_vp]),
+    "gl_malloc_host": (GlError, [ctypes.POINTER(_vp), _u64]),
+    "gl_free_host": (GlError, [_vp]),
     "gl_memcpy_h2d": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2h": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2d": (GlError, [_vp, _vp, _u64, _vp]),

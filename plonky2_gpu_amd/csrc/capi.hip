@@ -241,6 +241,17 @@ GlError gl_free(void *d_ptr) {
     return ok();
 }
 
+GlError gl_malloc_host(void **h_ptr, uint64_t bytes) {
+    if (!h_ptr) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault));
+    return ok();
+}
+
+GlError gl_free_host(void *h_ptr) {
+    HIP_TRY(hipHostFree(h_ptr));
+    return ok();
+}
+
 GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx) {
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(ctx)->stream));

@@ -282,11 +282,15 @@ hipError_t fri_proof_of_work(const NttTables &tb, const uint64_t state[12], uint
     PowState st;
     for (int k = 0; k < 12; k++) st.s[k] = state[k] % glh::P;
     unsigned long long *best = reinterpret_cast<unsigned long long *>(tb.scratch);
-    const uint64_t batch = 1ull << 22;
-    for (uint64_t base = 0; base < glh::P; base += batch) {
+    // Batches are scanned in order, so the first batch that holds a witness holds the smallest one. The
+    // expected search length is 2^min_leading_zeros' (16 proof-of-work bits -> 2^16 candidates): the batch
+    // starts at 2^17 (one launch ~ one permutation latency) and doubles while nothing is found.
+    uint64_t batch = 1ull << 17;
+    for (uint64_t base = 0; base < glh::P; base += batch, batch = batch < (1ull << 24) ? batch * 2 : batch) {
         hipError_t e = hipMemsetAsync(best, 0xFF, 8, stream);
         if (e != hipSuccess) return e;
-        uint64_t count = glh::P - base < batch ? glh::P - base : batch;
+        const uint64_t this_batch = batch;
+        uint64_t count = glh::P - base < this_batch ? glh::P - base : this_batch;
         hipLaunchKernelGGL(pow_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, st, pos, min_leading_zeros, base, count, best);
         unsigned long long h = ~0ull;
         e = hipMemcpyAsync(&h, best, 8, hipMemcpyDeviceToHost, stream);

@@ -79,6 +79,29 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """A page-locked host array of u64 (hipHostMalloc): the twin of the reference's pinned staging
+    vectors (MyAllocator, plonky2/src/fri/oracle.rs:49-73). `.array` is a numpy view."""
+
+    def __init__(self, n_elems):
+        p = ctypes.c_void_p()
+        _lib.call("gl_malloc_host", ctypes.byref(p), int(n_elems) * 8)
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint64)), shape=(int(n_elems),))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            _lib.call("gl_free_host", self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Event:
     def __init__(self):
         p = ctypes.c_void_p()
