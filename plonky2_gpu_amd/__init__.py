@@ -14,6 +14,7 @@ from .fft import coset_fft, coset_ifft, coset_lde_bit_reversed, fft_with_options
 from .merkle_tree import MerkleTree  # noqa: F401
 from .polynomial_batch import PolynomialBatch  # noqa: F401
 from .challenger import Challenger  # noqa: F401
+from . import serialization  # noqa: F401
 from .fri import prove_openings  # noqa: F401
 from .prover import CircuitData, GateProgram, all_wires_permutation_partial_products, compute_quotient_polys, prove  # noqa: F401
 

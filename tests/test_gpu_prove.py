@@ -24,6 +24,10 @@ def test_prove_equals_oracle_and_verifies(gpu, degree_bits, two_groups, arity_bi
         for k in ("wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap", "openings", "public_inputs"):
             assert proof[k] == exp[k], k
         assert proof["opening_proof"] == exp["opening_proof"]
+        # the proof on the wire (util/serialization.rs:674-689) is byte-identical
+        from oracle import serialize_ref
+
+        assert pg.serialization.proof_to_bytes(proof) == serialize_ref.proof_bytes(exp)
     assert set(timing) >= {"wires commitment", "quotient polys", "opening proof (FRI)"}
 
 
