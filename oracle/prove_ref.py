@@ -16,7 +16,7 @@ A circuit is a dict:
   constants (columns, selectors first), sigmas (columns), fri_params, circuit_digest,
   constants_sigmas = the preprocessed commitment {"polynomials","leaves","digests","cap"}.
 """
-from . import fri_ref, plonk_ref, pyref
+from . import fri_ref, gates_ref, plonk_ref, pyref
 
 P = pyref.P
 ext_add, ext_sub, ext_mul, ext_inv, ext_pow = fri_ref.ext_add, fri_ref.ext_sub, fri_ref.ext_mul, fri_ref.ext_inv, fri_ref.ext_pow
@@ -58,7 +58,11 @@ def commit_from_values(values, rate_bits, cap_height):
 def base_gates(circuit):
     mk = dict(noop=lambda p: plonk_ref.noop_gate(), constant=plonk_ref.constant_gate, public_input=lambda p: plonk_ref.public_input_gate(),
               arithmetic=plonk_ref.arithmetic_gate)
-    return [mk[kind](param) for kind, param in circuit["gates"]]
+
+    def other(kind, param):  # the rest of the ed25519 gate list lives in gates_ref.py
+        return lambda consts, wires, pih: gates_ref.constraints(kind, param, consts, wires, pih, gates_ref.Base)
+
+    return [mk[kind](param) if kind in mk else other(kind, param) for kind, param in circuit["gates"]]
 
 
 def fri_instance(circuit, zeta):
@@ -180,7 +184,7 @@ def gate_constraints_ext(circuit, local_constants, local_wires, pih):
                 m = ext_mul(ext_mul(local_wires[4 * i], local_wires[4 * i + 1]), consts[0])
                 cons.append(ext_sub(local_wires[4 * i + 3], ext_add(m, ext_mul(local_wires[4 * i + 2], consts[1]))))
         else:
-            raise ValueError(kind)
+            cons = gates_ref.constraints(kind, param, consts, local_wires, pih, gates_ref.Ext)
         for k, c in enumerate(cons):
             out[k] = ext_add(out[k], ext_mul(filt, c))
     return out

@@ -18,20 +18,51 @@ LOAD_WIRE, LOAD_CONST, LOAD_PI, LOAD_IMM, ADD, SUB, MUL, EMIT = range(8)
 MAX_REGS = 64
 
 
-class GateAsm:
+class ImmediatePool:
+    """Field constants referenced by LOAD_IMM, shared by all gates of a circuit (deduplicated)."""
+
     def __init__(self):
+        self.values = []
+        self._index = {}
+
+    def index(self, value):
+        value = int(value) % P
+        if value not in self._index:
+            if len(self.values) >= 65536:
+                raise ValueError("more than 65536 distinct immediates")
+            self._index[value] = len(self.values)
+            self.values.append(value)
+        return self._index[value]
+
+
+P = 0xFFFFFFFF00000001
+
+
+class GateAsm:
+    """Emits one gate's register program. Registers come from a free list: `free()` returns
+    temporaries, `release()` returns all of them (between independent constraints)."""
+
+    def __init__(self, pool=None):
         self.instrs = []
-        self.next_reg = 0
+        self.pool = pool
+        self._free = list(range(MAX_REGS - 1, -1, -1))
 
     def _reg(self):
-        r = self.next_reg
-        self.next_reg += 1
-        if r >= MAX_REGS:
-            raise ValueError("gate program needs more than %d registers" % MAX_REGS)
-        return r
+        if not self._free:
+            raise ValueError("gate program needs more than %d live registers" % MAX_REGS)
+        return self._free.pop()
 
-    def op(self, code, a, b=0):
-        r = self._reg()
+    def free(self, *regs):
+        for r in regs:
+            if r in self._free:
+                raise ValueError("register freed twice")
+            self._free.append(r)
+
+    def release(self):
+        self._free = list(range(MAX_REGS - 1, -1, -1))
+
+    def op(self, code, a, b=0, dst=None):
+        r = self._reg() if dst is None else dst
         self.instrs.append((code, r, a, b))
         return r
 
@@ -44,21 +75,40 @@ class GateAsm:
     def pi(self, i):
         return self.op(LOAD_PI, i)
 
-    def add(self, a, b):
-        return self.op(ADD, a, b)
+    def imm(self, value):
+        if self.pool is None:
+            raise ValueError("this gate needs an ImmediatePool")
+        return self.op(LOAD_IMM, self.pool.index(value))
 
-    def sub(self, a, b):
-        return self.op(SUB, a, b)
+    def add(self, a, b, dst=None):
+        return self.op(ADD, a, b, dst)
 
-    def mul(self, a, b):
-        return self.op(MUL, a, b)
+    def sub(self, a, b, dst=None):
+        return self.op(SUB, a, b, dst)
+
+    def mul(self, a, b, dst=None):
+        return self.op(MUL, a, b, dst)
 
     def emit(self, a):
         self.instrs.append((EMIT, 0, a, 0))
 
-    def release(self):
-        """registers are per constraint group: callers may reset between independent constraints"""
-        self.next_reg = 0
+    # -- helpers shared by several gates ---------------------------------------------------------
+    def reduce_with_powers(self, terms, base_reg):
+        """sum terms[i] * base^i (plonk_common.rs:116-128); returns a fresh register"""
+        acc = self.imm(0)
+        for t in reversed(terms):
+            self.mul(acc, base_reg, dst=acc)
+            self.add(acc, t, dst=acc)
+        return acc
+
+    def range_product(self, x, small):
+        """prod_{k < len(small)} (x - k); `small[k]` = register holding the constant k"""
+        acc = self.sub(x, small[0])
+        for k in range(1, len(small)):
+            t = self.sub(x, small[k])
+            self.mul(acc, t, dst=acc)
+            self.free(t)
+        return acc
 
 
 def arithmetic_gate(num_ops):
@@ -93,6 +143,394 @@ def public_input_gate():
 
 def noop_gate():
     return []
+
+
+def base_sum_gate(B, num_limbs, pool):
+    """BaseSumGate<B> { num_limbs } (plonky2/src/gates/base_sum.rs:213-230)"""
+    g = GateAsm(pool)
+    base = g.imm(B)
+    limbs = [g.wire(1 + i) for i in range(num_limbs)] if num_limbs <= 40 else None
+    if limbs is None:  # wide gates: reload instead of keeping every limb live
+        acc = g.imm(0)
+        for i in reversed(range(num_limbs)):
+            g.mul(acc, base, dst=acc)
+            t = g.wire(1 + i)
+            g.add(acc, t, dst=acc)
+            g.free(t)
+    else:
+        acc = g.reduce_with_powers(limbs, base)
+    s = g.wire(0)
+    g.emit(g.sub(acc, s))
+    g.release()
+    small = [g.imm(k) for k in range(B)]
+    for i in range(num_limbs):
+        x = g.wire(1 + i)
+        p = g.range_product(x, small)
+        g.emit(p)
+        g.free(x, p)
+    return g.instrs
+
+
+def _u32_limb_checks(g, first_limb_wire, count, split, small, four):
+    """range-check `count` base-4 limbs (emitting one constraint each, from the LAST limb down like the
+    reference's `for j in (0..n).rev()`), and return (low, high) = the limbs below / from `split`
+    recombined in base 4"""
+    low, high = g.imm(0), g.imm(0)
+    for j in reversed(range(count)):
+        limb = g.wire(first_limb_wire + j)
+        p = g.range_product(limb, small)
+        g.emit(p)
+        acc = low if j < split else high
+        g.mul(acc, four, dst=acc)
+        g.add(acc, limb, dst=acc)
+        g.free(limb, p)
+    return low, high
+
+
+def u32_add_many_gate(num_addends, num_ops, pool):
+    """U32AddManyGate (u32/src/gates/add_many_u32.rs:143-184)"""
+    g = GateAsm(pool)
+    for i in range(num_ops):
+        g.release()
+        o = (num_addends + 3) * i
+        small = [g.imm(k) for k in range(4)]
+        four, base = g.imm(4), g.imm(1 << 32)
+        computed = g.wire(o + num_addends)
+        for j in range(num_addends):
+            t = g.wire(o + j)
+            g.add(computed, t, dst=computed)
+            g.free(t)
+        res, car = g.wire(o + num_addends + 1), g.wire(o + num_addends + 2)
+        comb = g.mul(car, base)
+        g.add(comb, res, dst=comb)
+        g.emit(g.sub(comb, computed, dst=comb))
+        g.free(comb, computed)
+        low, high = _u32_limb_checks(g, (num_addends + 3) * num_ops + 18 * i, 18, 16, small, four)
+        g.emit(g.sub(low, res, dst=low))
+        g.emit(g.sub(high, car, dst=high))
+    return g.instrs
+
+
+def u32_arithmetic_gate(num_ops, pool):
+    """U32ArithmeticGate (u32/src/gates/arithmetic_u32.rs:326-385)"""
+    g = GateAsm(pool)
+    for i in range(num_ops):
+        g.release()
+        small = [g.imm(k) for k in range(4)]
+        four, base, one, umax = g.imm(4), g.imm(1 << 32), small[1], g.imm(0xFFFFFFFF)
+        m0, m1, ad, lo, hi, inv = (g.wire(6 * i + k) for k in range(6))
+        computed = g.mul(m0, m1)
+        g.add(computed, ad, dst=computed)
+        t = g.sub(umax, hi)
+        g.mul(inv, t, dst=t)
+        g.sub(t, one, dst=t)
+        g.emit(g.mul(t, lo, dst=t))
+        g.mul(hi, base, dst=t)
+        g.add(t, lo, dst=t)
+        g.emit(g.sub(t, computed, dst=t))
+        g.free(t, computed, m0, m1, ad, inv)
+        low, high = _u32_limb_checks(g, 6 * num_ops + 32 * i, 32, 16, small, four)
+        g.emit(g.sub(low, lo, dst=low))
+        g.emit(g.sub(high, hi, dst=high))
+    return g.instrs
+
+
+def u32_subtraction_gate(num_ops, pool):
+    """U32SubtractionGate (u32/src/gates/subtraction_u32.rs:233-269)"""
+    g = GateAsm(pool)
+    for i in range(num_ops):
+        g.release()
+        small = [g.imm(k) for k in range(4)]
+        four, base, one = g.imm(4), g.imm(1 << 32), small[1]
+        x, y, bi, res, bo = (g.wire(5 * i + k) for k in range(5))
+        t = g.sub(x, y)
+        g.sub(t, bi, dst=t)
+        u = g.mul(bo, base)
+        g.add(t, u, dst=t)
+        g.emit(g.sub(res, t, dst=t))
+        g.free(t, u, x, y, bi)
+        low, _ = _u32_limb_checks(g, 5 * num_ops + 16 * i, 16, 16, small, four)
+        g.emit(g.sub(low, res, dst=low))
+        t = g.sub(one, bo)
+        g.emit(g.mul(bo, t, dst=t))
+    return g.instrs
+
+
+def u32_range_check_gate(num_input_limbs, pool):
+    """U32RangeCheckGate (u32/src/gates/range_check_u32.rs:89-111)"""
+    g = GateAsm(pool)
+    for i in range(num_input_limbs):
+        g.release()
+        small = [g.imm(k) for k in range(4)]
+        four = g.imm(4)
+        aux = [g.wire(num_input_limbs + 16 * i + j) for j in range(16)]
+        acc = g.reduce_with_powers(aux, four)
+        inp = g.wire(i)
+        g.emit(g.sub(acc, inp, dst=acc))
+        g.free(acc, inp)
+        for a in aux:
+            p = g.range_product(a, small)
+            g.emit(p)
+            g.free(p)
+    return g.instrs
+
+
+def comparison_gate(num_bits, num_chunks, pool):
+    """ComparisonGate (u32/src/gates/comparison.rs:325-402)"""
+    g = GateAsm(pool)
+    cb = -(-num_bits // num_chunks)
+    nc = num_chunks
+    base = g.imm(1 << cb)
+    for which in (0, 1):
+        acc = g.imm(0)
+        for i in reversed(range(nc)):
+            g.mul(acc, base, dst=acc)
+            t = g.wire(4 + which * nc + i)
+            g.add(acc, t, dst=acc)
+            g.free(t)
+        inp = g.wire(which)
+        g.emit(g.sub(acc, inp, dst=acc))
+        g.free(acc, inp)
+    g.release()
+    if cb > 4:
+        raise ValueError("comparison chunks wider than 4 bits are not supported by this emitter")
+    small = [g.imm(k) for k in range(1 << cb)]
+    base = g.imm(1 << cb)
+    one = small[1]
+    msd = g.imm(0)
+    for i in range(nc):
+        f, s2 = g.wire(4 + i), g.wire(4 + nc + i)
+        p = g.range_product(f, small)
+        g.emit(p)
+        g.free(p)
+        p = g.range_product(s2, small)
+        g.emit(p)
+        g.free(p)
+        diff = g.sub(s2, f)
+        dummy, eq, inter = g.wire(4 + 2 * nc + i), g.wire(4 + 3 * nc + i), g.wire(4 + 4 * nc + i)
+        neq = g.sub(one, eq)
+        t = g.mul(diff, dummy)
+        g.emit(g.sub(t, neq, dst=t))
+        g.emit(g.mul(eq, diff, dst=t))
+        g.mul(eq, msd, dst=t)
+        g.emit(g.sub(inter, t, dst=t))
+        g.mul(neq, diff, dst=t)
+        g.add(inter, t, dst=msd)
+        g.free(f, s2, diff, dummy, eq, inter, neq, t)
+    w3 = g.wire(3)
+    g.emit(g.sub(w3, msd, dst=msd))
+    bits = [g.wire(4 + 5 * nc + i) for i in range(cb + 1)]
+    for b in bits:
+        t = g.sub(one, b)
+        g.emit(g.mul(b, t, dst=t))
+        g.free(t)
+    two = g.imm(2)
+    comb = g.reduce_with_powers(bits, two)
+    t = g.add(w3, base)
+    g.emit(g.sub(t, comb, dst=t))
+    rb = g.wire(2)
+    g.emit(g.sub(rb, bits[cb], dst=t))
+    return g.instrs
+
+
+def random_access_gate(bits, num_copies, num_extra_constants, pool):
+    """RandomAccessGate (plonky2/src/gates/random_access.rs:409-450)"""
+    g = GateAsm(pool)
+    vs = 1 << bits
+    routed = (2 + vs) * num_copies + num_extra_constants
+    for c in range(num_copies):
+        g.release()
+        o = (2 + vs) * c
+        one = g.imm(1)
+        bs = [g.wire(routed + c * bits + i) for i in range(bits)]
+        for b in bs:
+            t = g.sub(b, one)
+            g.emit(g.mul(b, t, dst=t))
+            g.free(t)
+        rec = g.imm(0)
+        for b in reversed(bs):
+            g.add(rec, rec, dst=rec)
+            g.add(rec, b, dst=rec)
+        idx = g.wire(o)
+        g.emit(g.sub(rec, idx, dst=rec))
+        g.free(rec, idx)
+        items = [g.wire(o + 2 + i) for i in range(vs)]
+        for b in bs:
+            nxt = []
+            for k in range(len(items) // 2):
+                x, y = items[2 * k], items[2 * k + 1]
+                g.sub(y, x, dst=y)
+                g.mul(b, y, dst=y)
+                g.add(x, y, dst=x)
+                g.free(y)
+                nxt.append(x)
+            items = nxt
+        claimed = g.wire(o + 1)
+        g.emit(g.sub(items[0], claimed, dst=claimed))
+    g.release()
+    for i in range(num_extra_constants):
+        c, w = g.const(i), g.wire((2 + vs) * num_copies + i)
+        g.emit(g.sub(c, w, dst=c))
+        g.free(c, w)
+    return g.instrs
+
+
+def poseidon_gate(pool):
+    """PoseidonGate (plonky2/src/gates/poseidon.rs:485-564) over the permutation's own tables
+    (hash/poseidon.rs:53-151, poseidon_goldilocks.rs:21-212)."""
+    from .poseidon_tables import TABLES as T
+
+    g = GateAsm(pool)
+    SW, WIRE_SWAP, START_DELTA = 12, 24, 25
+    START_FULL_0 = START_DELTA + 4
+    START_PARTIAL = START_FULL_0 + SW * 3
+    START_FULL_1 = START_PARTIAL + 22
+    one = g.imm(1)
+    swap = g.wire(WIRE_SWAP)
+    t = g.sub(swap, one)
+    g.emit(g.mul(swap, t, dst=t))
+    g.free(t, one)
+    state = [None] * SW
+    for i in range(4):
+        lhs, rhs, delta = g.wire(i), g.wire(i + 4), g.wire(START_DELTA + i)
+        t = g.sub(rhs, lhs)
+        g.mul(swap, t, dst=t)
+        g.emit(g.sub(t, delta, dst=t))
+        g.free(t)
+        state[i] = g.add(lhs, delta, dst=lhs)
+        state[i + 4] = g.sub(rhs, delta, dst=rhs)
+        g.free(delta)
+    g.free(swap)
+    for i in range(8, SW):
+        state[i] = g.wire(i)
+
+    def constant_layer(rc):
+        for i in range(SW):
+            c = g.imm(T["ALL_ROUND_CONSTANTS"][rc * SW + i])
+            g.add(state[i], c, dst=state[i])
+            g.free(c)
+
+    def sbox(x):
+        x2 = g.mul(x, x)
+        x4 = g.mul(x2, x2)
+        g.mul(x, x2, dst=x2)
+        g.mul(x2, x4, dst=x)
+        g.free(x2, x4)
+
+    def mds_layer():
+        circ = [g.imm(c) for c in T["MDS_CIRC"]]
+        new = []
+        for r in range(SW):
+            d = g.imm(T["MDS_DIAG"][r])
+            acc = g.mul(state[r], d)
+            g.free(d)
+            for i in range(SW):
+                t2 = g.mul(state[(i + r) % SW], circ[i])
+                g.add(acc, t2, dst=acc)
+                g.free(t2)
+            new.append(acc)
+        g.free(*circ)
+        g.free(*state)
+        state[:] = new
+
+    def check_against_wire(i, wire):
+        sin = g.wire(wire)
+        g.emit(g.sub(state[i], sin, dst=state[i]))
+        g.free(state[i])
+        state[i] = sin
+
+    rc = 0
+    for r in range(4):
+        constant_layer(rc)
+        if r != 0:
+            for i in range(SW):
+                check_against_wire(i, START_FULL_0 + SW * (r - 1) + i)
+        for i in range(SW):
+            sbox(state[i])
+        mds_layer()
+        rc += 1
+    # partial_first_constant_layer + mds_partial_layer_init
+    for i in range(SW):
+        c = g.imm(T["FAST_PARTIAL_FIRST_ROUND_CONSTANT"][i])
+        g.add(state[i], c, dst=state[i])
+        g.free(c)
+    new = [state[0]]
+    for c in range(1, SW):
+        acc = g.imm(0)
+        for r in range(1, SW):
+            m = g.imm(T["FAST_PARTIAL_ROUND_INITIAL_MATRIX"][(r - 1) * 11 + (c - 1)])
+            g.mul(state[r], m, dst=m)
+            g.add(acc, m, dst=acc)
+            g.free(m)
+        new.append(acc)
+    g.free(*state[1:])
+    state[:] = new
+    for r in range(22):
+        check_against_wire(0, START_PARTIAL + r)
+        sbox(state[0])
+        if r < 21:
+            c = g.imm(T["FAST_PARTIAL_ROUND_CONSTANTS"][r])
+            g.add(state[0], c, dst=state[0])
+            g.free(c)
+        # mds_partial_layer_fast
+        k = g.imm(T["MDS_CIRC"][0] + T["MDS_DIAG"][0])
+        d = g.mul(state[0], k)
+        g.free(k)
+        for i in range(1, SW):
+            wh = g.imm(T["FAST_PARTIAL_ROUND_W_HATS"][r * 11 + i - 1])
+            g.mul(state[i], wh, dst=wh)
+            g.add(d, wh, dst=d)
+            g.free(wh)
+        for i in range(1, SW):
+            v = g.imm(T["FAST_PARTIAL_ROUND_VS"][r * 11 + i - 1])
+            g.mul(state[0], v, dst=v)
+            g.add(state[i], v, dst=state[i])
+            g.free(v)
+        g.free(state[0])
+        state[0] = d
+    rc += 22
+    for r in range(4):
+        constant_layer(rc)
+        for i in range(SW):
+            check_against_wire(i, START_FULL_1 + SW * r + i)
+        for i in range(SW):
+            sbox(state[i])
+        mds_layer()
+        rc += 1
+    for i in range(SW):
+        out = g.wire(SW + i)
+        g.emit(g.sub(state[i], out, dst=out))
+        g.free(out)
+    return g.instrs
+
+
+def build_gate(kind, param, pool):
+    """(kind, param) -> instruction list; the kinds of the ed25519 gate list"""
+    if kind == "noop":
+        return noop_gate()
+    if kind == "constant":
+        return constant_gate(param)
+    if kind == "public_input":
+        return public_input_gate()
+    if kind == "arithmetic":
+        return arithmetic_gate(param)
+    if kind == "base_sum":
+        return base_sum_gate(param[0], param[1], pool)
+    if kind == "u32_add_many":
+        return u32_add_many_gate(param[0], param[1], pool)
+    if kind == "u32_arithmetic":
+        return u32_arithmetic_gate(param, pool)
+    if kind == "u32_subtraction":
+        return u32_subtraction_gate(param, pool)
+    if kind == "u32_range_check":
+        return u32_range_check_gate(param, pool)
+    if kind == "comparison":
+        return comparison_gate(param[0], param[1], pool)
+    if kind == "random_access":
+        return random_access_gate(param[0], param[1], param[2], pool)
+    if kind == "poseidon":
+        return poseidon_gate(pool)
+    raise ValueError(f"no register-program emitter for gate kind {kind!r}")
 
 
 def pack_program(gate_instrs, selector_indices, groups):

@@ -136,10 +136,10 @@ class CircuitData:
         self.constants_sigmas_commitment = PolynomialBatch.from_values(ctx, cs, fp["rate_bits"], False, fp["cap_height"], leaf_major=False)
         self.d_sigmas = DeviceBuffer.from_host(ctx, _host_u64(circuit["sigmas"]))
         self.d_k_is = DeviceBuffer.from_host(ctx, _host_u64(circuit["k_is"]))
-        mk = dict(noop=lambda p: gp.noop_gate(), constant=gp.constant_gate, public_input=lambda p: gp.public_input_gate(),
-                  arithmetic=gp.arithmetic_gate)
-        self.gate_program = GateProgram(ctx, [mk[kind](param) for kind, param in circuit["gates"]], circuit["selector_indices"],
-                                        circuit["groups"], [0, 0, 0, 0])
+        pool = gp.ImmediatePool()
+        programs = [gp.build_gate(kind, param, pool) for kind, param in circuit["gates"]]
+        self.gate_program = GateProgram(ctx, programs, circuit["selector_indices"], circuit["groups"], [0, 0, 0, 0],
+                                        immediates=pool.values or None)
         if compile_gates:
             self.gate_program.compile(self.num_gate_constraints, self.num_challenges)
 

@@ -133,3 +133,70 @@ def make_circuit(degree_bits=4, seed=1, two_groups=False, arity_bits=(2, 1), rat
                                    proof_of_work_bits=pow_bits, num_query_rounds=num_queries),
                    constants_sigmas=cs, circuit_digest=prove_ref.circuit_digest(cs["cap"], degree_bits))
     return circuit, inst["wires"], public_inputs
+
+
+FULL_GATES = [("noop", None), ("constant", 2), ("public_input", None), ("base_sum", (2, 8)), ("arithmetic", 3),
+              ("base_sum", (4, 6)), ("comparison", (8, 4)), ("u32_add_many", (2, 2)), ("u32_arithmetic", 2),
+              ("u32_subtraction", 2), ("u32_range_check", 2), ("random_access", (2, 2, 2)),
+              ("poseidon", None)]
+FULL_GROUPS = [(0, 5), (5, 9), (9, 12), (12, 13)]
+FULL_SELECTOR_INDICES = [0] * 5 + [1] * 4 + [2] * 3 + [3]
+
+
+def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap_height=1, pow_bits=3, num_queries=2):
+    """Every gate kind of the ed25519 gate list (small parameters) in one circuit of
+    the standard shape (135 wires, 80 routed): each row is one honestly generated gate row
+    (oracle/gates_ref.fill_row), copy constraints tie random pairs of arithmetic inputs. The selector
+    groups respect degree(gate) + |group| <= 9 like the reference's grouping (gates/selectors.rs)."""
+    from oracle import gates_ref, prove_ref
+
+    rng = random.Random(seed * 104729)
+    n = 1 << degree_bits
+    num_wires, num_routed = 135, 80
+    num_selectors = len(FULL_GROUPS)
+    public_inputs = [rng.randrange(P) for _ in range(3)]
+    pih = pyref.hash_no_pad(public_inputs)
+    row_gate = [rng.randrange(len(FULL_GATES)) for _ in range(n)]
+    row_gate[0] = 2
+    for k in range(len(FULL_GATES)):  # every gate at least once
+        if k != 2:
+            row_gate[1 + k % (n - 1)] = k if k != 2 else row_gate[1 + k % (n - 1)]
+    row_gate = [g if (g != 2 or r == 0) else 0 for r, g in enumerate(row_gate)]
+    consts = [[rng.randrange(P) for _ in range(n)] for _ in range(2)]
+    sel = [[(row_gate[r] if FULL_SELECTOR_INDICES[row_gate[r]] == g else 0xFFFFFFFF) for r in range(n)] for g in range(num_selectors)]
+    wires = [[rng.randrange(P) for _ in range(n)] for _ in range(num_wires)]
+    k_is = [pow(pyref.GENERATOR, j, P) for j in range(num_routed)]
+    w = pyref.root_of_unity(degree_bits)
+    subgroup = [pow(w, i, P) for i in range(n)]
+    sigma = {(r, j): (r, j) for j in range(num_routed) for r in range(n)}
+    # copy constraints between inputs of arithmetic rows (gate index 4), set before the rows are generated
+    arith_rows = [r for r in range(n) if row_gate[r] == 4]
+    inputs = [(r, 4 * i + k) for r in arith_rows for i in range(3) for k in range(3)]
+    rng.shuffle(inputs)
+    fixed = {}
+    for a, b in zip(inputs[0::2], inputs[1::2]):
+        v = rng.randrange(P)
+        fixed[a] = fixed[b] = v
+        sigma[a], sigma[b] = b, a
+    for r in range(n):
+        kind, param = FULL_GATES[row_gate[r]]
+        row = gates_ref.fill_row(kind, param, rng, [consts[0][r], consts[1][r]], pih)
+        if kind == "arithmetic":
+            for i in range(3):
+                for k in range(3):
+                    if (r, 4 * i + k) in fixed:
+                        row[4 * i + k] = fixed[(r, 4 * i + k)]
+                row[4 * i + 3] = (row[4 * i] * row[4 * i + 1] % P * consts[0][r] + row[4 * i + 2] * consts[1][r]) % P
+        for j, v in enumerate(row):
+            wires[j][r] = v
+    sigmas = [[k_is[sigma[(i, j)][1]] * subgroup[sigma[(i, j)][0]] % P for i in range(n)] for j in range(num_routed)]
+    constants = sel + consts
+    cs = prove_ref.commit_from_values(constants + sigmas, rate_bits, cap_height)
+    ngc = max(gates_ref.num_constraints(k, p) for k, p in FULL_GATES)
+    circuit = dict(degree_bits=degree_bits, num_wires=num_wires, num_routed_wires=num_routed, num_constants=num_selectors + 2,
+                   num_challenges=2, quotient_degree_factor=8, k_is=k_is, gates=FULL_GATES, selector_indices=FULL_SELECTOR_INDICES,
+                   groups=FULL_GROUPS, num_gate_constraints=ngc, constants=constants, sigmas=sigmas,
+                   fri_params=dict(rate_bits=rate_bits, cap_height=cap_height, reduction_arity_bits=list(arity_bits),
+                                   proof_of_work_bits=pow_bits, num_query_rounds=num_queries),
+                   constants_sigmas=cs, circuit_digest=prove_ref.circuit_digest(cs["cap"], degree_bits))
+    return circuit, wires, public_inputs

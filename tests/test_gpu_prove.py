@@ -40,3 +40,23 @@ def test_unsatisfied_witness_is_rejected_by_the_verifier(gpu):
     proof = pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)
     with pytest.raises(AssertionError):
         prove_ref.verify(circuit, proof)
+
+
+@pytest.mark.parametrize("compile_gates", [True, False])
+def test_full_gate_list_circuit(gpu, compile_gates):
+    """Every gate kind of the ed25519 gate list (BaseSum, U32 add-many / arithmetic / subtraction /
+    range-check, Comparison, RandomAccess, Poseidon + the four basic ones) as register programs, run
+    by the run-time compiled kernel and by the interpreter: the proof equals the oracle's."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+    from plonk_instance import make_full_circuit
+
+    circuit, wires, pis = make_full_circuit(4, seed=2)
+    cd = pg.CircuitData(gpu, circuit, compile_gates=compile_gates)
+    proof = pg.prove(gpu, cd, wires, pis)
+    assert prove_ref.verify(circuit, proof)
+    exp = prove_ref.prove(circuit, wires, pis)
+    assert pg.serialization.proof_to_bytes(proof) == serialize_ref.proof_bytes(exp)
+    if compile_gates:
+        src = cd.gate_program.kernel_source()
+        assert "gate_12" in src  # the Poseidon gate is gate 12 of this circuit

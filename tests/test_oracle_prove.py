@@ -68,3 +68,16 @@ def test_synthetic_circuit_generator_gives_a_provable_circuit():
     circuit["constants_sigmas"] = prove_ref.commit_from_values(circuit["constants"] + circuit["sigmas"], 3, 1)
     circuit["circuit_digest"] = prove_ref.circuit_digest(circuit["constants_sigmas"]["cap"], 4)
     assert prove_ref.verify(circuit, prove_ref.prove(circuit, wires, pis))
+
+
+def test_full_gate_list_prove_then_verify():
+    """every gate kind of the ed25519 gate list in one circuit (tests/plonk_instance.make_full_circuit)"""
+    from plonk_instance import make_full_circuit
+
+    circuit, wires, pis = make_full_circuit(4, seed=2)
+    proof = prove_ref.prove(circuit, wires, pis)
+    assert prove_ref.verify(circuit, proof)
+    bad = [list(c) for c in wires]
+    bad[30] = [(v + 1) % P for v in bad[30]]
+    with pytest.raises(AssertionError):
+        prove_ref.verify(circuit, prove_ref.prove(circuit, bad, pis))
