@@ -133,6 +133,7 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
  *   0 LOAD_WIRE dst<-local_wires[a]      1 LOAD_CONST dst<-local_constants[num_selectors+a]
  *   2 LOAD_PI dst<-public_inputs_hash[a]  3 LOAD_IMM dst<-d_immediates[a]
  *   4 ADD  5 SUB  6 MUL  dst<-r[a] op r[b]       7 EMIT next constraint of the gate <- r[a]
+ *   8 MULK dst<-r[a] * 2^b  (b < 64; a shift in the run-time compiled kernel)
  * (64 registers). Gate g is described by GlGateDesc {row = its index in the circuit's gate list,
  * selector_index, group_start, group_end (selectors_info.groups[selector_index]), prog_start, prog_len}.
  * Constraint k of every gate accumulates into term k, multiplied by the gate's filter. */

@@ -376,8 +376,6 @@ GlError gl_gate_kernel_build(const GlGateInstr *h_instrs, uint32_t num_instrs, c
                              uint32_t num_gate_constraints, uint32_t num_challenges, void **kernel) {
     if (!h_instrs || !h_gates || !kernel || (num_immediates && !h_immediates)) return fail(GL_E_INVALID, "null pointer");
     if (num_gate_constraints > 256) return fail(GL_E_INVALID, "num_gate_constraints > 256");
-    const NttTables *tb;
-    HIP_TRY(get_tables(&tb));  // binds the device before the module is loaded
     std::string err;
     GateKernel *k = gate_kernel_build(reinterpret_cast<const uint16_t *>(h_instrs), num_instrs, reinterpret_cast<const uint32_t *>(h_gates),
                                       num_gates, h_immediates, num_immediates, num_selectors, num_gate_constraints, num_challenges, &err);

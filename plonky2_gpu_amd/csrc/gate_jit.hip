@@ -19,6 +19,9 @@
 
 #include <hip/hiprtc.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <sstream>
 #include <vector>
 
@@ -31,14 +34,15 @@ const char *const GL_FIELD_SRC =
 #include "build/gl_field_src.inc"
     ;
 
-enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT };
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK };
 constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
 }  // namespace
 
 struct GateKernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
-    uint64_t *d_apow = nullptr;  // [num_challenges][num_constraints]
+    uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
+    uint64_t *d_pih = nullptr;   // the module's g_pih[4]
     uint32_t num_challenges = 0, num_constraints = 0;
     std::string source;
 };
@@ -50,7 +54,9 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n";
     o << "#define NCH " << nch << "\n#define NGC " << ngc << "\n";
     o << "struct GateSum { uint64_t v[NCH]; };\n";
-    o << "struct Pih { uint64_t v[4]; };\n";
+    // alpha powers and the public-inputs hash live at link-time-constant addresses, so every read is a scalar
+    // load (a pointer ARGUMENT of a non-inlined device function arrives in VGPRs and would be read per lane)
+    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n";
     for (uint32_t g = 0; g < num_gates; g++) {
         const uint32_t *d = gates + 6 * g;
         const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
@@ -59,14 +65,15 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
             return "";
         }
         o << "static __device__ __noinline__ GateSum gate_" << g
-          << "(const uint64_t* __restrict__ W, uint64_t wes, const uint64_t* __restrict__ C, uint64_t ces, "
-             "const uint64_t* __restrict__ apow, Pih pih) {\n";
+          << "(const uint64_t* __restrict__ W, uint64_t wes, const uint64_t* __restrict__ C, uint64_t ces) {\n";
         // compute_filter (gates/gate.rs:261-268)
         o << "  const uint64_t s = C[" << si << " * ces];\n  uint64_t filt = 1;\n";
         for (uint32_t i = gs; i < ge; i++)
             if (i != row) o << "  filt = gl::mul(filt, gl::sub(" << i << "ull, s));\n";
         if (num_selectors > 1) o << "  filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));\n";  // UNUSED_SELECTOR (selectors.rs:11)
-        o << "  uint64_t ga[NCH];\n  for (int c = 0; c < NCH; c++) ga[c] = 0;\n";
+        // the gate's constraints are reduced with powers of alpha lazily: one 192-bit column accumulator per
+        // challenge, one reduction per gate (gl::DotAcc) instead of a multiply-reduce-add per constraint
+        o << "  gl::DotAcc ga[NCH];\n";
         bool used[MAX_REGS] = {};
         for (uint32_t pc = ps; pc < ps + pl; pc++) used[instrs[4 * pc + 1] & (MAX_REGS - 1)] = true;
         for (uint32_t r = 0; r < MAX_REGS; r++)
@@ -78,7 +85,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
             switch (op) {
                 case GP_LOAD_WIRE: o << "  r" << dst << " = W[" << a << " * wes];\n"; break;
                 case GP_LOAD_CONST: o << "  r" << dst << " = C[" << (num_selectors + a) << " * ces];\n"; break;
-                case GP_LOAD_PI: o << "  r" << dst << " = pih.v[" << (a & 3) << "];\n"; break;
+                case GP_LOAD_PI: o << "  r" << dst << " = g_pih[" << (a & 3) << "];\n"; break;
                 case GP_LOAD_IMM:
                     if (a >= num_imms) {
                         *error = "LOAD_IMM index out of range";
@@ -101,22 +108,28 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                         *error = "register read before any write";
                         return "";
                     }
-                    if (k < ngc) o << "  for (int c = 0; c < NCH; c++) ga[c] = gl::mac(ga[c], r" << ra << ", apow[c * NGC + " << k << "]);\n";
+                    if (k < ngc) o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga[c], r" << ra << ", g_apow[c * NGC + " << k << "]);\n";
                     k++;
+                    break;
+                case GP_MULK:
+                    if (!used[ra] || b >= 96) {
+                        *error = "MULK: register read before any write, or shift >= 96";
+                        return "";
+                    }
+                    o << "  r" << dst << " = gl::mul_pow2<" << b << ">(r" << ra << ");\n";
                     break;
                 default: *error = "unknown opcode"; return "";
             }
         }
-        o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, ga[c]);\n  return out;\n}\n";
+        o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::dot_finish(ga[c]));\n  return out;\n}\n";
     }
     o << "extern \"C\" __global__ __launch_bounds__(128) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
-         "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, const uint64_t* __restrict__ apow, Pih pih, "
-         "uint64_t lde_size, uint64_t* __restrict__ out) {\n"
+         "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, uint64_t lde_size, uint64_t* __restrict__ out) {\n"
          "  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;\n  if (t >= lde_size) return;\n"
          "  const uint64_t* W = wires + t * wrs;\n  const uint64_t* C = cs + t * crs;\n"
          "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = 0;\n";
     for (uint32_t g = 0; g < num_gates; g++)
-        o << "  { GateSum s = gate_" << g << "(W, wes, C, ces, apow, pih); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
+        o << "  { GateSum s = gate_" << g << "(W, wes, C, ces); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
     o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t] = gl::canon(acc[c]);\n}\n";
     return o.str();
 }
@@ -137,6 +150,23 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         delete k;
         return nullptr;
     }
+    // Optional on-disk cache (PLONKY2_HIP_KERNEL_CACHE=<dir>): the code object is keyed by a hash of the
+    // generated source, so a circuit is compiled once per machine instead of once per process; the
+    // source is stored next to it for inspection.
+    std::string cache_path;
+    if (const char *dir = getenv("PLONKY2_HIP_KERNEL_CACHE")) {
+        uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
+        for (unsigned char ch : k->source) h = (h ^ ch) * 0x100000001b3ull;
+        char name[64];
+        snprintf(name, sizeof name, "/gate_%016llx", (unsigned long long)h);
+        cache_path = std::string(dir) + name;
+    }
+    std::vector<char> code;
+    if (!cache_path.empty()) {
+        std::ifstream f(cache_path + ".hsaco", std::ios::binary);
+        if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    if (code.empty()) {
     hiprtcProgram prog;
     hiprtcResult r = hiprtcCreateProgram(&prog, k->source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) {
@@ -158,12 +188,19 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
+    code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    if (!cache_path.empty()) {
+        std::ofstream(cache_path + ".hip") << k->source;
+        std::ofstream(cache_path + ".hsaco", std::ios::binary).write(code.data(), (std::streamsize)code.size());
+    }
+    }
     hipError_t e = hipModuleLoadData(&k->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "gate_constraints_kernel");
-    if (e == hipSuccess) e = hipMalloc(&k->d_apow, sizeof(uint64_t) * num_challenges * num_gate_constraints);
+    size_t bytes = 0;
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_apow), &bytes, k->module, "g_apow");
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_pih), &bytes, k->module, "g_pih");
     if (e != hipSuccess) {
         *error = std::string("loading the compiled gate kernel: ") + hipGetErrorString(e);
         gate_kernel_destroy(k);
@@ -174,7 +211,6 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
 
 void gate_kernel_destroy(GateKernel *k) {
     if (!k) return;
-    if (k->d_apow) (void)hipFree(k->d_apow);
     if (k->module) (void)hipModuleUnload(k->module);
     delete k;
 }
@@ -197,13 +233,12 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
     // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
     hipError_t e = hipMemcpyAsync(k->d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
+    const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
+    e = hipMemcpyAsync(k->d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
-    struct {
-        uint64_t v[4];
-    } pi = {{pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P}};
-    const uint64_t *apow_d = k->d_apow;
-    void *args[] = {&wires, &w_rs, &w_es, &cs, &c_rs, &c_es, &apow_d, &pi, &lde_size, &out};
+    void *args[] = {&wires, &w_rs, &w_es, &cs, &c_rs, &c_es, &lde_size, &out};
     const unsigned grid = (unsigned)((lde_size + 127) / 128);
     return hipModuleLaunchKernel(k->fn, grid, 1, 1, 128, 1, 1, 0, stream, args, nullptr);
 }

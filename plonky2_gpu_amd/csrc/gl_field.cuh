@@ -412,6 +412,52 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
     return mul(x3, x4);
 }
 
+// ---- lazy dot products --------------------------------------------------------------------
+// sum_i a_i * b_i over Goldilocks with ONE reduction at the end (the reference does the same on
+// the CPU with a u160 accumulator, poseidon.rs:34-47, 400-413). A 64x64 product is four 32x32
+// partial products; they are accumulated column-wise,
+//     A0 += a0*b0        A1 += a0*b1 + a1*b0        A2 += a1*b1
+// each column in a wrapping 64-bit accumulator (v_mad_u64_u32 adds for free) plus a 32-bit count
+// of its wrap-arounds (the mad's carry-out, one v_addc each). 8 half-rate instructions per term
+// instead of ~20 for a multiply-reduce-add. The carry SGPRs are consumed >= 2 instructions
+// after they are written (gfx950 VALU-writes-SGPR -> VALU-reads-it hazard).
+struct DotAcc {
+    uint64_t a0 = 0, a1 = 0, a2 = 0;
+    uint32_t k0 = 0, k1 = 0, k2 = 0;
+};
+
+__device__ __forceinline__ void dot_term(DotAcc &d, uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32);
+    uint32_t bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t c0, c1, c2;
+    asm("v_mad_u64_u32 %0, %6, %9, %11, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %9, %12, %1\n\t"
+        "v_mad_u64_u32 %2, %8, %10, %12, %2\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, %3, %6\n\t"
+        "v_mad_u64_u32 %1, %6, %10, %11, %1\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %7\n\t"
+        "v_addc_co_u32_e64 %5, vcc, 0, %5, %8\n\t"
+        "v_addc_co_u32_e64 %4, vcc, 0, %4, %6"
+        : "+v"(d.a0), "+v"(d.a1), "+v"(d.a2), "+v"(d.k0), "+v"(d.k1), "+v"(d.k2), "=&s"(c0), "=&s"(c1), "=&s"(c2)
+        : "v"(al), "v"(ah), "s"(bl), "s"(bh)
+        : "vcc");
+}
+
+// value = (A0 + k0*2^64) + (A1 + k1*2^64)*2^32 + (A2 + k2*2^64)*2^64   (mod p)
+__device__ __forceinline__ uint64_t dot_finish(const DotAcc &d) {
+    uint64_t lo = d.a0 + (d.a1 << 32);
+    uint64_t c0 = lo < d.a0;
+    uint64_t h1 = (d.a1 >> 32) + c0 + d.k0;  // < 2^33, no wrap
+    uint64_t hi = h1 + d.a2;
+    uint64_t top = (uint64_t)(hi < h1) + d.k2;  // units of 2^128
+    uint64_t k1s = (uint64_t)d.k1 << 32;  // k1 * 2^96 = (k1 << 32) * 2^64
+    uint64_t hi2 = hi + k1s;
+    top += hi2 < k1s;
+    // 2^128 = -2^32 (mod p); top < 2^7 so top << 32 is canonical
+    return sub(reduce128(lo, hi2), top << 32);
+}
+
+
 }  // namespace gl
 
 #ifndef GL_JIT

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void perm_finalize_kernel(uint64_t *out, const
 // the circuit is a small register program (see plonky2_gpu_amd/gate_program.py for the instruction set);
 // all lanes of a wavefront execute the same instruction stream, so the interpreter does not diverge.
 constexpr int GP_MAX_REGS = 64, GP_MAX_CONSTRAINTS = 256;
-enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT };
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK };
 
 struct GateProgramDev {
     const uint16_t *instrs;  // 4 x u16 per instruction: op, dst, a, b
@@ -184,6 +184,7 @@ __device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *loca
                 case GP_ADD: regs[dst] = gl::add(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
                 case GP_SUB: regs[dst] = gl::sub(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
                 case GP_MUL: regs[dst] = gl::mul(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
+                case GP_MULK: regs[dst] = gl::mul(regs[a & (GP_MAX_REGS - 1)], 1ull << (b & 63)); break;  // b < 64 here
                 case GP_EMIT:
                     if (k < gp.num_gate_constraints) acc[k] = gl::add(acc[k], gl::mul(filt, regs[a & (GP_MAX_REGS - 1)]));
                     k++;

@@ -10,11 +10,12 @@ Instruction = 4 x u16 {op, dst, a, b}; registers hold field elements.
     LOAD_PI    dst <- public_inputs_hash[a]
     LOAD_IMM   dst <- immediates[a]
     ADD/SUB/MUL dst <- r[a] (op) r[b]
+    MULK       dst <- r[a] * 2^b                                (b < 64)
     EMIT       next constraint of this gate <- r[a]            (accumulated as filter * r[a])
 """
 import numpy as np
 
-LOAD_WIRE, LOAD_CONST, LOAD_PI, LOAD_IMM, ADD, SUB, MUL, EMIT = range(8)
+LOAD_WIRE, LOAD_CONST, LOAD_PI, LOAD_IMM, ADD, SUB, MUL, EMIT, MULK = range(9)
 MAX_REGS = 64
 
 
@@ -89,20 +90,43 @@ class GateAsm:
     def mul(self, a, b, dst=None):
         return self.op(MUL, a, b, dst)
 
+    def mulk(self, a, shift, dst=None):
+        return self.op(MULK, a, shift, dst)
+
     def emit(self, a):
         self.instrs.append((EMIT, 0, a, 0))
 
     # -- helpers shared by several gates ---------------------------------------------------------
-    def reduce_with_powers(self, terms, base_reg):
-        """sum terms[i] * base^i (plonk_common.rs:116-128); returns a fresh register"""
+    def times(self, acc, base):
+        """acc <- acc * base for a small integer base: a shift when base is a power of two"""
+        if base & (base - 1) == 0:
+            self.mulk(acc, base.bit_length() - 1, dst=acc)
+        else:
+            b = self.imm(base)
+            self.mul(acc, b, dst=acc)
+            self.free(b)
+
+    def reduce_with_powers(self, terms, base):
+        """sum terms[i] * base^i (plonk_common.rs:116-128) for an integer base; returns a fresh register"""
         acc = self.imm(0)
         for t in reversed(terms):
-            self.mul(acc, base_reg, dst=acc)
+            self.times(acc, base)
             self.add(acc, t, dst=acc)
         return acc
 
     def range_product(self, x, small):
-        """prod_{k < len(small)} (x - k); `small[k]` = register holding the constant k"""
+        """prod_{k < len(small)} (x - k); `small[k]` = register holding the constant k. The value is what
+        the reference's product computes; for four factors it is formed as y (y + 2) with y = x^2 - 3x
+        (two multiplications instead of three)."""
+        if len(small) == 4:
+            y = self.mul(x, x)
+            t = self.add(x, x)
+            self.add(t, x, dst=t)
+            self.sub(y, t, dst=y)
+            self.add(y, small[2], dst=t)
+            self.mul(y, t, dst=y)
+            self.free(t)
+            return y
         acc = self.sub(x, small[0])
         for k in range(1, len(small)):
             t = self.sub(x, small[k])
@@ -148,17 +172,12 @@ def noop_gate():
 def base_sum_gate(B, num_limbs, pool):
     """BaseSumGate<B> { num_limbs } (plonky2/src/gates/base_sum.rs:213-230)"""
     g = GateAsm(pool)
-    base = g.imm(B)
-    limbs = [g.wire(1 + i) for i in range(num_limbs)] if num_limbs <= 40 else None
-    if limbs is None:  # wide gates: reload instead of keeping every limb live
-        acc = g.imm(0)
-        for i in reversed(range(num_limbs)):
-            g.mul(acc, base, dst=acc)
-            t = g.wire(1 + i)
-            g.add(acc, t, dst=acc)
-            g.free(t)
-    else:
-        acc = g.reduce_with_powers(limbs, base)
+    acc = g.imm(0)
+    for i in reversed(range(num_limbs)):  # reduce_with_powers(limbs, B)
+        g.times(acc, B)
+        t = g.wire(1 + i)
+        g.add(acc, t, dst=acc)
+        g.free(t)
     s = g.wire(0)
     g.emit(g.sub(acc, s))
     g.release()
@@ -171,7 +190,7 @@ def base_sum_gate(B, num_limbs, pool):
     return g.instrs
 
 
-def _u32_limb_checks(g, first_limb_wire, count, split, small, four):
+def _u32_limb_checks(g, first_limb_wire, count, split, small):
     """range-check `count` base-4 limbs (emitting one constraint each, from the LAST limb down like the
     reference's `for j in (0..n).rev()`), and return (low, high) = the limbs below / from `split`
     recombined in base 4"""
@@ -181,7 +200,7 @@ def _u32_limb_checks(g, first_limb_wire, count, split, small, four):
         p = g.range_product(limb, small)
         g.emit(p)
         acc = low if j < split else high
-        g.mul(acc, four, dst=acc)
+        g.mulk(acc, 2, dst=acc)
         g.add(acc, limb, dst=acc)
         g.free(limb, p)
     return low, high
@@ -194,18 +213,17 @@ def u32_add_many_gate(num_addends, num_ops, pool):
         g.release()
         o = (num_addends + 3) * i
         small = [g.imm(k) for k in range(4)]
-        four, base = g.imm(4), g.imm(1 << 32)
         computed = g.wire(o + num_addends)
         for j in range(num_addends):
             t = g.wire(o + j)
             g.add(computed, t, dst=computed)
             g.free(t)
         res, car = g.wire(o + num_addends + 1), g.wire(o + num_addends + 2)
-        comb = g.mul(car, base)
+        comb = g.mulk(car, 32)
         g.add(comb, res, dst=comb)
         g.emit(g.sub(comb, computed, dst=comb))
         g.free(comb, computed)
-        low, high = _u32_limb_checks(g, (num_addends + 3) * num_ops + 18 * i, 18, 16, small, four)
+        low, high = _u32_limb_checks(g, (num_addends + 3) * num_ops + 18 * i, 18, 16, small)
         g.emit(g.sub(low, res, dst=low))
         g.emit(g.sub(high, car, dst=high))
     return g.instrs
@@ -217,7 +235,7 @@ def u32_arithmetic_gate(num_ops, pool):
     for i in range(num_ops):
         g.release()
         small = [g.imm(k) for k in range(4)]
-        four, base, one, umax = g.imm(4), g.imm(1 << 32), small[1], g.imm(0xFFFFFFFF)
+        one, umax = small[1], g.imm(0xFFFFFFFF)
         m0, m1, ad, lo, hi, inv = (g.wire(6 * i + k) for k in range(6))
         computed = g.mul(m0, m1)
         g.add(computed, ad, dst=computed)
@@ -225,11 +243,11 @@ def u32_arithmetic_gate(num_ops, pool):
         g.mul(inv, t, dst=t)
         g.sub(t, one, dst=t)
         g.emit(g.mul(t, lo, dst=t))
-        g.mul(hi, base, dst=t)
+        g.mulk(hi, 32, dst=t)
         g.add(t, lo, dst=t)
         g.emit(g.sub(t, computed, dst=t))
         g.free(t, computed, m0, m1, ad, inv)
-        low, high = _u32_limb_checks(g, 6 * num_ops + 32 * i, 32, 16, small, four)
+        low, high = _u32_limb_checks(g, 6 * num_ops + 32 * i, 32, 16, small)
         g.emit(g.sub(low, lo, dst=low))
         g.emit(g.sub(high, hi, dst=high))
     return g.instrs
@@ -241,15 +259,15 @@ def u32_subtraction_gate(num_ops, pool):
     for i in range(num_ops):
         g.release()
         small = [g.imm(k) for k in range(4)]
-        four, base, one = g.imm(4), g.imm(1 << 32), small[1]
+        one = small[1]
         x, y, bi, res, bo = (g.wire(5 * i + k) for k in range(5))
         t = g.sub(x, y)
         g.sub(t, bi, dst=t)
-        u = g.mul(bo, base)
+        u = g.mulk(bo, 32)
         g.add(t, u, dst=t)
         g.emit(g.sub(res, t, dst=t))
         g.free(t, u, x, y, bi)
-        low, _ = _u32_limb_checks(g, 5 * num_ops + 16 * i, 16, 16, small, four)
+        low, _ = _u32_limb_checks(g, 5 * num_ops + 16 * i, 16, 16, small)
         g.emit(g.sub(low, res, dst=low))
         t = g.sub(one, bo)
         g.emit(g.mul(bo, t, dst=t))
@@ -262,9 +280,8 @@ def u32_range_check_gate(num_input_limbs, pool):
     for i in range(num_input_limbs):
         g.release()
         small = [g.imm(k) for k in range(4)]
-        four = g.imm(4)
         aux = [g.wire(num_input_limbs + 16 * i + j) for j in range(16)]
-        acc = g.reduce_with_powers(aux, four)
+        acc = g.reduce_with_powers(aux, 4)
         inp = g.wire(i)
         g.emit(g.sub(acc, inp, dst=acc))
         g.free(acc, inp)
@@ -280,11 +297,10 @@ def comparison_gate(num_bits, num_chunks, pool):
     g = GateAsm(pool)
     cb = -(-num_bits // num_chunks)
     nc = num_chunks
-    base = g.imm(1 << cb)
     for which in (0, 1):
         acc = g.imm(0)
         for i in reversed(range(nc)):
-            g.mul(acc, base, dst=acc)
+            g.times(acc, 1 << cb)
             t = g.wire(4 + which * nc + i)
             g.add(acc, t, dst=acc)
             g.free(t)
@@ -324,8 +340,7 @@ def comparison_gate(num_bits, num_chunks, pool):
         t = g.sub(one, b)
         g.emit(g.mul(b, t, dst=t))
         g.free(t)
-    two = g.imm(2)
-    comb = g.reduce_with_powers(bits, two)
+    comb = g.reduce_with_powers(bits, 2)
     t = g.add(w3, base)
     g.emit(g.sub(t, comb, dst=t))
     rb = g.wire(2)
