@@ -192,8 +192,10 @@ __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, u
 //             -> lo = (T.lo, V.lo), hi = W           (no intermediate can overflow 64 bits)
 //   reduce :  t0 = lo - hh (borrow => -= 2^32-1) ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32
 //             whose carry-out drives the last correction (goldilocks_field.rs:345-358).
-// `s_nop 1` = the two wait states between a VALU instruction that writes VCC/an SGPR and the VALU
-// instruction that consumes it as carry-in or select mask.
+// No wait states are spent between a VALU instruction that writes VCC and the next one that reads it
+// (carry-in, or v_cndmask's mask): gfx950 interlocks VCC. Measured, not assumed: the schedule with and
+// without `s_nop 1` pads agrees on 4M random + all edge-operand pairs, also when a single wavefront
+// runs alone and issues back to back; explicit SGPR-pair carries (dot_term) DO need two wait states.
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
     uint32_t rl, rh;
@@ -208,21 +210,15 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
         "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
         "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo = (lo.hi, carry)
         "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi   -> hi = (hl, hh) = (v122, v123)
-        "s_nop 1\n\t"
         "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
         "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh, lo = (v116, v120)
-        "s_nop 1\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
-        "s_nop 1\n\t"
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // borrow: t0 -= 2^32-1
         "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
-        "s_nop 1\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
         "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
-        "s_nop 1\n\t"
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
         "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
-        "s_nop 1\n\t"
         "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
         : "=&v"(rl), "=&v"(rh)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
@@ -243,7 +239,6 @@ __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
         "v_mov_b32_e32 v124, %6\n\t"                            // X = (c.lo, 0)
         "v_mad_u64_u32 v[116:117], vcc, %2, %4, v[124:125]\n\t" // T = al*bl + c.lo
         "v_add_co_u32_e32 v124, vcc, v117, %7\n\t"              // X = T.hi + c.hi (33 bits)
-        "s_nop 1\n\t"
         "v_addc_co_u32_e32 v125, vcc, 0, v125, vcc\n\t"
         "v_mad_u64_u32 v[118:119], vcc, %2, %5, v[124:125]\n\t" // U = al*bh + X
         "v_mov_b32_e32 v125, 0\n\t"
@@ -252,21 +247,15 @@ __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
         "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
         "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo
         "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi
-        "s_nop 1\n\t"
         "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
         "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh
-        "s_nop 1\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
-        "s_nop 1\n\t"
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
         "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
-        "s_nop 1\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
         "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"
-        "s_nop 1\n\t"
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
         "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
-        "s_nop 1\n\t"
         "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
         : "=&v"(rl), "=&v"(rh)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh), "v"(cl), "v"(ch)
