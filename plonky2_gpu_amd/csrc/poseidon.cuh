@@ -1,9 +1,10 @@
 // poseidon.cuh — Poseidon permutation over Goldilocks (width 12, 4+22+4 rounds, x^7) for gfx950.
 //
 // Same permutation as Poseidon::poseidon (plonky2/src/hash/poseidon.rs:602-616) with the "fast"
-// partial rounds (poseidon.rs:312-365, 400-427). One thread owns one permutation; the 12-word
-// state lives in 24 VGPRs for the whole permutation, every loop is unrolled so all table indices
-// are compile-time and the constants arrive as scalar literals / s_load, not per-lane loads.
+// partial rounds (poseidon.rs:312-365, 400-427), restructured in blocks of eleven rounds (see
+// partial_rounds). One thread owns one permutation; the 12-word state lives in 24 VGPRs for the whole
+// permutation, inner loops are unrolled so table indices are uniform and the constants arrive as
+// s_load / literals, not per-lane loads.
 // Integer modular arithmetic only — no MFMA use is possible or attempted.
 #pragma once
 #include "gl_field.cuh"
@@ -17,10 +18,12 @@ constexpr int W = 12;
 constexpr int HALF_FULL = 4;
 constexpr int N_PARTIAL = 22;
 
-// MDS layer, state' = (circ(C) + diag(D)) * state  (poseidon.rs:174-194, 238-260).
-// All C[i] <= 41 and D[0] = 8, so each row is accumulated exactly in two u64 lanes (low and
-// high 32-bit halves of the state words; 12*41*2^32 < 2^42) and reduced once.
-__device__ __forceinline__ void mds_layer(uint64_t (&s)[W]) {
+// MDS layer, state' = (circ(C) + diag(D)) * state  (poseidon.rs:174-194, 238-260), plus the NEXT
+// layer's additive constants `rc_next` (constant_layer of the following round, poseidon.rs:484-493, or
+// partial_first_constant_layer, :312-320): they ride on the accumulators' initial values for free.
+// All C[i] <= 41 and D[0] = 8, so each row is accumulated exactly in two u64 lanes (low and high
+// 32-bit halves of the state words; 2^32 + 12*41*2^32 < 2^42) and reduced once.
+__device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const uint64_t *__restrict__ rc_next) {
     uint64_t lo[W], hi[W];
 #pragma unroll
     for (int i = 0; i < W; i++) {
@@ -29,7 +32,8 @@ __device__ __forceinline__ void mds_layer(uint64_t (&s)[W]) {
     }
 #pragma unroll
     for (int r = 0; r < W; r++) {
-        uint64_t al = 0, ah = 0;
+        const uint64_t rc = rc_next[r];
+        uint64_t al = rc & 0xFFFFFFFFull, ah = rc >> 32;
 #pragma unroll
         for (int i = 0; i < W; i++) {
             al += lo[(i + r) % W] * POSEIDON_MDS_CIRC[i];
@@ -44,12 +48,13 @@ __device__ __forceinline__ void mds_layer(uint64_t (&s)[W]) {
     }
 }
 
-__device__ __forceinline__ void full_round(uint64_t (&s)[W], int round_ctr) {
-#pragma unroll
-    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i + W * round_ctr]);
+__device__ const uint64_t POSEIDON_ZERO_ROW[W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// s-box layer + MDS layer; the round's own constants were added by the previous layer
+__device__ __forceinline__ void full_round(uint64_t (&s)[W], const uint64_t *__restrict__ rc_next) {
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = gl::pow7(s[i]);
-    mds_layer(s);
+    mds_layer(s, rc_next);
 }
 
 // lazy dot products (one reduction per sum): gl::DotAcc / dot_term / dot_finish in gl_field.cuh
@@ -57,10 +62,18 @@ using gl::DotAcc;
 using gl::dot_finish;
 using gl::dot_term;
 
+// The 22 partial rounds (poseidon.rs:400-427, 587-599; partial_first_constant_layer has already been
+// added by the preceding MDS layer). The reference's recurrence per round is
+//     u_r = sbox(s0) + rc_r;   d_r = c*u_r + sum_i s_i*w_hat[r][i];   s_i += u_r*v[r][i];   s0 = d_r
+// i.e. eleven multiply-REDUCE-adds per round just to keep the s_i current. The s_i are linear in the
+// u_q, so inside a block of eleven rounds they are left at their block-start values and the missing
+// part is added through precomputed cross terms,
+//     d_r = c*u_r + sum_i s_i(block start)*w_hat[r][i] + sum_{q in block, q < r} CROSS[r][q]*u_q,
+//     CROSS[r][q] = sum_i w_hat[r][i]*v[q][i]      (tools/gen_poseidon_constants.py)
+// and the s_i are brought up to date once per block, s_i += sum_q v[q][i]*u_q — all of it lazy dot
+// products (8 VALU per term, one reduction per sum) instead of 22-instruction macs: 638 terms and
+// 44 reductions for the 22 rounds instead of 264 terms, 242 macs and 22 reductions.
 __device__ __forceinline__ void partial_rounds(uint64_t (&s)[W]) {
-    // partial_first_constant_layer (poseidon.rs:312-320)
-#pragma unroll
-    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT[i]);
     // mds_partial_layer_init (poseidon.rs:339-365): out[c] = sum_r s[r] * M[r-1][c-1]
     {
         uint64_t out[W];
@@ -75,28 +88,48 @@ __device__ __forceinline__ void partial_rounds(uint64_t (&s)[W]) {
 #pragma unroll
         for (int i = 0; i < W; i++) s[i] = out[i];
     }
+    constexpr int B = 11;
 #pragma unroll 1
-    for (int r = 0; r < N_PARTIAL; r++) {
-        s[0] = gl::pow7(s[0]);
-        s[0] = gl::add_canonical(s[0], POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[r]);
-        // mds_partial_layer_fast (poseidon.rs:400-427): d = s0*(C0+D0) + sum_i s[i]*w_hat[i]
-        DotAcc acc;
-        dot_term(acc, s[0], POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]);
+    for (int base = 0; base < N_PARTIAL; base += B) {
+        uint64_t u[B];
+        uint64_t x = s[0];
 #pragma unroll
-        for (int i = 1; i < W; i++) dot_term(acc, s[i], POSEIDON_FAST_PARTIAL_ROUND_W_HATS[r * 11 + (i - 1)]);
-        uint64_t s0 = s[0];
+        for (int k = 0; k < B; k++) {
+            const int r = base + k;
+            u[k] = gl::add_canonical(gl::pow7(x), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[r]);
+            DotAcc acc;
+            dot_term(acc, u[k], POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]);
 #pragma unroll
-        for (int i = 1; i < W; i++) s[i] = gl::mac(s[i], s0, POSEIDON_FAST_PARTIAL_ROUND_VS[r * 11 + (i - 1)]);
-        s[0] = dot_finish(acc);
+            for (int i = 1; i < W; i++) dot_term(acc, s[i], POSEIDON_FAST_PARTIAL_ROUND_W_HATS[r * 11 + (i - 1)]);
+#pragma unroll
+            for (int q = 0; q < k; q++) dot_term(acc, u[q], POSEIDON_FAST_PARTIAL_ROUND_CROSS[r * N_PARTIAL + base + q]);
+            x = dot_finish(acc);
+        }
+        s[0] = x;
+#pragma unroll
+        for (int i = 1; i < W; i++) {
+            DotAcc acc;
+            acc.a0 = s[i];  // the block-start value, weight 2^0
+#pragma unroll
+            for (int q = 0; q < B; q++) dot_term(acc, u[q], POSEIDON_FAST_PARTIAL_ROUND_VS[(base + q) * 11 + (i - 1)]);
+            s[i] = dot_finish(acc);
+        }
     }
 }
 
 __device__ __forceinline__ void permute(uint64_t (&s)[W]) {
+    // constant_layer of round 0; every later constant layer is folded into the MDS layer before it
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i]);
 #pragma unroll 1
-    for (int r = 0; r < HALF_FULL; r++) full_round(s, r);
+    for (int r = 0; r < HALF_FULL; r++)
+        full_round(s, r + 1 < HALF_FULL ? POSEIDON_ALL_ROUND_CONSTANTS + W * (r + 1) : POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT);
     partial_rounds(s);
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i + W * (HALF_FULL + N_PARTIAL)]);
 #pragma unroll 1
-    for (int r = 0; r < HALF_FULL; r++) full_round(s, HALF_FULL + N_PARTIAL + r);
+    for (int r = 0; r < HALF_FULL; r++)
+        full_round(s, r + 1 < HALF_FULL ? POSEIDON_ALL_ROUND_CONSTANTS + W * (HALF_FULL + N_PARTIAL + r + 1) : POSEIDON_ZERO_ROW);
 }
 
 }  // namespace poseidon
