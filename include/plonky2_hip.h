@@ -274,6 +274,47 @@ GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t lo
                               uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                               uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx);
 
+/* ---- the whole prover in two calls ---------------------------------------------------------------
+ * gl_circuit_create = the prover-side part of CircuitBuilder::build (plonky2/src/plonk/circuit_builder.rs:
+ * 849-960): uploads sigmas / k_is, commits constants||sigmas (constants_sigmas_commitment), derives the
+ * circuit digest (:915-927, empty domain separator) unless one is given, and compiles the gate programs.
+ * gl_prove = prove() (plonky2/src/plonk/prover.rs:40-233) from the full witness on: d_wires is the flat
+ * [num_wires][2^degree_bits] matrix of wire values in HBM (MatrixWitness::my_wire_values,
+ * iop/witness.rs:351-362; left untouched). The proof comes back in the reference's wire format
+ * (write_proof_with_public_inputs, util/serialization.rs:674-689) in a malloc'd buffer (gl_bytes_free).
+ * h_stage_ms (optional, GL_PROVE_STAGES doubles) receives per-stage wall times with a device
+ * synchronisation at each boundary: wires commit, partial products, Z/pp commit, quotient, quotient
+ * commit, opening set, FRI combine, FRI commit phase, proof of work, query rounds, serialisation. */
+typedef struct GlFriParams {
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t num_reductions;
+    const uint32_t *reduction_arity_bits; /* host, num_reductions */
+} GlFriParams;
+typedef struct GlCircuitDesc {
+    uint32_t degree_bits, num_wires, num_routed_wires, num_constants, num_challenges, quotient_degree_factor;
+    uint32_t num_gate_constraints;
+    GlFriParams fri;
+    const uint64_t *h_k_is;      /* num_routed_wires */
+    const uint64_t *h_constants; /* [num_constants][n] value columns, selectors first */
+    const uint64_t *h_sigmas;    /* [num_routed_wires][n] value columns */
+    const GlGateInstr *h_instrs;
+    uint32_t num_instrs;
+    const GlGateDesc *h_gates;
+    uint32_t num_gates;
+    const uint64_t *h_immediates;
+    uint32_t num_immediates, num_selectors;
+    int compile_gates;                /* 1: run-time compiled kernel, 0: interpreter */
+    const uint64_t *h_circuit_digest; /* 4, or NULL to derive it */
+} GlCircuitDesc;
+#define GL_PROVE_STAGES 11
+GlError gl_circuit_create(const GlCircuitDesc *desc, void **circuit, void *ctx);
+void gl_circuit_destroy(void *circuit);
+/* circuit digest (4) and constants_sigmas cap (4 << cap_height): what VerifierOnlyCircuitData holds */
+GlError gl_circuit_info(const void *circuit, uint64_t *h_digest, uint64_t *h_constants_sigmas_cap);
+GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                 uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx);
+void gl_bytes_free(uint8_t *p);
+
 /* ---------------------------------------------------------------------------------------------
  * (A) the reference's extern "C" surface (cuda/src/lib.rs:58-145). Synchronous.
  * ------------------------------------------------------------------------------------------- */

@@ -57,6 +57,47 @@ class GlQuotientArgs(ctypes.Structure):
     ]
 
 
+class GlFriParams(ctypes.Structure):
+    _fields_ = [
+        ("rate_bits", ctypes.c_uint32),
+        ("cap_height", ctypes.c_uint32),
+        ("proof_of_work_bits", ctypes.c_uint32),
+        ("num_query_rounds", ctypes.c_uint32),
+        ("num_reductions", ctypes.c_uint32),
+        ("reduction_arity_bits", ctypes.c_void_p),
+    ]
+
+
+class GlCircuitDesc(ctypes.Structure):
+    _fields_ = [
+        ("degree_bits", ctypes.c_uint32),
+        ("num_wires", ctypes.c_uint32),
+        ("num_routed_wires", ctypes.c_uint32),
+        ("num_constants", ctypes.c_uint32),
+        ("num_challenges", ctypes.c_uint32),
+        ("quotient_degree_factor", ctypes.c_uint32),
+        ("num_gate_constraints", ctypes.c_uint32),
+        ("fri", GlFriParams),
+        ("h_k_is", ctypes.c_void_p),
+        ("h_constants", ctypes.c_void_p),
+        ("h_sigmas", ctypes.c_void_p),
+        ("h_instrs", ctypes.c_void_p),
+        ("num_instrs", ctypes.c_uint32),
+        ("h_gates", ctypes.c_void_p),
+        ("num_gates", ctypes.c_uint32),
+        ("h_immediates", ctypes.c_void_p),
+        ("num_immediates", ctypes.c_uint32),
+        ("num_selectors", ctypes.c_uint32),
+        ("compile_gates", ctypes.c_int),
+        ("h_circuit_digest", ctypes.c_void_p),
+    ]
+
+
+GL_PROVE_STAGES = 11
+PROVE_STAGE_NAMES = ["wires commitment", "partial products", "zs partial products commitment", "quotient polys", "quotient commitment",
+                     "opening set", "fri: combine + divide", "fri: commit phase", "fri: proof of work", "fri: query rounds", "serialise"]
+
+
 class Plonky2HipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"plonky2_hip error {code}: {message}")
@@ -94,6 +135,11 @@ SIGNATURES = {
     "gl_gate_kernel_build": (GlError, [_vp, _u32, _vp, _u32, _vp, _u32, _u32, _u32, _u32, ctypes.POINTER(_vp)]),
     "gl_gate_kernel_destroy": (None, [_vp]),
     "gl_gate_kernel_source": (ctypes.c_char_p, [_vp]),
+    "gl_circuit_create": (GlError, [ctypes.POINTER(GlCircuitDesc), ctypes.POINTER(_vp), _vp]),
+    "gl_circuit_destroy": (None, [_vp]),
+    "gl_circuit_info": (GlError, [_vp, _vp, _vp]),
+    "gl_prove": (GlError, [_vp, _vp, _vp, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
+    "gl_bytes_free": (None, [_vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
     "gl_eval_polys_ext2": (GlError, [_vp, _u64, _u32, _u64, _vp, _u32, _vp, _vp]),
     "gl_fri_reduce_polys_base": (GlError, [_vp, _u32, _u64, _vp, _vp, _vp]),

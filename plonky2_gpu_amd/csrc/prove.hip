@@ -1,0 +1,583 @@
+// prove.hip — the prover's HOST logic in native code: gl_circuit_create / gl_prove.
+//
+// prove() (plonky2/src/plonk/prover.rs:40-233) from the full witness on, with PolynomialBatch::prove_openings
+// (plonky2/src/fri/oracle.rs:1047-1112), fri_proof (plonky2/src/fri/prover.rs:24-260), the Challenger
+// (plonky2/src/iop/challenger.rs) and the proof wire format (plonky2/src/util/serialization.rs:466-700).
+// Everything data-parallel is a kernel behind the gl_* entry points of this library; what lives here is
+// the serial glue a Rust host would otherwise write against those entry points — the transcript's
+// buffers, challenge arithmetic on single field elements, buffer management, serialisation — so that a
+// host in any language needs exactly two calls. No polynomial, LDE, tree or witness column is touched
+// by the CPU; the transcript's permutations run on the device (gl_sponge_absorb).
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plonky2_hip.h"
+#include "gl_field.cuh"
+
+namespace {
+
+using glh::P;
+
+#define TRY(expr)                  \
+    do {                           \
+        GlError _e = (expr);       \
+        if (_e.code != 0) return _e; \
+    } while (0)
+
+GlError ok() { return GlError{0, nullptr}; }
+GlError fail(const std::string &m) { return GlError{GL_E_INVALID, strdup(m.c_str())}; }
+
+struct E2 {  // a + bX, X^2 = 7 (field/src/goldilocks_extensions.rs:13-26)
+    uint64_t a, b;
+};
+E2 e2_mul(E2 x, E2 y) {
+    return E2{glh::add(glh::mul(x.a, y.a), glh::mul(7, glh::mul(x.b, y.b))), glh::add(glh::mul(x.a, y.b), glh::mul(x.b, y.a))};
+}
+E2 e2_pow(E2 x, uint64_t e) {
+    E2 acc{1, 0};
+    while (e) {
+        if (e & 1) acc = e2_mul(acc, x);
+        x = e2_mul(x, x);
+        e >>= 1;
+    }
+    return acc;
+}
+
+struct DevBuf {  // RAII device buffer of u64
+    uint64_t *p = nullptr;
+    uint64_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        reset();
+        p = o.p, n = o.n, o.p = nullptr;
+        return *this;
+    }
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) (void)gl_free(p);
+        p = nullptr;
+    }
+    GlError alloc(uint64_t elems) {
+        reset();
+        n = elems;
+        void *q = nullptr;
+        TRY(gl_malloc(&q, (elems ? elems : 1) * 8));
+        p = static_cast<uint64_t *>(q);
+        return ok();
+    }
+};
+
+// A committed batch resident in HBM (PolynomialBatch, fri/oracle.rs:112-120), without a leaf-major copy.
+struct Batch {
+    DevBuf coeffs, lde, digests, cap_d;
+    uint32_t n_polys = 0;
+    std::vector<uint64_t> cap;  // host copy, 4 << cap_height
+};
+
+// ---- transcript ----------------------------------------------------------------------------------
+struct Challenger {  // iop/challenger.rs:19-149, overwrite-mode duplex sponge over Poseidon
+    uint64_t state[12] = {0};
+    std::vector<uint64_t> in, out;
+    void *ctx;
+    explicit Challenger(void *c) : ctx(c) {}
+
+    GlError observe(const uint64_t *es, size_t n) {  // observe_element for each (challenger.rs:43-59)
+        if (!n) return ok();
+        std::vector<uint64_t> buf(in);
+        for (size_t i = 0; i < n; i++) buf.push_back(es[i] % P);
+        const size_t full = buf.size() / 8 * 8;
+        out.clear();
+        if (full) {
+            // all full rate blocks in one device call; only the last duplexing's output can be read
+            TRY(gl_sponge_absorb(state, buf.data(), (uint32_t)(full / 8), ctx));
+            if (full == buf.size()) out.assign(state, state + 8);
+        }
+        in.assign(buf.begin() + full, buf.end());
+        return ok();
+    }
+    GlError observe(const std::vector<uint64_t> &v) { return observe(v.data(), v.size()); }
+    GlError duplexing() {  // challenger.rs:131-149
+        for (size_t i = 0; i < in.size(); i++) state[i] = in[i];
+        in.clear();
+        uint64_t block[8];
+        memcpy(block, state, sizeof block);
+        TRY(gl_sponge_absorb(state, block, 1, ctx));
+        out.assign(state, state + 8);
+        return ok();
+    }
+    GlError challenge(uint64_t *c) {  // challenger.rs:87-97
+        if (!in.empty() || out.empty()) TRY(duplexing());
+        *c = out.back();
+        out.pop_back();
+        return ok();
+    }
+    GlError challenges(uint32_t n, std::vector<uint64_t> *v) {
+        v->resize(n);
+        for (uint32_t i = 0; i < n; i++) TRY(challenge(&(*v)[i]));
+        return ok();
+    }
+    GlError ext_challenge(E2 *e) {
+        TRY(challenge(&e->a));
+        return challenge(&e->b);
+    }
+};
+
+GlError hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4], void *ctx) {  // hash/hashing.rs:81-108
+    uint64_t st[12] = {0};
+    std::vector<uint64_t> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = in[i] % P;
+    const size_t full = n / 8 * 8;
+    if (full) TRY(gl_sponge_absorb(st, v.data(), (uint32_t)(full / 8), ctx));
+    if (full < n) {  // a short last chunk leaves the old lanes in place
+        for (size_t i = full; i < n; i++) st[i - full] = v[i];
+        uint64_t block[8];
+        memcpy(block, st, sizeof block);
+        TRY(gl_sponge_absorb(st, block, 1, ctx));
+    }
+    memcpy(out, st, 32);
+    return ok();
+}
+
+// ---- the circuit object ---------------------------------------------------------------------------
+struct Circuit {
+    uint32_t degree_bits, num_wires, num_routed, num_constants, num_challenges, qdf, num_gate_constraints;
+    uint32_t rate_bits, cap_height, pow_bits, num_queries;
+    std::vector<uint32_t> arity_bits;
+    uint64_t digest[4];
+    DevBuf k_is, sigmas;
+    Batch cs;  // constants_sigmas_commitment
+    // gates
+    DevBuf d_instrs, d_gates, d_imms;
+    uint32_t num_gates = 0, num_selectors = 0;
+    void *gate_kernel = nullptr;
+    ~Circuit() {
+        if (gate_kernel) gl_gate_kernel_destroy(gate_kernel);
+    }
+};
+
+uint32_t num_partial_products(uint32_t routed, uint32_t qdf) { return (routed + qdf - 1) / qdf - 1; }
+
+GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx) {
+    const uint64_t n_ext = 1ull << (c.degree_bits + c.rate_bits);
+    b->coeffs = std::move(polys);
+    b->n_polys = n_polys;
+    TRY(b->lde.alloc((uint64_t)n_polys * n_ext));
+    TRY(b->digests.alloc(8 * (n_ext - (1ull << c.cap_height))));
+    TRY(b->cap_d.alloc(4ull << c.cap_height));
+    if (from_values)
+        TRY(gl_commit_from_values(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, 0, 7, b->lde.p, nullptr, b->digests.p,
+                                  b->cap_d.p, ctx));
+    else
+        TRY(gl_commit_from_coeffs(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, 0, 7, b->lde.p, nullptr, b->digests.p,
+                                  b->cap_d.p, ctx));
+    b->cap.resize(4ull << c.cap_height);
+    return gl_memcpy_d2h(b->cap.data(), b->cap_d.p, b->cap.size() * 8, ctx);
+}
+
+struct Bytes {  // util/serialization.rs:466-560
+    std::vector<uint8_t> v;
+    void u8(uint8_t x) { v.push_back(x); }
+    void field(uint64_t x) {
+        x %= P;
+        for (int i = 0; i < 8; i++) v.push_back((uint8_t)(x >> (8 * i)));
+    }
+    void fields(const uint64_t *p, size_t n) {
+        for (size_t i = 0; i < n; i++) field(p[i]);
+    }
+    void fields(const std::vector<uint64_t> &a) { fields(a.data(), a.size()); }
+    void merkle_proof(const uint64_t *sib, uint32_t layers) {  // :573-589
+        u8((uint8_t)layers);
+        fields(sib, 4ull * layers);
+    }
+};
+
+struct Stages {
+    double *ms;
+    void *ctx;
+    std::chrono::steady_clock::time_point t;
+    Stages(double *m, void *c) : ms(m), ctx(c), t(std::chrono::steady_clock::now()) {}
+    GlError mark(int i) {
+        if (!ms) return ok();
+        TRY(gl_ctx_synchronize(ctx));
+        auto now = std::chrono::steady_clock::now();
+        ms[i] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+        return ok();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+GlError gl_circuit_create(const GlCircuitDesc *d, void **circuit, void *ctx) {
+    if (!d || !circuit || !ctx || !d->h_k_is || !d->h_constants || !d->h_sigmas || (d->fri.num_reductions && !d->fri.reduction_arity_bits))
+        return fail("null pointer");
+    if (d->degree_bits > 24 || d->num_challenges == 0 || d->num_challenges > 4 || d->num_routed_wires > d->num_wires ||
+        d->quotient_degree_factor < 2 || d->quotient_degree_factor >= d->num_routed_wires)
+        return fail("bad circuit shape (the prover needs quotient_degree_factor < num_routed_wires, prover.rs:99-102)");
+    Circuit *c = new Circuit();
+    c->degree_bits = d->degree_bits, c->num_wires = d->num_wires, c->num_routed = d->num_routed_wires;
+    c->num_constants = d->num_constants, c->num_challenges = d->num_challenges, c->qdf = d->quotient_degree_factor;
+    c->num_gate_constraints = d->num_gate_constraints;
+    c->rate_bits = d->fri.rate_bits, c->cap_height = d->fri.cap_height, c->pow_bits = d->fri.proof_of_work_bits;
+    c->num_queries = d->fri.num_query_rounds;
+    c->arity_bits.assign(d->fri.reduction_arity_bits, d->fri.reduction_arity_bits + d->fri.num_reductions);
+    const uint64_t n = 1ull << c->degree_bits;
+    auto bail = [&](GlError e) {
+        delete c;
+        return e;
+    };
+#define CTRY(expr)                         \
+    do {                                   \
+        GlError _e = (expr);               \
+        if (_e.code != 0) return bail(_e); \
+    } while (0)
+    CTRY(c->k_is.alloc(c->num_routed));
+    CTRY(gl_memcpy_h2d(c->k_is.p, d->h_k_is, 8ull * c->num_routed, ctx));
+    CTRY(c->sigmas.alloc((uint64_t)c->num_routed * n));
+    CTRY(gl_memcpy_h2d(c->sigmas.p, d->h_sigmas, 8ull * c->num_routed * n, ctx));
+    // constants_sigmas_commitment (circuit_builder.rs:861-873): constants then sigmas, from values
+    DevBuf csv;
+    CTRY(csv.alloc((uint64_t)(c->num_constants + c->num_routed) * n));
+    CTRY(gl_memcpy_h2d(csv.p, d->h_constants, 8ull * c->num_constants * n, ctx));
+    CTRY(gl_memcpy_h2d(csv.p + (uint64_t)c->num_constants * n, d->h_sigmas, 8ull * c->num_routed * n, ctx));
+    CTRY(commit(&c->cs, std::move(csv), true, c->num_constants + c->num_routed, *c, ctx));
+    if (d->h_circuit_digest) {
+        memcpy(c->digest, d->h_circuit_digest, 32);
+    } else {
+        // circuit_builder.rs:915-927: hash_no_pad(cap || hash_pad(domain separator = []) || degree_bits)
+        uint64_t pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, dsd[4];
+        CTRY(hash_no_pad(pad, 12, dsd, ctx));
+        std::vector<uint64_t> parts(c->cs.cap);
+        parts.insert(parts.end(), dsd, dsd + 4);
+        parts.push_back(c->degree_bits);
+        CTRY(hash_no_pad(parts.data(), parts.size(), c->digest, ctx));
+    }
+    if (d->num_gates) {
+        if (!d->h_instrs || !d->h_gates) return bail(fail("null gate program"));
+        c->num_gates = d->num_gates, c->num_selectors = d->num_selectors;
+        if (d->compile_gates) {
+            CTRY(gl_gate_kernel_build(d->h_instrs, d->num_instrs, d->h_gates, d->num_gates, d->h_immediates, d->num_immediates,
+                                      d->num_selectors, d->num_gate_constraints, d->num_challenges, &c->gate_kernel));
+        } else {
+            CTRY(c->d_instrs.alloc(d->num_instrs ? d->num_instrs : 1));  // 8 bytes per GlGateInstr
+            CTRY(gl_memcpy_h2d(c->d_instrs.p, d->h_instrs, 8ull * d->num_instrs, ctx));
+            CTRY(c->d_gates.alloc(3ull * d->num_gates));  // 24 bytes per GlGateDesc
+            CTRY(gl_memcpy_h2d(c->d_gates.p, d->h_gates, 24ull * d->num_gates, ctx));
+            if (d->num_immediates) {
+                CTRY(c->d_imms.alloc(d->num_immediates));
+                CTRY(gl_memcpy_h2d(c->d_imms.p, d->h_immediates, 8ull * d->num_immediates, ctx));
+            }
+        }
+    }
+    CTRY(gl_ctx_synchronize(ctx));
+#undef CTRY
+    *circuit = c;
+    return ok();
+}
+
+void gl_circuit_destroy(void *circuit) { delete static_cast<Circuit *>(circuit); }
+
+GlError gl_circuit_info(const void *circuit, uint64_t h_digest[4], uint64_t *h_constants_sigmas_cap) {
+    if (!circuit) return fail("null pointer");
+    const Circuit *c = static_cast<const Circuit *>(circuit);
+    if (h_digest) memcpy(h_digest, c->digest, 32);
+    if (h_constants_sigmas_cap) memcpy(h_constants_sigmas_cap, c->cs.cap.data(), c->cs.cap.size() * 8);
+    return ok();
+}
+
+void gl_bytes_free(uint8_t *p) { free(p); }
+
+GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                 uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
+    if (!circuit || !d_wires || !proof || !proof_len || !ctx || (num_public_inputs && !h_public_inputs)) return fail("null pointer");
+    const Circuit &c = *static_cast<const Circuit *>(circuit);
+    const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf;
+    const uint64_t n = 1ull << db, n_ext = n << c.rate_bits;
+    const uint32_t npp = num_partial_products(c.num_routed, qdf);
+    if (h_stage_ms) memset(h_stage_ms, 0, sizeof(double) * GL_PROVE_STAGES);
+    Stages st(h_stage_ms, ctx);
+
+    uint64_t pih[4];
+    TRY(hash_no_pad(h_public_inputs, num_public_inputs, pih, ctx));  // prover.rs:52
+    // wires commitment (prover.rs:66-90); the caller's witness stays intact for the partial products
+    Batch wires;
+    {
+        DevBuf w;
+        TRY(w.alloc((uint64_t)c.num_wires * n));
+        TRY(gl_memcpy_d2d(w.p, d_wires, 8ull * c.num_wires * n, ctx));
+        TRY(commit(&wires, std::move(w), true, c.num_wires, c, ctx));
+    }
+    TRY(st.mark(0));
+    Challenger ch(ctx);
+    TRY(ch.observe(c.digest, 4));
+    TRY(ch.observe(pih, 4));
+    TRY(ch.observe(wires.cap));
+    std::vector<uint64_t> betas, gammas, alphas;
+    TRY(ch.challenges(nch, &betas));
+    TRY(ch.challenges(nch, &gammas));
+    // partial products and Z (prover.rs:99-117), committed in place
+    Batch zs;
+    {
+        DevBuf z;
+        TRY(z.alloc((uint64_t)nch * (1 + npp) * n));
+        TRY(gl_permutation_partial_products(d_wires, n, c.sigmas.p, n, c.k_is.p, betas.data(), gammas.data(), nch, c.num_routed, qdf, db, z.p,
+                                            ctx));
+        TRY(st.mark(1));
+        TRY(commit(&zs, std::move(z), true, nch * (1 + npp), c, ctx));
+    }
+    TRY(st.mark(2));
+    TRY(ch.observe(zs.cap));
+    TRY(ch.challenges(nch, &alphas));
+    // quotient polynomials (prover.rs:137-151)
+    uint32_t qdb = 0;
+    while ((1u << qdb) < qdf) qdb++;
+    DevBuf quotient, work;
+    TRY(quotient.alloc((uint64_t)nch << (db + qdb)));
+    {
+        GlQuotientArgs a;
+        memset(&a, 0, sizeof a);
+        a.d_wires_leaves = wires.lde.p, a.d_constants_sigmas_leaves = c.cs.lde.p, a.d_zs_partial_products_leaves = zs.lde.p;
+        a.wires_leaf_len = c.num_wires, a.constants_sigmas_leaf_len = c.num_constants + c.num_routed;
+        a.zs_partial_products_leaf_len = nch * (1 + npp);
+        a.d_k_is = c.k_is.p;
+        a.h_betas = betas.data(), a.h_gammas = gammas.data(), a.h_alphas = alphas.data();
+        a.num_constants = c.num_constants, a.num_routed_wires = c.num_routed, a.num_challenges = nch;
+        a.num_gate_constraints = c.num_gates ? c.num_gate_constraints : 0;
+        a.degree_bits = db, a.rate_bits = c.rate_bits, a.quotient_degree_factor = qdf, a.coset_shift = 7;
+        a.column_stride = n_ext;
+        GlGateProgram gp;
+        memset(&gp, 0, sizeof gp);
+        if (c.gate_kernel) {
+            TRY(work.alloc((uint64_t)nch << (db + qdb)));
+            a.gate_kernel = c.gate_kernel, a.h_public_inputs_hash = pih, a.d_gate_workspace = work.p;
+        } else if (c.num_gates) {
+            gp.d_instrs = reinterpret_cast<const GlGateInstr *>(c.d_instrs.p);
+            gp.d_gates = reinterpret_cast<const GlGateDesc *>(c.d_gates.p);
+            gp.d_immediates = c.d_imms.p;
+            gp.num_gates = c.num_gates, gp.num_selectors = c.num_selectors;
+            memcpy(gp.public_inputs_hash, pih, 32);
+            a.gate_program = &gp;
+        }
+        TRY(gl_compute_quotient_polys(&a, quotient.p, ctx));
+    }
+    TRY(st.mark(3));
+    // split into degree-n chunks (prover.rs:153-166) and commit from coefficients
+    Batch quot;
+    {
+        DevBuf chunks;
+        if (qdf == (1u << qdb)) {
+            chunks = std::move(quotient);  // [nch][n << qdb] read flat is [nch * qdf][n]
+        } else {
+            TRY(chunks.alloc((uint64_t)nch * qdf * n));
+            std::vector<uint64_t> tail((n << qdb) - (uint64_t)qdf * n);
+            for (uint32_t k = 0; k < nch; k++) {
+                TRY(gl_memcpy_d2h(tail.data(), quotient.p + ((uint64_t)k << (db + qdb)) + (uint64_t)qdf * n, tail.size() * 8, ctx));
+                for (uint64_t t : tail)
+                    if (t) return fail("Quotient has failed, the vanishing polynomial is not divisible by Z_H");
+                TRY(gl_memcpy_d2d(chunks.p + (uint64_t)k * qdf * n, quotient.p + ((uint64_t)k << (db + qdb)), 8ull * qdf * n, ctx));
+            }
+        }
+        TRY(commit(&quot, std::move(chunks), false, nch * qdf, c, ctx));
+    }
+    TRY(st.mark(4));
+    TRY(ch.observe(quot.cap));
+    E2 zeta;
+    TRY(ch.ext_challenge(&zeta));
+    if (E2 zn = e2_pow(zeta, n); zn.a == 1 && zn.b == 0) return fail("Opening point is in the subgroup.");
+    const uint64_t g = glh::root_of_unity(db);
+    const E2 g_zeta = e2_mul(E2{g, 0}, zeta);
+    // OpeningSet::new (plonk/proof.rs:305-334)
+    const Batch *oracles[4] = {&c.cs, &wires, &zs, &quot};
+    std::vector<uint64_t> ev[4], zs_next;
+    {
+        DevBuf out;
+        const uint64_t pts[4] = {zeta.a, zeta.b, g_zeta.a, g_zeta.b};
+        for (int o = 0; o < 4; o++) {
+            const uint32_t np = o == 2 ? 2 : 1;
+            TRY(out.alloc(2ull * np * oracles[o]->n_polys));
+            TRY(gl_eval_polys_ext2(oracles[o]->coeffs.p, oracles[o]->n_polys, db, n, pts, np, out.p, ctx));
+            std::vector<uint64_t> h(2ull * np * oracles[o]->n_polys);
+            TRY(gl_memcpy_d2h(h.data(), out.p, h.size() * 8, ctx));
+            ev[o].assign(h.begin(), h.begin() + 2ull * oracles[o]->n_polys);
+            if (o == 2) zs_next.assign(h.begin() + 2ull * oracles[o]->n_polys, h.begin() + 2ull * oracles[o]->n_polys + 2ull * nch);
+        }
+    }
+    TRY(st.mark(5));
+    // to_fri_openings (proof.rs:336-356): [constants, sigmas, wires, zs, partial products, quotient], then zs_next
+    {
+        std::vector<uint64_t> batch0;
+        for (int o = 0; o < 4; o++) batch0.insert(batch0.end(), ev[o].begin(), ev[o].end());
+        TRY(ch.observe(batch0));
+        TRY(ch.observe(zs_next));
+    }
+
+    // ---- PolynomialBatch::prove_openings (fri/oracle.rs:1047-1112) ----
+    E2 alpha;
+    TRY(ch.ext_challenge(&alpha));
+    DevBuf final_poly;  // planar [2][n]
+    TRY(final_poly.alloc(2 * n));
+    {
+        // batch 0: every polynomial of the four oracles at zeta; batch 1: the Zs at g*zeta (circuit_data.rs:351-371)
+        std::vector<const uint64_t *> ptrs;
+        for (int o = 0; o < 4; o++)
+            for (uint32_t k = 0; k < oracles[o]->n_polys; k++) ptrs.push_back(oracles[o]->coeffs.p + (uint64_t)k * n);
+        const uint32_t m0 = (uint32_t)ptrs.size();
+        for (uint32_t k = 0; k < nch; k++) ptrs.push_back(zs.coeffs.p + (uint64_t)k * n);
+        DevBuf d_ptrs, comp;
+        TRY(d_ptrs.alloc(ptrs.size()));
+        TRY(gl_memcpy_h2d(d_ptrs.p, ptrs.data(), ptrs.size() * 8, ctx));
+        TRY(comp.alloc(2 * n));
+        const uint64_t al[2] = {alpha.a, alpha.b};
+        const struct {
+            uint32_t off, m;
+            E2 point;
+        } batches[2] = {{0, m0, zeta}, {m0, nch, g_zeta}};
+        for (int b = 0; b < 2; b++) {
+            TRY(gl_fri_reduce_polys_base(reinterpret_cast<const uint64_t *const *>(d_ptrs.p) + batches[b].off, batches[b].m, n, al, comp.p,
+                                         ctx));
+            const E2 sc = e2_pow(alpha, batches[b].m);  // alpha.shift_poly (util/reducing.rs:103-106)
+            const uint64_t pt[2] = {batches[b].point.a, batches[b].point.b}, scale[2] = {sc.a, sc.b};
+            TRY(gl_fri_divide_by_linear(comp.p, n, pt, scale, b != 0, final_poly.p, ctx));
+        }
+        TRY(gl_ctx_synchronize(ctx));  // d_ptrs / comp go out of scope
+    }
+    TRY(st.mark(6));
+    // ---- fri_committed_trees (fri/prover.rs:77-120) ----
+    struct Layer {
+        DevBuf rows, digests, cap_d;
+        std::vector<uint64_t> cap;
+        uint64_t n_leaves;
+        uint32_t leaf_len;
+    };
+    std::vector<Layer> layers(c.arity_bits.size());
+    std::vector<uint64_t> final_coeffs;
+    {
+        DevBuf coeffs = std::move(final_poly), vals;
+        uint64_t len = n, shift = 7;
+        auto lde = [&](DevBuf *dst) -> GlError {
+            uint32_t lg = 0;
+            while ((1ull << lg) < len) lg++;
+            TRY(dst->alloc(2 * (len << c.rate_bits)));
+            return gl_coset_lde_batch(coeffs.p, dst->p, 2, lg, c.rate_bits, shift, len, len << c.rate_bits, ctx);
+        };
+        if (!layers.empty()) TRY(lde(&vals));
+        for (size_t li = 0; li < layers.size(); li++) {
+            const uint32_t ab = c.arity_bits[li];
+            const uint64_t lde_len = len << c.rate_bits;
+            Layer &L = layers[li];
+            L.n_leaves = lde_len >> ab, L.leaf_len = 2u << ab;
+            if (L.n_leaves < (1ull << c.cap_height)) return fail("FRI layer smaller than the Merkle cap");
+            TRY(L.rows.alloc(2 * lde_len));
+            TRY(gl_ext2_interleave(vals.p, lde_len, L.rows.p, ctx));
+            TRY(L.digests.alloc(8 * (L.n_leaves - (1ull << c.cap_height)) + 4));
+            TRY(L.cap_d.alloc(4ull << c.cap_height));
+            TRY(gl_merkle_tree_from_leaves(L.rows.p, L.leaf_len, L.n_leaves, c.cap_height, L.digests.p, L.cap_d.p, ctx));
+            L.cap.resize(4ull << c.cap_height);
+            TRY(gl_memcpy_d2h(L.cap.data(), L.cap_d.p, L.cap.size() * 8, ctx));
+            TRY(ch.observe(L.cap));
+            E2 beta;
+            TRY(ch.ext_challenge(&beta));
+            DevBuf next;
+            TRY(next.alloc(2 * (len >> ab)));
+            const uint64_t be[2] = {beta.a, beta.b};
+            TRY(gl_fri_fold(coeffs.p, len, ab, be, next.p, ctx));
+            TRY(gl_ctx_synchronize(ctx));
+            coeffs = std::move(next);
+            len >>= ab;
+            shift = glh::pow(shift, 1ull << ab);
+            if (li + 1 < layers.size()) TRY(lde(&vals));
+        }
+        std::vector<uint64_t> planes(2 * len);
+        TRY(gl_memcpy_d2h(planes.data(), coeffs.p, planes.size() * 8, ctx));
+        final_coeffs.resize(2 * len);
+        for (uint64_t i = 0; i < len; i++) final_coeffs[2 * i] = planes[i], final_coeffs[2 * i + 1] = planes[len + i];
+        TRY(ch.observe(final_coeffs));
+    }
+    TRY(st.mark(7));
+    // ---- fri_proof_of_work (fri/prover.rs:122-171) ----
+    uint64_t pow_witness = 0;
+    {
+        const uint32_t min_lz = c.pow_bits + 0;  // F::order() has 64 bits: leading zeros of the u64 response
+        uint64_t s[12];
+        memcpy(s, ch.state, sizeof s);
+        for (size_t i = 0; i < ch.in.size(); i++) s[i] = ch.in[i];
+        TRY(gl_fri_proof_of_work(s, (uint32_t)ch.in.size(), min_lz, &pow_witness, ctx));
+        TRY(ch.observe(&pow_witness, 1));
+        uint64_t resp;
+        TRY(ch.challenge(&resp));
+        if (min_lz && (resp >> (64 - min_lz)) != 0) return fail("proof-of-work response does not have the required leading zeros");
+    }
+    TRY(st.mark(8));
+    // ---- fri_prover_query_rounds (fri/prover.rs:173-260) ----
+    std::vector<uint64_t> idx;
+    TRY(ch.challenges(c.num_queries, &idx));
+    for (auto &x : idx) x %= n_ext;
+    uint32_t lg_ext = db + c.rate_bits;
+    const uint32_t init_layers = lg_ext - c.cap_height;
+    std::vector<uint64_t> init_leaves[4], init_sib[4];
+    for (int o = 0; o < 4; o++) {
+        init_leaves[o].resize((uint64_t)c.num_queries * oracles[o]->n_polys);
+        init_sib[o].resize((uint64_t)c.num_queries * init_layers * 4 + 4);
+        TRY(gl_merkle_open_batch(oracles[o]->lde.p, 1, n_ext, oracles[o]->n_polys, n_ext, c.cap_height, oracles[o]->digests.p, idx.data(),
+                                 c.num_queries, init_leaves[o].data(), init_sib[o].data(), ctx));
+    }
+    std::vector<std::vector<uint64_t>> step_leaves(layers.size()), step_sib(layers.size());
+    std::vector<uint32_t> step_layers(layers.size());
+    {
+        std::vector<uint64_t> cur(idx);
+        for (size_t li = 0; li < layers.size(); li++) {
+            for (auto &x : cur) x >>= c.arity_bits[li];
+            uint32_t lg = 0;
+            while ((1ull << lg) < layers[li].n_leaves) lg++;
+            step_layers[li] = lg - c.cap_height;
+            step_leaves[li].resize((uint64_t)c.num_queries * layers[li].leaf_len);
+            step_sib[li].resize((uint64_t)c.num_queries * step_layers[li] * 4 + 4);
+            TRY(gl_merkle_open_batch(layers[li].rows.p, layers[li].leaf_len, 1, layers[li].leaf_len, layers[li].n_leaves, c.cap_height,
+                                     layers[li].digests.p, cur.data(), c.num_queries, step_leaves[li].data(), step_sib[li].data(), ctx));
+        }
+    }
+    TRY(st.mark(9));
+    // ---- write_proof_with_public_inputs (util/serialization.rs:641-689) ----
+    Bytes out;
+    out.fields(wires.cap);
+    out.fields(zs.cap);
+    out.fields(quot.cap);
+    // write_opening_set (:557-571): constants, sigmas, wires, zs, zs_next, partial products, quotient
+    out.fields(ev[0]);                                                       // constants then sigmas: contiguous
+    out.fields(ev[1]);                                                       // wires
+    out.fields(ev[2].data(), 2ull * nch);                                    // plonk_zs
+    out.fields(zs_next);                                                     // plonk_zs_next
+    out.fields(ev[2].data() + 2ull * nch, ev[2].size() - 2ull * nch);        // partial_products
+    out.fields(ev[3]);                                                       // quotient_polys
+    for (auto &L : layers) out.fields(L.cap);
+    for (uint32_t q = 0; q < c.num_queries; q++) {
+        for (int o = 0; o < 4; o++) {
+            out.fields(init_leaves[o].data() + (uint64_t)q * oracles[o]->n_polys, oracles[o]->n_polys);
+            out.merkle_proof(init_sib[o].data() + (uint64_t)q * init_layers * 4, init_layers);
+        }
+        for (size_t li = 0; li < layers.size(); li++) {
+            out.fields(step_leaves[li].data() + (uint64_t)q * layers[li].leaf_len, layers[li].leaf_len);
+            out.merkle_proof(step_sib[li].data() + (uint64_t)q * step_layers[li] * 4, step_layers[li]);
+        }
+    }
+    out.fields(final_coeffs);
+    out.field(pow_witness);
+    out.fields(h_public_inputs, num_public_inputs);
+    TRY(gl_ctx_synchronize(ctx));
+    uint8_t *buf = static_cast<uint8_t *>(malloc(out.v.size() ? out.v.size() : 1));
+    if (!buf) return fail("out of memory");
+    memcpy(buf, out.v.data(), out.v.size());
+    *proof = buf;
+    *proof_len = out.v.size();
+    return st.mark(10);
+}
+
+}  // extern "C"

@@ -244,3 +244,70 @@ def prove(ctx, cd, wires, public_inputs, timing=None):
     return dict(wires_cap=wires_c.merkle_tree.cap.tolist(), plonk_zs_partial_products_cap=zs_c.merkle_tree.cap.tolist(),
                 quotient_polys_cap=quot_c.merkle_tree.cap.tolist(), openings=openings, opening_proof=opening_proof,
                 public_inputs=[int(x) for x in public_inputs])
+
+
+class NativeCircuit:
+    """The circuit object of the library's own prover (gl_circuit_create): same input dict as
+    CircuitData, but the whole of prove() then runs inside one native call (gl_prove, csrc/prove.hip)."""
+
+    def __init__(self, ctx, circuit, compile_gates=True):
+        from . import gate_program as gp
+
+        self.ctx = ctx
+        self.circuit = circuit
+        pool = gp.ImmediatePool()
+        programs = [gp.build_gate(kind, param, pool) for kind, param in circuit["gates"]]
+        instrs, descs = gp.pack_program(programs, circuit["selector_indices"], circuit["groups"])
+        instrs, descs = np.ascontiguousarray(instrs), np.ascontiguousarray(descs)
+        imms = _host_u64(pool.values) if pool.values else None
+        fp = circuit["fri_params"]
+        arity = np.ascontiguousarray(fp["reduction_arity_bits"], dtype=np.uint32)
+        k_is, consts, sigmas = _host_u64(circuit["k_is"]), _host_u64(circuit["constants"]), _host_u64(circuit["sigmas"])
+        digest = _host_u64(circuit["circuit_digest"]) if circuit.get("circuit_digest") is not None else None
+        desc = _lib.GlCircuitDesc(
+            circuit["degree_bits"], circuit["num_wires"], circuit["num_routed_wires"], circuit["num_constants"], circuit["num_challenges"],
+            circuit["quotient_degree_factor"], circuit["num_gate_constraints"],
+            _lib.GlFriParams(fp["rate_bits"], fp["cap_height"], fp["proof_of_work_bits"], fp["num_query_rounds"], arity.size,
+                             arity.ctypes.data),
+            k_is.ctypes.data, consts.ctypes.data, sigmas.ctypes.data,
+            instrs.ctypes.data, instrs.size // 4, descs.ctypes.data, descs.size // 6,
+            imms.ctypes.data if imms is not None else None, 0 if imms is None else imms.size, len(circuit["groups"]),
+            1 if compile_gates else 0, digest.ctypes.data if digest is not None else None)
+        h = ctypes.c_void_p()
+        _lib.call("gl_circuit_create", ctypes.byref(desc), ctypes.byref(h), ctx.ptr)
+        self.ptr = h.value
+        dg = np.zeros(4, dtype=np.uint64)
+        cap = np.zeros(4 << fp["cap_height"], dtype=np.uint64)
+        _lib.call("gl_circuit_info", self.ptr, dg, cap)
+        self.circuit_digest = [int(x) for x in dg]
+        self.constants_sigmas_cap = cap.reshape(-1, 4).tolist()
+
+    def prove_bytes(self, wires, public_inputs, timing=None):
+        """gl_prove: the proof in the reference's wire format. `wires`: host [num_wires][n] or a DeviceBuffer."""
+        d_w = wires if isinstance(wires, DeviceBuffer) else DeviceBuffer.from_host(self.ctx, _host_u64(wires))
+        pis = _host_u64(public_inputs)
+        out, ln = ctypes.c_void_p(), ctypes.c_uint64()
+        ms = np.zeros(_lib.GL_PROVE_STAGES, dtype=np.float64) if timing is not None else None
+        _lib.call("gl_prove", self.ptr, d_w.ptr, pis, pis.size, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
+        data = ctypes.string_at(out.value, ln.value)
+        _lib.load().gl_bytes_free(out.value)
+        if timing is not None:
+            for name, v in zip(_lib.PROVE_STAGE_NAMES, ms):
+                timing[name] = timing.get(name, 0.0) + float(v)
+        return data
+
+    def prove(self, wires, public_inputs, timing=None):
+        from . import serialization
+
+        return serialization.proof_from_bytes(self.prove_bytes(wires, public_inputs, timing), self.circuit)
+
+    def close(self):
+        if self.ptr:
+            _lib.load().gl_circuit_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -60,3 +60,26 @@ def test_full_gate_list_circuit(gpu, compile_gates):
     if compile_gates:
         src = cd.gate_program.kernel_source()
         assert "gate_12" in src  # the Poseidon gate is gate 12 of this circuit
+
+
+@pytest.mark.parametrize("which,compile_gates", [("mini", True), ("mini2", False), ("full", True)])
+def test_native_prover_gl_prove(gpu, which, compile_gates):
+    """gl_circuit_create + gl_prove (csrc/prove.hip: the host logic in native code): the proof BYTES equal
+    the oracle's, for the mini circuits and for the circuit with the whole ed25519 gate list."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+    from plonk_instance import make_full_circuit
+
+    if which == "full":
+        circuit, wires, pis = make_full_circuit(4, seed=3)
+    else:
+        circuit, wires, pis = make_circuit(5 if which == "mini" else 4, seed=9, two_groups=which == "mini2", arity_bits=(2, 1))
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+    assert nc.circuit_digest == circuit["circuit_digest"]  # derived as circuit_builder.rs:915-927
+    assert nc.constants_sigmas_cap == circuit["constants_sigmas"]["cap"]
+    timing = {}
+    data = nc.prove_bytes(wires, pis, timing)
+    exp = prove_ref.prove(circuit, wires, pis)
+    assert data == serialize_ref.proof_bytes(exp)
+    assert prove_ref.verify(circuit, pg.serialization.proof_from_bytes(data, circuit))
+    assert timing["wires commitment"] > 0
