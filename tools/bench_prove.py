@@ -4,7 +4,8 @@ cap_height 4, FRI arities [4,4,4,4], 28 queries, 16 PoW bits) and check the proo
 verifier. The ed25519 circuit itself needs the Rust toolchain; the gate set here is
 Noop/Constant/PublicInput/Arithmetic{20}, so the gate-constraint part of the quotient stage is lighter
 than ed25519's 231-constraint gate list — every other stage runs at the real shape.
-usage: python tools/bench_prove.py [degree_bits=18] [num_wires=234] [reps=3] [verify=1]"""
+usage: python tools/bench_prove.py [degree_bits=18] [num_wires=234] [reps=3] [verify=1] [native=1]
+native=1 times gl_prove (the library's own C++ prover, csrc/prove.hip); native=0 the Python host mirror."""
 import json
 import os
 import sys
@@ -24,6 +25,7 @@ def main():
     num_wires = int(sys.argv[2]) if len(sys.argv) > 2 else 234
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     verify = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    native = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     ctx = pg.Context(0)
     t = time.perf_counter()
     circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=num_wires, num_routed=80, num_constants=8, seed=1)
@@ -38,21 +40,38 @@ def main():
     ctx.synchronize()
     build_s = time.perf_counter() - t
     d_wires = pg.DeviceBuffer.from_host(ctx, np.ascontiguousarray(wires))
-    runs = []
+    nc = pg.NativeCircuit(ctx, dict(circuit, circuit_digest=cd.circuit_digest)) if native else None
+    runs, untimed = [], []
     for r in range(reps + 1):
         timing = {}
         ctx.synchronize()
         t = time.perf_counter()
-        proof = pg.prove(ctx, cd, d_wires, pis, timing)
+        if native:
+            data = nc.prove_bytes(d_wires, pis, timing)
+        else:
+            proof = pg.prove(ctx, cd, d_wires, pis, timing)
         ctx.synchronize()
         timing["total"] = (time.perf_counter() - t) * 1e3
         if r:  # first run warms up (table builds, allocator)
             runs.append(timing)
+    for r in range(reps):  # without the per-stage synchronisations
+        ctx.synchronize()
+        t = time.perf_counter()
+        if native:
+            data = nc.prove_bytes(d_wires, pis)
+        else:
+            proof = pg.prove(ctx, cd, d_wires, pis)
+        ctx.synchronize()
+        untimed.append((time.perf_counter() - t) * 1e3)
+    if native:
+        proof = pg.serialization.proof_from_bytes(data, circuit)
     best = min(runs, key=lambda d: d["total"])
     out = dict(workload=f"prove() synthetic circuit n=2^{degree_bits} wires={num_wires} routed=80 preprocessed=88 gates=noop/const/pi/arith20",
                reps=reps, witness_gen_s=round(gen_s, 2), circuit_build_s=round(build_s, 2),
                best_ms={k: round(v, 3) for k, v in best.items()},
-               mean_total_ms=round(sum(d["total"] for d in runs) / len(runs), 3), pow_witness=proof["opening_proof"]["pow_witness"])
+               mean_total_ms=round(sum(d["total"] for d in runs) / len(runs), 3), best_ms_without_stage_syncs=round(min(untimed), 3),
+               prover="gl_prove (native)" if native else "python host mirror", proof_bytes=len(pg.serialization.proof_to_bytes(proof)),
+               pow_witness=proof["opening_proof"]["pow_witness"])
     if verify:
         from oracle import prove_ref
 
