@@ -401,6 +401,27 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
     return mul(x3, x4);
 }
 
+// al + ah*2^32 (mod p) for al, ah < 2^63 with ah < 2^43 — the two 64-bit column sums of an MDS row
+// (poseidon.cuh). The compiler's version of "fold into (lo64, hi32), then reduce96" is ~18 issue
+// slots of double-pumped 64-bit compares and adds; with the carry flags it is 7 single instructions:
+//   l = al + (ah << 32)  ->  l.hi = al.hi + ah.lo (carry c), h = ah.hi + c
+//   r = l + h*(2^32 - 1) as one v_mad_u64_u32, its carry-out adds 2^32 - 1 once more (cannot carry again).
+__device__ __forceinline__ uint64_t fold96(uint64_t al, uint64_t ah) {
+    uint32_t all = (uint32_t)al, alh = (uint32_t)(al >> 32), ahl = (uint32_t)ah, ahh = (uint32_t)(ah >> 32);
+    uint32_t rl, rh;
+    asm("v_mov_b32_e32 v116, %2\n\t"
+        "v_add_co_u32_e32 v117, vcc, %3, %4\n\t"
+        "v_addc_co_u32_e32 v118, vcc, 0, %5, vcc\n\t"                   // h
+        "v_mad_u64_u32 v[116:117], vcc, v118, -1, v[116:117]\n\t"      // l + h*(2^32-1)
+        "v_cndmask_b32_e64 v118, 0, -1, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, v116, v118\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
+        : "=&v"(rl), "=&v"(rh)
+        : "v"(all), "v"(alh), "v"(ahl), "v"(ahh)
+        : "vcc", "v116", "v117", "v118");
+    return pack64(rl, rh);
+}
+
 // ---- lazy dot products --------------------------------------------------------------------
 // sum_i a_i * b_i over Goldilocks with ONE reduction at the end (the reference does the same on
 // the CPU with a u160 accumulator, poseidon.rs:34-47, 400-413). A 64x64 product is four 32x32

@@ -41,10 +41,7 @@ __device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const uint64_t *__re
         }
         al += lo[r] * POSEIDON_MDS_DIAG[r];
         ah += hi[r] * POSEIDON_MDS_DIAG[r];
-        // value = al + ah*2^32  (< 2^75): fold into (lo64, hi32)
-        uint64_t l = al + (ah << 32);
-        uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[r] = gl::reduce96(l, h);
+        s[r] = gl::fold96(al, ah);  // al + ah*2^32 (< 2^75) mod p
     }
 }
 
