@@ -123,7 +123,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
         }
         o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::dot_finish(ga[c]));\n  return out;\n}\n";
     }
-    o << "extern \"C\" __global__ __launch_bounds__(128) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
+    o << "extern \"C\" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
          "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, uint64_t lde_size, uint64_t* __restrict__ out) {\n"
          "  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;\n  if (t >= lde_size) return;\n"
          "  const uint64_t* W = wires + t * wrs;\n  const uint64_t* C = cs + t * crs;\n"
