@@ -3,6 +3,7 @@ generated rows satisfy the constraints over the base field and the extension, co
 constraint counts match Gate::num_constraints, and the base and extension evaluators agree on
 base-field inputs."""
 import random
+import zlib
 
 import pytest
 
@@ -17,7 +18,8 @@ GATES = [("noop", None), ("constant", 2), ("public_input", None), ("arithmetic",
 
 @pytest.mark.parametrize("kind,param", GATES)
 def test_generated_rows_satisfy_constraints(kind, param):
-    rng = random.Random(hash((kind, str(param))) & 0xFFFF)
+    # zlib.crc32, not hash(): str hashes are randomised per process and the rows must be reproducible
+    rng = random.Random(zlib.crc32(f"{kind}{param}".encode()))
     for trial in range(3):
         consts = [rng.randrange(P) for _ in range(2)]
         pih = [rng.randrange(P) for _ in range(4)]
@@ -38,7 +40,9 @@ def test_generated_rows_satisfy_constraints(kind, param):
             bad = list(w)
             bad[j] = (bad[j] + 1 + rng.randrange(P - 1)) % P
             broken += any(c != 0 for c in g.constraints(kind, param, consts, bad, pih, g.Base))
-        floor = 1 if kind == "random_access" else 0.7 * len(sample)  # RandomAccess: the unselected list items are free
+        # legitimately free wires: RandomAccess's unselected list items; ComparisonGate's equality_dummy and
+        # intermediate values of equal chunks (all of them when the two inputs are equal)
+        floor = {"random_access": 1, "comparison": 0.25 * len(sample)}.get(kind, 0.7 * len(sample))
         assert broken >= floor, (kind, broken, len(sample))
 
 
