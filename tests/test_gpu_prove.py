@@ -83,3 +83,18 @@ def test_native_prover_gl_prove(gpu, which, compile_gates):
     assert data == serialize_ref.proof_bytes(exp)
     assert prove_ref.verify(circuit, pg.serialization.proof_from_bytes(data, circuit))
     assert timing["wires commitment"] > 0
+
+
+@pytest.mark.parametrize("qdf,two_groups", [(5, False), (6, False), (4, True)])
+def test_quotient_degree_factor_that_is_not_a_power_of_two(gpu, qdf, two_groups):
+    """The trimmed-and-copied chunk path (prover.rs:153-166) of both provers — the Python mirror and the
+    native gl_prove — against the oracle's proof bytes."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+
+    circuit, wires, pis = make_circuit(4, seed=20 + qdf, two_groups=two_groups, quotient_degree_factor=qdf)
+    exp = serialize_ref.proof_bytes(prove_ref.prove(circuit, wires, pis))
+    proof = pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)
+    assert pg.serialization.proof_to_bytes(proof) == exp
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    assert nc.prove_bytes(wires, pis) == exp

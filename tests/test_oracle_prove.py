@@ -81,3 +81,13 @@ def test_full_gate_list_prove_then_verify():
     bad[30] = [(v + 1) % P for v in bad[30]]
     with pytest.raises(AssertionError):
         prove_ref.verify(circuit, prove_ref.prove(circuit, bad, pis))
+
+
+@pytest.mark.parametrize("qdf,two_groups", [(5, False), (6, False), (7, True), (4, True)])
+def test_quotient_degree_factor_that_is_not_a_power_of_two(qdf, two_groups):
+    """prover.rs:153-166: the quotient is trimmed to quotient_degree_factor * n coefficients (the tail must
+    be zero for a satisfied circuit) and split into that many degree-n chunks."""
+    circuit, wires, pis = make_circuit(4, seed=20 + qdf, two_groups=two_groups, quotient_degree_factor=qdf)
+    proof = prove_ref.prove(circuit, wires, pis)
+    assert len(proof["openings"]["quotient_polys"]) == 2 * qdf
+    assert prove_ref.verify(circuit, proof)
