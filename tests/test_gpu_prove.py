@@ -98,3 +98,20 @@ def test_quotient_degree_factor_that_is_not_a_power_of_two(gpu, qdf, two_groups)
     assert pg.serialization.proof_to_bytes(proof) == exp
     nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
     assert nc.prove_bytes(wires, pis) == exp
+
+
+def test_unsatisfied_witness_fails_loudly_when_the_quotient_is_trimmed(gpu):
+    """prover.rs:161-165 `expect("Quotient has failed, the vanishing polynomial is not divisible by Z_H")`:
+    with quotient_degree_factor = 5 the 8n-coefficient quotient of a broken witness has a non-zero tail."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd._lib import Plonky2HipError
+
+    circuit, wires, pis = make_circuit(4, seed=25, quotient_degree_factor=5)
+    bad = [list(c) for c in wires]
+    bad[3] = [(v + 1) % prove_ref.P for v in bad[3]]
+    with pytest.raises(AssertionError, match="Quotient has failed"):
+        prove_ref.prove(circuit, bad, pis)
+    with pytest.raises(ValueError, match="Quotient has failed"):
+        pg.prove(gpu, pg.CircuitData(gpu, circuit), bad, pis)
+    with pytest.raises(Plonky2HipError, match="Quotient has failed"):
+        pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(bad, pis)
