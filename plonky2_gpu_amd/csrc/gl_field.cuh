@@ -32,8 +32,9 @@ static constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
 
 __device__ __forceinline__ uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
 
-// a + b for arbitrary representatives (goldilocks_field.rs:197-219).
-__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+// a + b for arbitrary representatives (goldilocks_field.rs:197-219): the portable statement of what
+// gl::add (carry-flag version, below) computes.
+__device__ __forceinline__ uint64_t add_generic(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
     uint64_t s1 = s + ((s < a) ? EPS : 0);
     return s1 + ((s1 < s) ? EPS : 0);
@@ -45,11 +46,49 @@ __device__ __forceinline__ uint64_t add_canonical(uint64_t a, uint64_t b) {
     return s + ((s < a) ? EPS : 0);
 }
 
-// a - b for arbitrary representatives (goldilocks_field.rs:234-256).
-__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+// a - b for arbitrary representatives (goldilocks_field.rs:234-256): the portable statement of gl::sub.
+__device__ __forceinline__ uint64_t sub_generic(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
     uint64_t d1 = d - ((a < b) ? EPS : 0);
     return d1 - ((d1 > d) ? EPS : 0);
+}
+
+// The same two operations on the carry flag: the compiler's lowering of the `s < a` tests above is ~14
+// issue slots of double-pumped 64-bit compares and adds; these are 8 single instructions each, with the
+// reference's double wrap correction (the second one is rare but non-canonical inputs can need it).
+// VCC-carried dependencies need no wait states on gfx950 (see mul below).
+__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t rl, rh, t;
+    asm("v_add_co_u32_e32 %0, vcc, %3, %5\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // overflow: 2^64 = 2^32 - 1
+        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // and once more (cannot overflow a third time)
+        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(rl), "=&v"(rh), "=&v"(t)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc");
+    return ((uint64_t)rh << 32) | rl;
+}
+
+__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t rl, rh, t;
+    asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // borrow: -2^64 = -(2^32 - 1)
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        : "=&v"(rl), "=&v"(rh), "=&v"(t)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc");
+    return ((uint64_t)rh << 32) | rl;
 }
 
 __device__ __forceinline__ uint64_t neg(uint64_t a) {
