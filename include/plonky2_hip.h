@@ -15,10 +15,15 @@
  *     values (< p), i.e. exactly what the reference yields after `to_canonical_u64`.
  *   - All `d_*` pointers are DEVICE pointers. The callee allocates nothing for data: the caller
  *     owns every buffer (as in the reference, plonky2/src/fri/oracle.rs:94-106). The library keeps,
- *     per device, a few hundred KiB of twiddle tables and one 128 MiB workspace for the
- *     natural-order transforms (created by gl_ctx_create()/init() or on first use). Because that
- *     workspace is shared, run at most one gl_ntt_batch / ifft per device at a time (the
- *     reference's callers are single-threaded and synchronous, oracle.rs:394-422).
+ *     per device, a few hundred KiB of twiddle tables and one 128 MiB workspace (created by
+ *     gl_ctx_create()/init() or on first use) that the natural-order transforms, the scans
+ *     (partial products, divide_by_linear), the opening partial sums, gl_sponge_absorb,
+ *     gl_merkle_open_batch and gl_fri_proof_of_work stage through. Because that workspace is
+ *     shared, drive each device from ONE host thread / context at a time (the reference's callers
+ *     are single-threaded and synchronous, oracle.rs:394-422); use one process per GPU for more.
+ *     Two entry points do allocate device memory themselves, because their job is to own a whole
+ *     computation: gl_circuit_create (the preprocessed commitment, freed by gl_circuit_destroy) and
+ *     gl_prove (every buffer of one proof, freed before it returns).
  *   - Errors are returned BY VALUE as {code, message}; code 0 = success; `message` is
  *     malloc'ed (strdup) and owned by the caller, who frees it with free() — the convention of
  *     cuda/src/lib.rs:21-35 / cuda/plonky2_gpu.cu:19-31.
