@@ -129,6 +129,23 @@ __device__ uint64_t pow2_case(uint64_t x, int k) {
     }
 }
 
+// A lazy-dot-product accumulator built from two test words, so that the parity tests can reach the
+// reduction's rare wrap corrections directly (random Poseidon states hit them with probability ~2^-32).
+//   mode 0: every field wide (a0 = x, a1 = y, a2 = ~x + (y << 13), small counters from the top bits)
+//   mode 1: a0 = x, the other five fields packed into y as small numbers:
+//           a1 = y[0:16), a2 = y[16:32), k0 = y[32:40), k1 = y[40:48), k2 = y[48:56)
+__device__ gl::DotAcc dotacc_from(int mode, uint64_t x, uint64_t y) {
+    gl::DotAcc d;
+    if (mode == 0) {
+        d.a0 = x, d.a1 = y, d.a2 = ~x + (y << 13);
+        d.k0 = (uint32_t)(y >> 59), d.k1 = (uint32_t)(x >> 58), d.k2 = (uint32_t)((x ^ y) & 7);
+    } else {
+        d.a0 = x, d.a1 = y & 0xFFFF, d.a2 = (y >> 16) & 0xFFFF;
+        d.k0 = (uint32_t)(y >> 32) & 0xFF, d.k1 = (uint32_t)(y >> 40) & 0xFF, d.k2 = (uint32_t)(y >> 48) & 0xFF;
+    }
+    return d;
+}
+
 __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -147,9 +164,13 @@ __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, ui
         case 10: r = gl::mul_c(x, y); break;
         case 11: r = gl::canon_c(x); break;
         case 12: { uint64_t lo, hi; gl::mul_wide(x, y, lo, hi); r = gl::reduce128_c(lo ^ y, hi ^ x) ; } break;
+        case 13: r = gl::dot_finish(dotacc_from(0, x, y)); break;
+        case 14: r = gl::dot_finish_generic(dotacc_from(0, x, y)); break;
+        case 15: r = gl::dot_finish(dotacc_from(1, x, y)); break;
+        case 16: r = gl::dot_finish_generic(dotacc_from(1, x, y)); break;
         default: r = x; break;
     }
-    out[i] = (op >= 8) ? r : gl::canon(r);  // canonical-domain ops must already be canonical
+    out[i] = (op >= 8 && op <= 12) ? r : gl::canon(r);  // canonical-domain ops must already be canonical
 }
 
 GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,

@@ -75,3 +75,41 @@ def test_canonical_domain_asm_primitives(gpu):
         lo, hi = (prod & M) ^ y, (prod >> 64) ^ x
         exp.append(((hi << 64) | lo) % P)
     assert run_op(gpu, 12, a, b) == exp
+
+
+def _dotacc(mode, x, y):
+    """the accumulator capi.hip's dotacc_from() builds from two test words"""
+    m64 = (1 << 64) - 1
+    if mode == 0:
+        return x, y, ((~x & m64) + ((y << 13) & m64)) & m64, y >> 59, x >> 58, (x ^ y) & 7
+    return x, y & 0xFFFF, (y >> 16) & 0xFFFF, (y >> 32) & 0xFF, (y >> 40) & 0xFF, (y >> 48) & 0xFF
+
+
+def _dot_value(a0, a1, a2, k0, k1, k2):
+    return (a0 + (a1 << 32) + (a2 << 64) + (k0 << 64) + (k1 << 96) + (k2 << 128)) % P
+
+
+def test_dot_finish_including_its_rare_wrap_corrections(gpu):
+    """gl::dot_finish (carry flags) and dot_finish_generic against big ints. Two of the three wrap
+    corrections fire with probability ~2^-32 on random accumulators, so they are forced here:
+      borrow of (w0,w1) - w3:  low words zero, a2 = 2^64-1 (mode 0: x = 0, y = 0)
+      borrow of r.hi - w4:     everything zero except k2 (mode 1: x = 0, y = k2 << 48)"""
+    ops = edge_operands()
+    rng = np.random.default_rng(3)
+    pairs = list(itertools.product(ops, ops))
+    pairs += [(int(u), int(v)) for u, v in rng.integers(0, 2**64, size=(20000, 2), dtype=np.uint64)]
+    forced = [(0, 0), (0, 5 << 48), (0, 255 << 48), (3, 1 << 48), (0, (200 << 40) | (7 << 48)), ((1 << 64) - 1, (255 << 32) | (255 << 48)),
+              (0, 0xFFFF | (0xFFFF << 16) | (255 << 32) | (255 << 40) | (255 << 48))]
+    pairs += forced
+    a = np.array([x for x, _ in pairs], dtype=np.uint64)
+    b = np.array([y for _, y in pairs], dtype=np.uint64)
+    for mode, op_asm, op_generic in ((0, 13, 14), (1, 15, 16)):
+        exp = [_dot_value(*_dotacc(mode, x, y)) for x, y in pairs]
+        assert run_op(gpu, op_generic, a, b) == exp
+        assert run_op(gpu, op_asm, a, b) == exp
+    # the crafted inputs do reach the rare paths (so the test keeps covering them)
+    a0, a1, a2, k0, k1, k2 = _dotacc(0, 0, 0)
+    w3 = (a2 >> 32) + k1
+    assert (a0 & 0xFFFFFFFF) + (((a0 >> 32) + (a1 & 0xFFFFFFFF)) << 32) < w3          # first correction
+    a0, a1, a2, k0, k1, k2 = _dotacc(1, 0, 5 << 48)
+    assert a0 == a1 == a2 == k0 == k1 == 0 and k2 == 5                                   # last correction: 0 - 5*2^32
