@@ -116,7 +116,7 @@ def make_circuit_instance(degree_bits=4, seed=1, two_groups=False, num_challenge
 
 
 def make_circuit(degree_bits=4, seed=1, two_groups=False, arity_bits=(2, 1), rate_bits=3, cap_height=1, pow_bits=3, num_queries=3,
-                 quotient_degree_factor=8):
+                 quotient_degree_factor=8, num_challenges=2):
     """The tiny circuit above as the dict oracle/prove_ref.py and plonky2_gpu_amd.prove() take
     (CommonCircuitData + ProverOnlyCircuitData of plonk/circuit_data.rs), plus its witness.
     quotient_degree_factor must be at least (filtered gate degree) - 1: 5 with one selector group
@@ -127,8 +127,8 @@ def make_circuit(degree_bits=4, seed=1, two_groups=False, arity_bits=(2, 1), rat
     public_inputs = [rng.randrange(P) for _ in range(3)]
     inst = make_circuit_instance(degree_bits, seed, two_groups, public_inputs=public_inputs)
     cs = prove_ref.commit_from_values(inst["constants"] + inst["sigmas"], rate_bits, cap_height)
-    circuit = dict(degree_bits=degree_bits, num_wires=12, num_routed_wires=12, num_constants=inst["num_constants"], num_challenges=2,
-                   quotient_degree_factor=quotient_degree_factor, k_is=inst["k_is"],
+    circuit = dict(degree_bits=degree_bits, num_wires=12, num_routed_wires=12, num_constants=inst["num_constants"],
+                   num_challenges=num_challenges, quotient_degree_factor=quotient_degree_factor, k_is=inst["k_is"],
                    gates=[("noop", None), ("constant", 2), ("public_input", None), ("arithmetic", 3)],
                    selector_indices=inst["selector_indices"], groups=inst["groups"], num_gate_constraints=4,
                    constants=inst["constants"], sigmas=inst["sigmas"],

@@ -115,3 +115,16 @@ def test_unsatisfied_witness_fails_loudly_when_the_quotient_is_trimmed(gpu):
         pg.prove(gpu, pg.CircuitData(gpu, circuit), bad, pis)
     with pytest.raises(Plonky2HipError, match="Quotient has failed"):
         pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(bad, pis)
+
+
+@pytest.mark.parametrize("num_challenges", [1, 3])
+def test_other_numbers_of_challenges(gpu, num_challenges):
+    """num_challenges is a loop bound in the partial-product / quotient / FRI code and a compile-time
+    constant of the run-time compiled gate kernels; both provers against the oracle's proof bytes."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+
+    circuit, wires, pis = make_circuit(4, seed=40 + num_challenges, num_challenges=num_challenges)
+    exp = serialize_ref.proof_bytes(prove_ref.prove(circuit, wires, pis))
+    assert pg.serialization.proof_to_bytes(pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)) == exp
+    assert pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(wires, pis) == exp

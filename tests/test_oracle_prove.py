@@ -91,3 +91,14 @@ def test_quotient_degree_factor_that_is_not_a_power_of_two(qdf, two_groups):
     proof = prove_ref.prove(circuit, wires, pis)
     assert len(proof["openings"]["quotient_polys"]) == 2 * qdf
     assert prove_ref.verify(circuit, proof)
+
+
+@pytest.mark.parametrize("num_challenges", [1, 3])
+def test_other_numbers_of_challenges(num_challenges):
+    """config.num_challenges sizes the Z / partial-product / quotient batches and the alpha reduction
+    (prover.rs:97-151); 2 is only the standard configuration's value."""
+    circuit, wires, pis = make_circuit(4, seed=40 + num_challenges, num_challenges=num_challenges)
+    proof = prove_ref.prove(circuit, wires, pis)
+    assert len(proof["openings"]["plonk_zs"]) == num_challenges
+    assert len(proof["openings"]["quotient_polys"]) == 8 * num_challenges
+    assert prove_ref.verify(circuit, proof)
