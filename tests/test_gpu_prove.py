@@ -128,3 +128,18 @@ def test_other_numbers_of_challenges(gpu, num_challenges):
     exp = serialize_ref.proof_bytes(prove_ref.prove(circuit, wires, pis))
     assert pg.serialization.proof_to_bytes(pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)) == exp
     assert pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(wires, pis) == exp
+
+
+@pytest.mark.parametrize("degree_bits,arity_bits", [(3, ()), (4, (1, 1, 1)), (6, (4,))])
+def test_native_prover_fri_shapes(gpu, degree_bits, arity_bits):
+    """gl_prove with no commit-phase layer at all (the final polynomial is the whole combined polynomial),
+    with three binary layers (4-element leaves: the `<= 4 elements are not hashed` rule of hash_or_noop),
+    and with one 16-ary layer."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+
+    circuit, wires, pis = make_circuit(degree_bits, seed=50 + degree_bits, arity_bits=arity_bits)
+    exp = prove_ref.prove(circuit, wires, pis)
+    assert len(exp["opening_proof"]["final_poly"]) == 1 << (degree_bits - sum(arity_bits))
+    data = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(wires, pis)
+    assert data == serialize_ref.proof_bytes(exp)
