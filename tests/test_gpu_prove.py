@@ -143,3 +143,31 @@ def test_native_prover_fri_shapes(gpu, degree_bits, arity_bits):
     assert len(exp["opening_proof"]["final_poly"]) == 1 << (degree_bits - sum(arity_bits))
     data = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None)).prove_bytes(wires, pis)
     assert data == serialize_ref.proof_bytes(exp)
+
+
+def test_a_2e14_row_proof_is_accepted_by_the_oracle_verifier(gpu):
+    """Size-independent property at a size the Python prover cannot reach: a 2^14-row, 135-wire circuit
+    (standard_recursion_config's shape: 80 routed wires, rate 8, cap height 4, arities [4, 4, 4], 28 queries,
+    16 proof-of-work bits; witness from tools/synth_circuit.py) proven by gl_prove; the oracle's verifier
+    recomputes every challenge from the proof bytes and checks vanishing(zeta) = Z_H(zeta) t(zeta), all
+    Merkle paths, the folding consistency and the final polynomial. A corrupted byte is rejected."""
+    import os
+    import sys
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd.challenger import hash_no_pad
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import synth_circuit
+
+    circuit, wires, pis = synth_circuit.make(14, num_wires=135, num_routed=80, num_constants=8, seed=5)
+    assert circuit["fri_params"]["reduction_arity_bits"] == [4, 4, 4]
+    synth_circuit.set_public_input_row(wires, hash_no_pad(gpu, pis))
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    data = nc.prove_bytes(wires, pis)
+    vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
+    assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
+    bad = bytearray(data)
+    bad[len(bad) // 3] ^= 1
+    with pytest.raises((AssertionError, ValueError)):
+        prove_ref.verify(vc, pg.serialization.proof_from_bytes(bytes(bad), circuit))
