@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,28 +48,67 @@ E2 e2_pow(E2 x, uint64_t e) {
     return acc;
 }
 
+// Device buffers of one circuit's proofs are recycled: every proof of a circuit allocates the same ~50
+// sizes, hipMalloc/hipFree of multi-GiB buffers cost milliseconds and hipFree synchronises the device.
+// Handing a buffer back while kernels that use it are still in flight is safe here because everything
+// gl_prove launches is ordered on ONE stream: the next user's kernels queue behind them.
+struct Pool {
+    std::mutex m;
+    std::multimap<uint64_t, uint64_t *> free_;  // bytes -> buffer
+    ~Pool() {
+        for (auto &kv : free_) (void)gl_free(kv.second);
+    }
+    uint64_t *get(uint64_t bytes) {
+        std::lock_guard<std::mutex> lock(m);
+        auto it = free_.find(bytes);
+        if (it == free_.end()) return nullptr;
+        uint64_t *p = it->second;
+        free_.erase(it);
+        return p;
+    }
+    void put(uint64_t bytes, uint64_t *p) {
+        std::lock_guard<std::mutex> lock(m);
+        free_.emplace(bytes, p);
+    }
+};
+thread_local Pool *g_pool = nullptr;  // installed by gl_prove for its duration; null = plain gl_malloc / gl_free
+struct PoolScope {
+    Pool *prev;
+    explicit PoolScope(Pool *p) : prev(g_pool) { g_pool = p; }
+    ~PoolScope() { g_pool = prev; }
+};
+
 struct DevBuf {  // RAII device buffer of u64
     uint64_t *p = nullptr;
-    uint64_t n = 0;
+    uint64_t n = 0, bytes = 0;
+    Pool *pool = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), bytes(o.bytes), pool(o.pool) { o.p = nullptr; }
     DevBuf &operator=(DevBuf &&o) noexcept {
         reset();
-        p = o.p, n = o.n, o.p = nullptr;
+        p = o.p, n = o.n, bytes = o.bytes, pool = o.pool, o.p = nullptr;
         return *this;
     }
     ~DevBuf() { reset(); }
     void reset() {
-        if (p) (void)gl_free(p);
+        if (p) {
+            if (pool)
+                pool->put(bytes, p);
+            else
+                (void)gl_free(p);
+        }
         p = nullptr;
     }
     GlError alloc(uint64_t elems) {
         reset();
         n = elems;
+        bytes = (elems ? elems : 1) * 8;
+        pool = g_pool;
+        if (pool && (p = pool->get(bytes))) return ok();
         void *q = nullptr;
-        TRY(gl_malloc(&q, (elems ? elems : 1) * 8));
+        TRY(gl_malloc(&q, bytes));
         p = static_cast<uint64_t *>(q);
         return ok();
     }
@@ -156,6 +197,7 @@ struct Circuit {
     DevBuf d_instrs, d_gates, d_imms;
     uint32_t num_gates = 0, num_selectors = 0;
     void *gate_kernel = nullptr;
+    mutable Pool pool;  // the working buffers of this circuit's proofs, recycled from proof to proof
     ~Circuit() {
         if (gate_kernel) gl_gate_kernel_destroy(gate_kernel);
     }
@@ -299,6 +341,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
                  uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
     if (!circuit || !d_wires || !proof || !proof_len || !ctx || (num_public_inputs && !h_public_inputs)) return fail("null pointer");
     const Circuit &c = *static_cast<const Circuit *>(circuit);
+    PoolScope pool_scope(&c.pool);  // every DevBuf below comes from / returns to the circuit's pool
     const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf;
     const uint64_t n = 1ull << db, n_ext = n << c.rate_bits;
     const uint32_t npp = num_partial_products(c.num_routed, qdf);
@@ -447,7 +490,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
             const uint64_t pt[2] = {batches[b].point.a, batches[b].point.b}, scale[2] = {sc.a, sc.b};
             TRY(gl_fri_divide_by_linear(comp.p, n, pt, scale, b != 0, final_poly.p, ctx));
         }
-        TRY(gl_ctx_synchronize(ctx));  // d_ptrs / comp go out of scope
+        // d_ptrs / comp return to the pool here while their kernels may still be queued: stream order
     }
     TRY(st.mark(6));
     // ---- fri_committed_trees (fri/prover.rs:77-120) ----
@@ -489,8 +532,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
             TRY(next.alloc(2 * (len >> ab)));
             const uint64_t be[2] = {beta.a, beta.b};
             TRY(gl_fri_fold(coeffs.p, len, ab, be, next.p, ctx));
-            TRY(gl_ctx_synchronize(ctx));
-            coeffs = std::move(next);
+            coeffs = std::move(next);  // the old coefficients return to the pool (stream order keeps them valid)
             len >>= ab;
             shift = glh::pow(shift, 1ull << ab);
             if (li + 1 < layers.size()) TRY(lde(&vals));
