@@ -314,6 +314,10 @@ typedef struct GlCircuitDesc {
 #define GL_PROVE_STAGES 11
 GlError gl_circuit_create(const GlCircuitDesc *desc, void **circuit, void *ctx);
 void gl_circuit_destroy(void *circuit);
+/* gl_prove recycles its working buffers from proof to proof of the same circuit (one proof's worth of
+ * HBM stays attached to the circuit: ~10 GB at n = 2^18 with 234 wires). gl_circuit_trim releases them
+ * without destroying the circuit; the next proof allocates again. Call it only between proofs. */
+GlError gl_circuit_trim(void *circuit);
 /* circuit digest (4) and constants_sigmas cap (4 << cap_height): what VerifierOnlyCircuitData holds */
 GlError gl_circuit_info(const void *circuit, uint64_t *h_digest, uint64_t *h_constants_sigmas_cap);
 GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,

@@ -137,6 +137,7 @@ SIGNATURES = {
     "gl_gate_kernel_source": (ctypes.c_char_p, [_vp]),
     "gl_circuit_create": (GlError, [ctypes.POINTER(GlCircuitDesc), ctypes.POINTER(_vp), _vp]),
     "gl_circuit_destroy": (None, [_vp]),
+    "gl_circuit_trim": (GlError, [_vp]),
     "gl_circuit_info": (GlError, [_vp, _vp, _vp]),
     "gl_prove": (GlError, [_vp, _vp, _vp, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
     "gl_bytes_free": (None, [_vp]),

@@ -327,6 +327,15 @@ GlError gl_circuit_create(const GlCircuitDesc *d, void **circuit, void *ctx) {
 
 void gl_circuit_destroy(void *circuit) { delete static_cast<Circuit *>(circuit); }
 
+GlError gl_circuit_trim(void *circuit) {
+    if (!circuit) return fail("null pointer");
+    Pool &pool = static_cast<Circuit *>(circuit)->pool;
+    std::lock_guard<std::mutex> lock(pool.m);
+    for (auto &kv : pool.free_) TRY(gl_free(kv.second));
+    pool.free_.clear();
+    return ok();
+}
+
 GlError gl_circuit_info(const void *circuit, uint64_t h_digest[4], uint64_t *h_constants_sigmas_cap) {
     if (!circuit) return fail("null pointer");
     const Circuit *c = static_cast<const Circuit *>(circuit);

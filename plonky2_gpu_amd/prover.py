@@ -301,6 +301,10 @@ class NativeCircuit:
 
         return serialization.proof_from_bytes(self.prove_bytes(wires, public_inputs, timing), self.circuit)
 
+    def trim(self):
+        """release the working buffers gl_prove keeps attached to the circuit between proofs"""
+        _lib.call("gl_circuit_trim", self.ptr)
+
     def close(self):
         if self.ptr:
             _lib.load().gl_circuit_destroy(self.ptr)

@@ -171,3 +171,18 @@ def test_a_2e14_row_proof_is_accepted_by_the_oracle_verifier(gpu):
     bad[len(bad) // 3] ^= 1
     with pytest.raises((AssertionError, ValueError)):
         prove_ref.verify(vc, pg.serialization.proof_from_bytes(bytes(bad), circuit))
+
+
+def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
+    """gl_prove keeps one proof's working buffers attached to the circuit; proofs are deterministic across
+    the recycled buffers (nothing depends on stale contents) and across gl_circuit_trim."""
+    import plonky2_gpu_amd as pg
+
+    circuit, wires, pis = make_circuit(5, seed=61, two_groups=True)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    first = nc.prove_bytes(wires, pis)
+    assert nc.prove_bytes(wires, pis) == first  # second proof runs entirely on recycled buffers
+    # different public inputs change the transcript from the start: the buffers really are rewritten
+    assert nc.prove_bytes(wires, [(x + 1) % prove_ref.P for x in pis]) != first
+    nc.trim()
+    assert nc.prove_bytes(wires, pis) == first
