@@ -61,20 +61,23 @@ def cpu_baseline(log_n):
     """The oracle's threaded fft/ifft (port of fft.rs:73-229) on a bounded sample."""
     from oracle import oracle as o
 
-    cores = o.hardware_threads()
-    cols = max(4, min(32, cores))
+    hw = o.hardware_threads()
+    # one column per thread (the reference's rayon split is one task per column, oracle.rs:720), two
+    # columns per thread on small hosts so that the sample is not a single cold pass; 8 MiB per column
+    cols = max(4, min(hw, 256)) if hw >= 16 else 2 * max(2, hw)
+    threads = min(hw, cols)  # = the threads that actually have work
     x = o.random_field((cols, 1 << log_n), seed=7)
     t0 = time.perf_counter()
-    f = o.fft_batch(x, inverse=False, threads=cores)
-    o.fft_batch(f, inverse=True, threads=cores)
+    f = o.fft_batch(x, inverse=False, threads=threads)
+    o.fft_batch(f, inverse=True, threads=threads)
     dt = time.perf_counter() - t0
     return {
         "value": 2 * cols / dt,
         "unit": "NTT/s",
-        "cores": cores,
+        "cores": threads,
         "kind": "port",
-        "sample": f"{cols} columns x 2^{log_n}: forward + inverse NTT ({2 * cols} transforms) in {dt:.2f} s, "
-                  f"C restatement of fft_classic, one OpenMP task per column",
+        "sample": f"{cols} columns x 2^{log_n}: forward + inverse NTT ({2 * cols} transforms) in {dt:.2f} s on {threads} of "
+                  f"{hw} hardware threads, C restatement of fft_classic, one OpenMP task per column",
     }
 
 
