@@ -210,7 +210,8 @@ def main():
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
             },
-            "cpu_baseline": None if args.no_cpu else cpu_baseline(log_n),
+            # rank 0 at N = 1 only: at N > 1 the host cores belong to the other ranks' transcripts
+            "cpu_baseline": None if (args.no_cpu or dist.world > 1) else cpu_baseline(log_n),
             "extra": extra,
         }
         print(json.dumps(out))
