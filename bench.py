@@ -5,8 +5,9 @@ Metric (BASELINE.json): NTTs/sec at 2^20 Goldilocks.
 Workload at N=1 (BASELINE.json configs[1]): a batch of 64 independent 2^20-point columns
 (512 MiB, resident in HBM before the timed region), one step = forward NTT of the batch followed
 by the inverse NTT of the batch = 128 transforms, natural order in and out, bit-exact against
-field/src/fft.rs (checked every run on sampled columns against the CPU oracle, outside the timed
-region). Each rank owns its own batch on its own GPU: the path shards by column with no
+field/src/fft.rs (checked every run outside the timed region, without the oracle: the batch must
+survive the round trips unchanged, and sampled outputs must equal the DFT definition; the oracle is
+used by the cpu_baseline leg only, the parity tests proper are tests/ -m gpu). Each rank owns its own batch on its own GPU: the path shards by column with no
 data-path collective, so scaling is weak and torch.distributed is only used for
 the barrier and the max-over-ranks of the elapsed time.
 
@@ -81,6 +82,26 @@ def cpu_baseline(log_n):
     }
 
 
+def dft_point(x, log_n, k):
+    """X[k] = sum_j x[j] * w^(j k) mod p, w = the primitive 2^log_n-th root of unity (field/src/types.rs:268-272;
+    fft.rs:242-282 checks fft against exactly this naive evaluation). Vectorised numpy, no oracle."""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import synth_circuit as sc
+
+    p = sc.P
+    wk = pow(pow(1753635133440165772, 1 << (32 - log_n), p), k, p)
+    pw = np.ones(1, dtype=np.uint64)  # (w^k)^j for j < n, by doubling
+    for b in range(log_n):
+        pw = np.concatenate([pw, sc.np_mul(pw, np.uint64(pow(wk, 1 << b, p)))])
+    terms = sc.np_mul(np.asarray(x, dtype=np.uint64), pw)
+    while terms.size > 1:  # modular sum by halving
+        half = terms.size // 2
+        terms = sc.np_add(terms[:half], terms[half:])
+    return int(terms[0])
+
+
 def pmc_traffic(log_n, batch):
     """HBM-side bytes per forward batch transform from the committed PMC summary (measured with
     rocprofv3 in separate counter passes; bench.py cannot read counters while it runs)."""
@@ -153,15 +174,17 @@ def main():
 
     out = None
     if dist.rank == 0:
-        # oracle equality on two columns of a fresh forward transform (outside the timed region)
-        from oracle import oracle as o
-
-        _lib.call("gl_ntt_batch", buf.ptr, 2, log_n, n, 0, 0, ctx.ptr)
-        got = buf.download(0, 2 * n).reshape(2, n)
-        if not (got == o.canon(o.fft_batch(host[:2].copy(), threads=2))).all():
-            raise SystemExit("bench: forward NTT differs from the oracle")
-        _lib.call("gl_ntt_batch", buf.ptr, 2, log_n, n, 1, 0, ctx.ptr)
+        # Outside the timed region, and without the oracle (which only the cpu_baseline leg may touch): the
+        # forward transform of column 0 against the DEFINITION X[k] = sum_j x[j] w^(jk) at a few output
+        # indices, evaluated with vectorised numpy field arithmetic. With the round trip above this pins the
+        # forward transform itself, not just its invertibility; the full parity tests are tests/test_gpu_ntt.py.
+        _lib.call("gl_ntt_batch", buf.ptr, 1, log_n, n, 0, 0, ctx.ptr)
+        got = buf.download(0, n)
+        _lib.call("gl_ntt_batch", buf.ptr, 1, log_n, n, 1, 0, ctx.ptr)
         ctx.synchronize()
+        for k in (1, 5, n // 2 + 3, n - 1):
+            if int(got[k]) != dft_point(host[0], log_n, k):
+                raise SystemExit(f"bench: forward NTT output {k} differs from the DFT definition")
 
     extra = {}
     if not args.no_commit and dist.rank == 0:
@@ -225,7 +248,8 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
     """prove() (plonk/prover.rs:40-233) per rank on its own synthetic circuit instance of the ed25519
     proof's shape; every rank proves `reps` independent proofs (configs[4]: one proof per GPU, no
     collective). The witness and the preprocessed commitment are resident before the timed region.
-    Rank 0's last proof is checked by the oracle's verifier outside the timed region."""
+    Rank 0's last proof gets oracle-free self-checks outside the timed region; a proof of this very shape
+    is verified by the oracle's verifier in tests/test_gpu_prove.py."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth_circuit
     from plonky2_gpu_amd.challenger import hash_no_pad
@@ -245,13 +269,16 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
     dist.barrier()
     elapsed = dist.max(time.perf_counter() - t0)
     timing = {}
-    nc.prove_bytes(d_wires, pis, timing)  # one more with per-stage synchronisation for the breakdown
+    again = nc.prove_bytes(d_wires, pis, timing)  # one more with per-stage synchronisation for the breakdown
     res = None
     if dist.rank == 0:
-        from oracle import prove_ref
-
-        vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
-        ok = bool(prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit)))
+        # Self-checks that need no oracle (only the cpu_baseline leg may touch it): the proof parses with the
+        # product's reader into the shape the circuit dictates, re-serialises to the same bytes, and is
+        # identical from run to run. Its VALIDITY at this very shape is established where the oracle is allowed:
+        # tests/test_gpu_prove.py::test_full_size_proof_is_accepted_by_the_oracle_verifier (run with -m gpu).
+        parsed = pg.serialization.proof_from_bytes(data, circuit)
+        if pg.serialization.proof_to_bytes(parsed) != data or again != data:
+            raise SystemExit("bench: the proof does not round-trip through the wire format or is not deterministic")
         res = {
             "workload": f"configs[3] shape, synthetic circuit: n=2^{degree_bits}, {num_wires} wires (80 routed), 88 preprocessed polys, "
                         f"2 challenges, rate 8, cap_height 4, FRI arities {circuit['fri_params']['reduction_arity_bits']}, 28 queries, "
@@ -262,7 +289,8 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
             "proof_bytes": len(data),
             "prover": "gl_prove (native host logic, csrc/prove.hip)",
             "stage_ms": {k: round(v, 3) for k, v in timing.items()},
-            "oracle_verifier_accepts": ok,
+            "self_checks": "parses, re-serialises identically, deterministic across runs",
+            "validity_checked_by": "tests/test_gpu_prove.py::test_full_size_proof_is_accepted_by_the_oracle_verifier",
         }
     d_wires.free()
     return res

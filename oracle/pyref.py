@@ -6,7 +6,7 @@ textbook round function (ARK -> S-box -> MDS, no "fast partial round" tables), t
 built level by level and only then mapped into the reference's digest layout through the closed
 form used by `MerkleTree::prove` (plonky2/src/hash/merkle_tree.rs:424-435).
 
-Only tests/ (and tools/gen_golden.py) import this. Small sizes only — it is slow on purpose.
+Only tests/ (including tests/golden/gen_golden.py) import this. Small sizes only — it is slow on purpose.
 """
 import os
 import re

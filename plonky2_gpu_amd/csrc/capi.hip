@@ -1,4 +1,5 @@
 // capi.hip — the extern "C" boundary of libplonky2_hip.so (declared in include/plonky2_hip.h).
+#include <list>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -38,12 +39,19 @@ GlError hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 // Per-device table registry (twiddles are data-independent, a few hundred KiB).
+struct CosetEntry {
+    CosetTables ct;
+    uint64_t last_use = 0;
+    uint32_t pins = 0;  // callers between get_coset_tables() and the end of their enqueues
+};
 struct DeviceState {
     bool have_tables = false;
     NttTables tables;
-    std::vector<CosetTables> cosets;
+    std::list<CosetEntry> cosets;  // LRU cache keyed by (log_n, rate_bits, shift); addresses are stable
+    uint64_t coset_tick = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
+constexpr size_t COSET_CACHE_ENTRIES = 64;  // a prover uses a handful (one shift, a few sizes); 80 KiB each at 2^18 x 8
 std::mutex g_mu;
 DeviceState g_dev[64];
 
@@ -79,27 +87,68 @@ hipError_t get_events(hipEvent_t *a, hipEvent_t *b) {
     return hipSuccess;
 }
 
-hipError_t get_coset_tables(uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream, const CosetTables **out) {
+// Holds one cache entry pinned while its owner enqueues the kernels that read it; an unpinned entry may be
+// evicted, and eviction synchronises the device first, so work already enqueued on any stream is safe too.
+class CosetLease {
+public:
+    CosetLease() = default;
+    CosetLease(const CosetLease &) = delete;
+    CosetLease &operator=(const CosetLease &) = delete;
+    ~CosetLease() { release(); }
+    const CosetTables &operator*() const { return entry_->ct; }
+    void acquire(CosetEntry *e) {  // g_mu held
+        release_locked();
+        entry_ = e;
+        e->pins++;
+    }
+    void release() {
+        if (!entry_) return;
+        std::lock_guard<std::mutex> lk(g_mu);
+        release_locked();
+    }
+
+private:
+    void release_locked() {
+        if (entry_) entry_->pins--;
+        entry_ = nullptr;
+    }
+    CosetEntry *entry_ = nullptr;
+};
+
+hipError_t get_coset_tables(uint32_t log_n, uint32_t rate_bits, uint64_t shift, hipStream_t stream, CosetLease *out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceState &st = g_dev[dev & 63];
     for (auto &c : st.cosets)
-        if (c.log_n == log_n && c.rate_bits == rate_bits && c.shift == shift) {
-            *out = &c;
+        if (c.ct.log_n == log_n && c.ct.rate_bits == rate_bits && c.ct.shift == shift) {
+            c.last_use = ++st.coset_tick;
+            out->acquire(&c);
             return hipSuccess;
         }
-    st.cosets.reserve(64);  // pointers handed out stay valid
-    if (st.cosets.size() >= 64) return hipErrorOutOfMemory;
-    CosetTables ct;
-    e = coset_tables_create(&ct, log_n, rate_bits, shift, stream);
-    if (e != hipSuccess) return e;
-    // tables are built on `stream`; other streams of this device may use them later
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    st.cosets.push_back(ct);
-    *out = &st.cosets.back();
+    // Miss on a full cache: drop the least recently used entry nobody holds. If every entry is pinned
+    // (more concurrent callers than entries) the cache grows instead: a full cache is never an error.
+    while (st.cosets.size() >= COSET_CACHE_ENTRIES) {
+        auto victim = st.cosets.end();
+        for (auto it = st.cosets.begin(); it != st.cosets.end(); ++it)
+            if (it->pins == 0 && (victim == st.cosets.end() || it->last_use < victim->last_use)) victim = it;
+        if (victim == st.cosets.end()) break;
+        e = hipDeviceSynchronize();  // kernels enqueued by earlier, already-returned calls may still read it
+        if (e != hipSuccess) return e;
+        coset_tables_destroy(&victim->ct);
+        st.cosets.erase(victim);
+    }
+    CosetEntry entry;
+    e = coset_tables_create(&entry.ct, log_n, rate_bits, shift, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // built on `stream`; other streams may use them later
+    if (e != hipSuccess) {
+        coset_tables_destroy(&entry.ct);
+        return e;
+    }
+    entry.last_use = ++st.coset_tick;
+    st.cosets.push_back(entry);
+    out->acquire(&st.cosets.back());
     return hipSuccess;
 }
 
@@ -183,7 +232,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     if (poly_num + salt_size == 0 || poly_num + salt_size > 0xFFFFFFFFull) return fail(GL_E_INVALID, "bad poly_num");
     const uint64_t n = 1ull << log_n, n_ext = n << rate_bits;
     const NttTables *tb;
-    const CosetTables *ct;
+    CosetLease ct;
     HIP_TRY(get_tables(&tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
@@ -349,7 +398,7 @@ GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t p
     if (((uintptr_t)d_coeffs | (uintptr_t)d_out) & 15) return fail(GL_E_INVALID, "buffers must be 16-byte aligned");
     if (log_n > 0 && ((src_stride | dst_stride) & 1)) return fail(GL_E_INVALID, "strides must be even");
     const NttTables *tb;
-    const CosetTables *ct;
+    CosetLease ct;
     HIP_TRY(get_tables(&tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, S(ctx)->stream, &ct));
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_out, poly_num, src_stride, dst_stride, S(ctx)->stream));
@@ -360,7 +409,7 @@ GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n
                            void *ctx) {
     if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
     if (shift % glh::P == 0) return fail(GL_E_INVALID, "shift must be non-zero");
-    const CosetTables *ct;
+    CosetLease ct;
     if (!inverse) {
         // coset_fft: c_i *= shift^i, then fft (polynomial/mod.rs:286-299)
         HIP_TRY(get_coset_tables(log_n, 0, shift % glh::P, S(ctx)->stream, &ct));

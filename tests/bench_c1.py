@@ -1,6 +1,6 @@
 """BASELINE.json configs[0] (CPU only, plumbing): the reference's criterion workloads
 (plonky2/benches/field_arithmetic.rs, ffts.rs) over the C restatement — builds and runs oracle/bench_c1,
-adds the host description. ns per iteration, one thread. usage: python tools/bench_c1.py [out.json]"""
+adds the host description. ns per iteration, one thread. usage: python tests/bench_c1.py [out.json]"""
 import json
 import os
 import platform

@@ -1,6 +1,6 @@
 """Differential campaign one level below fuzz_prove.py: randomly shaped NTTs, coset LDEs and
 PolynomialBatch commits on the device against the C oracle (oracle/gl_oracle.c).
-    python tools/fuzz_commit.py [cases=60] [seed=1]
+    python tests/fuzz_commit.py [cases=60] [seed=1]
 Shapes: 1..48 polynomials (crossing the 8-element sponge block and the <=4 `not hashed` rule), 2^0..2^13
 rows, rate 0..3 bits, every legal cap height, values that are NOT canonical (>= p) in a tenth of the
 cases, from_values and from_coeffs, with and without the leaf-major copy; forward / inverse NTT with

@@ -2,7 +2,7 @@
 compared byte for byte with the oracle's (oracle/prove_ref.py). Shapes vary in degree, selector
 grouping, FRI arities, rate, cap height, proof-of-work bits, query count, quotient degree factor,
 number of challenges and gate compilation. Not part of the test suite; run it on a GPU box:
-    python tools/fuzz_prove.py [cases=40] [seed=1]
+    python tests/fuzz_prove.py [cases=40] [seed=1]
 Prints one line per case and a JSON summary; exits non-zero on the first mismatch."""
 import json
 import os

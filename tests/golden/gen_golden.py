@@ -4,14 +4,14 @@
 The reference holds no golden FFT outputs, Merkle caps or commitments, so the
 fixtures are produced here, in the build container, by the model that is itself pinned by the
 reference's known answers (tests/test_oracle_*.py). Inputs come from the SplitMix64 stream of
-SURVEY.md §8d, seed 0x706C6F6E6B7932. Run:  python tools/gen_golden.py
+SURVEY.md §8d, seed 0x706C6F6E6B7932. Run:  python tests/golden/gen_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyref  # noqa: E402
 

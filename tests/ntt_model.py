@@ -3,7 +3,7 @@
 
 Not part of the product: a CPU-side check of the four-step decomposition, digit order, twiddle
 exponents, LDS slot permutation and store addressing, run on small sizes against the O(n log n)
-definition in oracle/pyref.py. `python tools/ntt_model.py` exits non-zero on a mismatch.
+definition in oracle/pyref.py. `python tests/ntt_model.py` exits non-zero on a mismatch.
 """
 import os
 import sys

@@ -57,6 +57,26 @@ def test_product_never_imports_oracle():
                     assert needle not in src.replace("oracle.rs", ""), (needle, os.path.join(dirpath, f))
 
 
+def _imports_of_oracle(src):
+    return [ln.strip() for ln in src.splitlines() if ln.strip().startswith(("from oracle", "import oracle"))]
+
+
+def test_oracle_is_used_only_where_it_may_be():
+    """③ beyond the package: in bench.py only the cpu_baseline leg imports oracle/; nothing under tools/
+    does (scripts that need the checker live under tests/); smoke() may."""
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    start = bench.index("def cpu_baseline(")
+    end = bench.index("\ndef ", start + 1)
+    assert _imports_of_oracle(bench[start:end]), "the cpu_baseline leg times the oracle"
+    assert not _imports_of_oracle(bench[:start] + bench[end:]), "bench.py uses oracle/ outside its cpu_baseline leg"
+    for dirpath, dirs, files in os.walk(os.path.join(ROOT, "tools")):
+        dirs[:] = [d for d in dirs if not d.startswith("jitcache")]
+        for f in files:
+            if f.endswith(".py"):
+                hits = _imports_of_oracle(open(os.path.join(dirpath, f)).read())
+                assert not hits, (os.path.join(dirpath, f), hits)
+
+
 def test_no_gpu_means_loud_failure(lib):
     import plonky2_gpu_amd as pg
 

@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/*.npz, made by tools/gen_golden.py from the independent
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/gen_golden.py from the independent
 big-int model): the C oracle must reproduce them on the CPU, the HIP path on the GPU. Bit-exact."""
 import glob
 import os

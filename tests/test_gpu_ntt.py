@@ -170,6 +170,29 @@ def test_coset_fft_and_ifft_natural_order(gpu, oracle, log_n):
             assert (pg.coset_ifft(gpu, x[i], shift) == oracle.canon(oracle.coset_ifft(x[i], shift))).all()
 
 
+def test_more_distinct_cosets_than_the_table_cache_holds(gpu, oracle):
+    """The per-device coset-table cache (capi.hip get_coset_tables) is a bounded LRU: a process that has used
+    more distinct (size, rate, shift) combinations than it holds must keep working and keep being right,
+    including for a combination that was evicted and is built again. 150 shifts x (forward + inverse tables)
+    is several times the bound whatever ran earlier in this process."""
+    import plonky2_gpu_amd as pg
+
+    log_n = 6
+    x = oracle.random_field((1 << log_n,), seed=7100)
+    shifts = [7] + [int(s) for s in oracle.random_field((149,), seed=7101) if int(s) != 0]
+    first = pg.coset_fft(gpu, x, shifts[0])
+    assert (first == oracle.canon(oracle.coset_fft(x, shifts[0]))).all()
+    for shift in shifts[1:]:
+        ev = pg.coset_fft(gpu, x, shift)
+        assert (ev == oracle.canon(oracle.coset_fft(x, shift))).all(), shift
+        assert (pg.coset_ifft(gpu, ev, shift) == x).all(), shift
+    assert (pg.coset_fft(gpu, x, shifts[0]) == first).all()  # long since evicted: rebuilt, same answer
+    # and a combination of the LDE kind after the churn
+    c = oracle.random_field((1 << 10,), seed=7102)
+    got = pg.coset_lde_bit_reversed(gpu, c.reshape(1, -1), 2)
+    assert (got[0] == oracle.canon(oracle.coset_lde(c, 2))[bitrev_perm(12)]).all()
+
+
 def test_ntt_argument_errors(gpu):
     import plonky2_gpu_amd as pg
     from plonky2_gpu_amd import _lib

@@ -186,3 +186,32 @@ def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
     assert nc.prove_bytes(wires, [(x + 1) % prove_ref.P for x in pis]) != first
     nc.trim()
     assert nc.prove_bytes(wires, pis) == first
+
+
+def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu):
+    """The shape bench.py times (BASELINE.json configs[3]: n = 2^18, 234 wires / 80 routed, 88 preprocessed
+    polynomials, rate 8, cap height 4, FRI arities [4, 4, 4, 4], 28 queries, 16 proof-of-work bits) proven by
+    gl_prove and checked by the oracle's verifier, which recomputes every challenge from the bytes. bench.py
+    itself may not use the oracle for this (only its cpu_baseline leg may), so the validity of what it times is
+    established here; the witness comes from the same generator with the same seed as the bench's rank 0."""
+    import os
+    import sys
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd.challenger import hash_no_pad
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import synth_circuit
+
+    circuit, wires, pis = synth_circuit.make(18, num_wires=234, num_routed=80, num_constants=8, seed=1)
+    assert circuit["fri_params"]["reduction_arity_bits"] == [4, 4, 4, 4]
+    synth_circuit.set_public_input_row(wires, hash_no_pad(gpu, pis))
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))
+    data = nc.prove_bytes(d_wires, pis)
+    assert len(data) == 204544
+    vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
+    assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
+    nc.close()
