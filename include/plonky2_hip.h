@@ -158,7 +158,7 @@ typedef struct GlGateProgram {
 
 /* The same gate programs compiled at run time (hiprtc, gfx950) into a kernel specialised to the circuit:
  * one device function per gate, registers in VGPRs, immediates as literals. Built once per circuit
- * (seconds), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.
+ * (under a second for a few small gates, about a minute for the 25-gate ed25519 list), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.
  * On failure the GlError message carries the compiler log. */
 GlError gl_gate_kernel_build(const GlGateInstr *h_instrs, uint32_t num_instrs, const GlGateDesc *h_gates, uint32_t num_gates,
                              const uint64_t *h_immediates, uint32_t num_immediates, uint32_t num_selectors,
@@ -365,9 +365,28 @@ GlError merkle_tree_from_values(uint64_t *d_values_flatten, uint64_t *d_ext_valu
 GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly, int log_len,
                           int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx);
 
-/* lib.rs:117-143 / plonky2_gpu.cu:609-783. The reference kernel is hard-wired to one circuit
- * (ed25519); the table-driven replacement is the next row of the scope table.
- * Returns GL_E_UNSUPPORTED in this build. */
+/* lib.rs:117-143 / plonky2_gpu.cu:609-783: the quotient polynomials of the ONE circuit the reference kernel is
+ * hard-wired to — plonky2-ed25519: 234 wires / 80 routed, 8 constants, 2 challenges, quotient degree factor 8 =
+ * 2^rate_bits, 25 gates in 6 selector groups, 231 gate constraints (plonky2_gpu.cu:666-675,
+ * plonky2_gpu_impl.cuh:597-685). Same contract as the reference:
+ *   - d_ext_values_flatten (wires), zs_partial_products_commitment_leaves->ptr and
+ *     constants_sigmas_commitment_leaves->ptr are DEVICE buffers of LEAF-MAJOR rows [n_ext][leaf_len] with leaf t
+ *     holding the point bitrev(t) (leaf_len 234 + salt_size, 20, 88; n_ext = values_num_per_poly << rate_bits) —
+ *     region A of merkle_tree_from_values/coeffs; the DataSlice lengths are checked as the reference asserts them;
+ *   - k_is (>= 80), alphas, betas, gammas (2 each) are DEVICE slices;
+ *   - d_outs [2][n_ext] is scratch, d_quotient_polys [2][n_ext] receives the COEFFICIENTS of the two quotient
+ *     polynomials (values on the coset -> ifft -> x shift^-i, plonky2_gpu.cu:737-765); the call synchronises ctx->stream.
+ * Not read: d_root_table2, d_shift_inv_powers, points, z_h_on_coset_evals, z_h_on_coset_inverses (may be NULL) —
+ * the kernels derive these from the library's own tables. Other shapes return GL_E_INVALID: every other circuit goes
+ * through gl_compute_quotient_polys, of which this is one instance with the gate programs compiled in
+ * (csrc/ed25519_gate_program.inc). The first call on a device builds that kernel with hiprtc: about a minute
+ * of single-threaded compilation when nothing is cached (72 s measured on the build container), about 2 s when ROCm's
+ * own compilation cache (~/.cache/comgr, on by default) has seen the source, immediate from
+ * $PLONKY2_HIP_KERNEL_CACHE. gl_reference_quotient_prepare() does it ahead of the first proof.
+ * The reference also compiles in the hash of one proof's public inputs (plonky2_gpu.cu:686-689); the same value is
+ * the default here, and gl_reference_set_public_inputs_hash() replaces it (process-wide; NULL restores the default). */
+GlError gl_reference_quotient_prepare(void *ctx);
+GlError gl_reference_set_public_inputs_hash(const uint64_t *h_hash /* 4, host */);
 GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly,
                                int log_len, const uint64_t *d_root_table2, const uint64_t *d_shift_inv_powers,
                                int rate_bits, int salt_size, const GlDataSlice *zs_partial_products_commitment_leaves,

@@ -17,6 +17,7 @@ from .challenger import Challenger  # noqa: F401
 from . import serialization  # noqa: F401
 from .fri import prove_openings  # noqa: F401
 from .prover import CircuitData, GateProgram, NativeCircuit, all_wires_permutation_partial_products, compute_quotient_polys, prove  # noqa: F401
+from .prover import reference_compute_quotient_polys, reference_set_public_inputs_hash  # noqa: F401
 
 P = 0xFFFFFFFF00000001
 COSET_SHIFT = 7  # F::coset_shift(), field/src/types.rs:431-433

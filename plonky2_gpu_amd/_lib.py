@@ -164,6 +164,8 @@ SIGNATURES = {
     "merkle_tree_from_values": (GlError, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "build_merkle_tree": (GlError, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "compute_quotient_polys": (GlError, [_vp, _i, _i, _i, _vp, _vp, _i, _i] + [_vp] * 12),
+    "gl_reference_quotient_prepare": (GlError, [_vp]),
+    "gl_reference_set_public_inputs_hash": (GlError, [_vp]),
     "cudaGetErrorString": (ctypes.c_char_p, [_i]),
 }
 

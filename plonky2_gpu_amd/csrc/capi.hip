@@ -14,6 +14,7 @@
 #include "ntt.h"
 #include "plonk.h"
 #include "fri.h"
+#include "ed25519_gate_program.inc"
 
 using namespace plonky2_hip;
 
@@ -50,6 +51,7 @@ struct DeviceState {
     std::list<CosetEntry> cosets;  // LRU cache keyed by (log_n, rate_bits, shift); addresses are stable
     uint64_t coset_tick = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    GateKernel *ed25519_kernel = nullptr;  // the reference symbol compute_quotient_polys' circuit, built on first use
 };
 constexpr size_t COSET_CACHE_ENTRIES = 64;  // a prover uses a handful (one shift, a few sizes); 80 KiB each at 2^18 x 8
 std::mutex g_mu;
@@ -150,6 +152,30 @@ hipError_t get_coset_tables(uint32_t log_n, uint32_t rate_bits, uint64_t shift, 
     st.cosets.push_back(entry);
     out->acquire(&st.cosets.back());
     return hipSuccess;
+}
+
+// The gate kernel of the one circuit the reference's compute_quotient_polys is compiled for (ed25519_gate_program.inc).
+// A cold hiprtc build of it takes about a minute (gate_jit.hip keeps compiled code objects under
+// $PLONKY2_HIP_KERNEL_CACHE; comgr's own cache cuts a repeat to ~2 s), so this has its own lock: table lookups of
+// other threads do not wait for it.
+std::mutex g_ref_mu;
+uint64_t g_ref_pih[4] = {ED25519_REFERENCE_PUBLIC_INPUTS_HASH[0], ED25519_REFERENCE_PUBLIC_INPUTS_HASH[1],
+                         ED25519_REFERENCE_PUBLIC_INPUTS_HASH[2], ED25519_REFERENCE_PUBLIC_INPUTS_HASH[3]};
+
+GlError get_ed25519_kernel(const GateKernel **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (!st.ed25519_kernel) {
+        std::string err;
+        st.ed25519_kernel = gate_kernel_build(ED25519_INSTRS, ED25519_NUM_INSTRS, ED25519_GATES, ED25519_NUM_GATES, ED25519_IMMEDIATES,
+                                              ED25519_NUM_IMMEDIATES, ED25519_NUM_SELECTORS, ED25519_NUM_GATE_CONSTRAINTS,
+                                              ED25519_NUM_CHALLENGES, &err);
+        if (!st.ed25519_kernel) return fail(GL_E_INVALID, "compute_quotient_polys: building the ed25519 gate kernel failed: " + err);
+    }
+    *out = st.ed25519_kernel;
+    return ok();
 }
 
 Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
@@ -764,13 +790,82 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
     return ok();
 }
 
-GlError compute_quotient_polys(const uint64_t *, int, int, int, const uint64_t *, const uint64_t *, int, int,
-                               const GlDataSlice *, const GlDataSlice *, void *, void *, const GlDataSlice *,
-                               const GlDataSlice *, const GlDataSlice *, const GlDataSlice *, const GlDataSlice *,
-                               const GlDataSlice *, const GlDataSlice *, void *) {
-    return fail(GL_E_UNSUPPORTED,
-                "compute_quotient_polys: the reference kernel is specialised to one circuit; the table-driven "
-                "quotient kernel is not part of this build");
+GlError gl_reference_quotient_prepare(void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null pointer");
+    const GateKernel *k;
+    return get_ed25519_kernel(&k);
+}
+
+GlError gl_reference_set_public_inputs_hash(const uint64_t *h_hash) {
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    for (int k = 0; k < 4; k++) g_ref_pih[k] = h_hash ? h_hash[k] : ED25519_REFERENCE_PUBLIC_INPUTS_HASH[k];
+    return ok();
+}
+
+// cuda/plonky2_gpu.cu:609-783. The circuit (shape, gate table, selector groups) is compiled in, as in the
+// reference; what the reference precomputes on the host and hands over as tables (root_table2, shift_inv_powers,
+// points, Z_H on the coset and its inverses) the kernels here derive themselves, so those arguments are not read.
+GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly, int log_len,
+                               const uint64_t *d_root_table2, const uint64_t *d_shift_inv_powers, int rate_bits, int salt_size,
+                               const GlDataSlice *zs_partial_products_commitment_leaves,
+                               const GlDataSlice *constants_sigmas_commitment_leaves, void *d_outs, void *d_quotient_polys,
+                               const GlDataSlice *points, const GlDataSlice *z_h_on_coset_evals,
+                               const GlDataSlice *z_h_on_coset_inverses, const GlDataSlice *k_is, const GlDataSlice *alphas,
+                               const GlDataSlice *betas, const GlDataSlice *gammas, void *ctx) {
+    (void)d_root_table2, (void)d_shift_inv_powers, (void)points, (void)z_h_on_coset_evals, (void)z_h_on_coset_inverses;
+    const GlDataSlice *zs = zs_partial_products_commitment_leaves, *cs = constants_sigmas_commitment_leaves;
+    if (!ctx || !d_ext_values_flatten || !zs || !cs || !d_outs || !d_quotient_polys || !k_is || !alphas || !betas || !gammas)
+        return fail(GL_E_INVALID, "null pointer");
+    if (!zs->ptr || !cs->ptr || !k_is->ptr || !alphas->ptr || !betas->ptr || !gammas->ptr) return fail(GL_E_INVALID, "null pointer in DataSlice");
+    if (log_len < 0 || log_len + (int)ED25519_RATE_BITS > 24 || values_num_per_poly != (1 << log_len)) return fail(GL_E_INVALID, "bad sizes");
+    if (salt_size < 0 || poly_num != (int)ED25519_NUM_WIRES || rate_bits != (int)ED25519_RATE_BITS)
+        return fail(GL_E_INVALID, "compute_quotient_polys is compiled for the ed25519 circuit: 234 wire polynomials, rate_bits 3 "
+                                  "(plonky2_gpu.cu:666-675); use gl_compute_quotient_polys for any other circuit");
+    const uint64_t n_ext = (uint64_t)values_num_per_poly << rate_bits;
+    // the reference's own asserts (plonky2_gpu.cu:677-683)
+    if ((uint64_t)cs->len != n_ext * ED25519_CONSTANTS_SIGMAS_LEAF_LEN || (uint64_t)zs->len != n_ext * ED25519_ZS_PARTIAL_PRODUCTS_LEAF_LEN)
+        return fail(GL_E_INVALID, "leaf buffers must hold n_ext x 88 (constants_sigmas) and n_ext x 20 (zs_partial_products) elements");
+    if (alphas->len != (int)ED25519_NUM_CHALLENGES || betas->len != (int)ED25519_NUM_CHALLENGES || gammas->len != (int)ED25519_NUM_CHALLENGES)
+        return fail(GL_E_INVALID, "alphas, betas and gammas must hold num_challenges = 2 elements each");
+    if (k_is->len < (int)ED25519_NUM_ROUTED_WIRES) return fail(GL_E_INVALID, "k_is must hold num_routed_wires = 80 elements");
+    const GateKernel *kernel;
+    GlError ge = get_ed25519_kernel(&kernel);
+    if (ge.code) return ge;
+    // the challenges live in device memory on the reference's side of the boundary (prover.rs:489-516)
+    uint64_t ch[3][2];
+    const GlDataSlice *src[3] = {alphas, betas, gammas};
+    for (int i = 0; i < 3; i++) HIP_TRY(hipMemcpyAsync(ch[i], src[i]->ptr, sizeof(ch[i]), hipMemcpyDeviceToHost, S(ctx)->stream));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    uint64_t pih[4];
+    {
+        std::lock_guard<std::mutex> lk(g_ref_mu);
+        for (int k = 0; k < 4; k++) pih[k] = g_ref_pih[k];
+    }
+    GlQuotientArgs a = {};
+    a.d_wires_leaves = d_ext_values_flatten;  // leaf-major, leaf t = point bitrev(t) (plonky2_gpu_impl.cuh:537-541)
+    a.d_constants_sigmas_leaves = static_cast<const uint64_t *>(cs->ptr);
+    a.d_zs_partial_products_leaves = static_cast<const uint64_t *>(zs->ptr);
+    a.wires_leaf_len = (uint32_t)(poly_num + salt_size);
+    a.constants_sigmas_leaf_len = ED25519_CONSTANTS_SIGMAS_LEAF_LEN;
+    a.zs_partial_products_leaf_len = ED25519_ZS_PARTIAL_PRODUCTS_LEAF_LEN;
+    a.d_k_is = static_cast<const uint64_t *>(k_is->ptr);
+    a.h_alphas = ch[0], a.h_betas = ch[1], a.h_gammas = ch[2];
+    a.num_constants = ED25519_NUM_CONSTANTS;
+    a.num_routed_wires = ED25519_NUM_ROUTED_WIRES;
+    a.num_challenges = ED25519_NUM_CHALLENGES;
+    a.num_gate_constraints = ED25519_NUM_GATE_CONSTRAINTS;
+    a.degree_bits = (uint32_t)log_len;
+    a.rate_bits = (uint32_t)rate_bits;
+    a.quotient_degree_factor = ED25519_QUOTIENT_DEGREE_FACTOR;
+    a.coset_shift = 7;
+    a.column_stride = 0;
+    a.gate_kernel = kernel;
+    a.h_public_inputs_hash = pih;
+    a.d_gate_workspace = static_cast<uint64_t *>(d_outs);  // [2][n_ext]: the reference's scratch for the same stage
+    GlError e = gl_compute_quotient_polys(&a, static_cast<uint64_t *>(d_quotient_polys), ctx);
+    if (e.code) return e;
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    return ok();
 }
 
 const char *cudaGetErrorString(int code) {

@@ -69,6 +69,36 @@ def compute_quotient_polys(ctx, wires_commitment, constants_sigmas_commitment, z
     return out
 
 
+def reference_compute_quotient_polys(ctx, d_wires_leaves, log_len, d_zs_partial_products_leaves, d_constants_sigmas_leaves, d_k_is,
+                                     d_alphas, d_betas, d_gammas, salt_size=0):
+    """The reference's own FFI symbol `compute_quotient_polys` (cuda/src/lib.rs:117-143, called at
+    plonky2/src/plonk/prover.rs:539-566): the ed25519 circuit is compiled into the library (ed25519_circuit.py),
+    every buffer is a DEVICE buffer — three leaf-major LDEs [n_ext][234 + salt | 20 | 88], k_is (80) and the three
+    challenge pairs. Returns the DeviceBuffer d_quotient_polys [2][n_ext] (coefficients)."""
+    from . import ed25519_circuit as ed
+
+    n = 1 << log_len
+    n_ext = n << ed.RATE_BITS
+    sl = lambda buf, count: _lib.GlDataSlice(buf.ptr, count)  # noqa: E731
+    zs = sl(d_zs_partial_products_leaves, n_ext * ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN)
+    cs = sl(d_constants_sigmas_leaves, n_ext * ed.CONSTANTS_SIGMAS_LEAF_LEN)
+    k_is, al, be, ga = sl(d_k_is, ed.NUM_ROUTED_WIRES), sl(d_alphas, 2), sl(d_betas, 2), sl(d_gammas, 2)
+    d_outs = DeviceBuffer(ctx, 2 * n_ext)
+    out = DeviceBuffer(ctx, 2 * n_ext)
+    ref = ctypes.addressof
+    try:
+        _lib.call("compute_quotient_polys", d_wires_leaves.ptr, ed.NUM_WIRES, n, log_len, None, None, ed.RATE_BITS, salt_size,
+                  ref(zs), ref(cs), d_outs.ptr, out.ptr, None, None, None, ref(k_is), ref(al), ref(be), ref(ga), ctx.ptr)
+    finally:
+        d_outs.free()
+    return out
+
+
+def reference_set_public_inputs_hash(public_inputs_hash=None):
+    """Replace (None: restore) the public-inputs hash the reference compiles into its kernel (plonky2_gpu.cu:686-689)."""
+    _lib.call("gl_reference_set_public_inputs_hash", _host_u64(public_inputs_hash) if public_inputs_hash is not None else None)
+
+
 class GateProgram:
     """Device-resident gate programs of a circuit (see gate_program.py): the table-driven replacement
     of the reference's hard-wired gate list (cuda/plonky2_gpu_impl.cuh:600-685)."""

@@ -164,13 +164,14 @@ def test_reference_abi_entry_points(gpu, oracle):
     ext3.upload(nat, pad)
     _lib.call("build_merkle_tree", ext3.ptr, P_, n, log_n, rate_bits, 0, h, pad, gpu.ptr)
     assert (ext3.download(2 * pad + 4 * nd, 4 << h).reshape(-1, 4) == cap).all()
-    # wrong n_inv is rejected instead of silently ignored; quotient entry reports unsupported
+    # wrong n_inv is rejected instead of silently ignored; the quotient entry (tests/test_reference_quotient.py)
+    # rejects null arguments
     bad = ctypes.c_uint64(12345)
     with pytest.raises(pg.Plonky2HipError):
         _lib.call("ifft", ext.ptr, P_, n, log_n, None, ctypes.addressof(bad), gpu.ptr)
     with pytest.raises(pg.Plonky2HipError) as e:
         _lib.call("compute_quotient_polys", None, 0, 0, 0, None, None, 0, 0, *([None] * 12))
-    assert e.value.code == pg.GL_E_UNSUPPORTED
+    assert e.value.code == pg.GL_E_INVALID
 
 
 def test_open_batch_equals_get_and_prove(gpu, oracle):

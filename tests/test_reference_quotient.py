@@ -1,0 +1,145 @@
+"""The reference's circuit-specific FFI symbol `compute_quotient_polys` (cuda/src/lib.rs:117-143,
+cuda/plonky2_gpu.cu:609-783): the ed25519 circuit compiled into the library, buffers in the reference's layout.
+
+Checked on RANDOM leaf data, which is the stronger test for this stage: with random selector columns every one of
+the 25 gates' filters is non-zero at every point, so all 231 constraints of all gates contribute everywhere (on a
+satisfying witness one gate per row is live and its constraints are zero). The oracle evaluates the same table
+with oracle/gates_ref.py + oracle/plonk_ref.py. Bit-exact."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import gpu  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 0xFFFFFFFF00000001
+
+
+def test_committed_gate_program_is_what_the_generator_writes():
+    """csrc/ed25519_gate_program.inc is generated data; it must follow the emitters and the circuit table."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_ed25519_program as g
+
+    from plonky2_gpu_amd import ed25519_circuit as ed
+
+    committed = open(os.path.join(ROOT, "plonky2_gpu_amd", "csrc", "ed25519_gate_program.inc")).read()
+    assert committed == g.render(), "re-run tools/gen_ed25519_program.py and rebuild"
+    assert len(ed.GATES) == len(ed.SELECTOR_INDICES) == 25 and ed.GROUPS[-1][1] == 25
+    for row, sel in enumerate(ed.SELECTOR_INDICES):
+        assert ed.GROUPS[sel][0] <= row < ed.GROUPS[sel][1]
+    assert ed.CONSTANTS_SIGMAS_LEAF_LEN == ed.NUM_CONSTANTS + ed.NUM_ROUTED_WIRES
+    assert ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN == ed.NUM_CHALLENGES * (1 + ed.NUM_PARTIAL_PRODUCTS)
+    assert ed.NUM_PARTIAL_PRODUCTS == -(-ed.NUM_ROUTED_WIRES // ed.QUOTIENT_DEGREE_FACTOR) - 1
+
+
+def random_instance(log_len, seed):
+    from plonky2_gpu_amd import ed25519_circuit as ed
+
+    rng = np.random.default_rng(seed)
+    n_ext = (1 << log_len) << ed.RATE_BITS
+    rnd = lambda *shape: rng.integers(0, P, size=shape, dtype=np.uint64)  # noqa: E731
+    return dict(log_len=log_len, n_ext=n_ext, wires=rnd(n_ext, ed.NUM_WIRES), cs=rnd(n_ext, ed.CONSTANTS_SIGMAS_LEAF_LEN),
+                zs=rnd(n_ext, ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN), k_is=np.array([pow(7, j, P) for j in range(ed.NUM_ROUTED_WIRES)], dtype=np.uint64),
+                alphas=rnd(2), betas=rnd(2), gammas=rnd(2))
+
+
+def run_symbol(gpu, inst):
+    import plonky2_gpu_amd as pg
+
+    up = lambda a: pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(a).reshape(-1))  # noqa: E731
+    bufs = {k: up(inst[k]) for k in ("wires", "zs", "cs", "k_is", "alphas", "betas", "gammas")}
+    out = pg.reference_compute_quotient_polys(gpu, bufs["wires"], inst["log_len"], bufs["zs"], bufs["cs"], bufs["k_is"], bufs["alphas"],
+                                              bufs["betas"], bufs["gammas"])
+    return out.download().reshape(2, inst["n_ext"]), bufs
+
+
+def oracle_quotient(inst, pih):
+    from oracle import plonk_ref, prove_ref, pyref
+    from plonky2_gpu_amd import ed25519_circuit as ed
+
+    gates = prove_ref.base_gates({"gates": ed.GATES})
+    bits = inst["log_len"] + ed.RATE_BITS
+    w_l, cs_l, z_l = (inst[k].tolist() for k in ("wires", "cs", "zs"))
+    terms = []
+    for i in range(inst["n_ext"]):
+        row = pyref.reverse_bits(i, bits)
+        terms.append(plonk_ref.evaluate_gate_constraints(gates, ed.SELECTOR_INDICES, ed.GROUPS, ed.NUM_GATE_CONSTRAINTS,
+                                                         cs_l[row][:ed.NUM_CONSTANTS], w_l[row], list(pih)))
+    lst = lambda k: [int(v) for v in inst[k]]  # noqa: E731
+    return plonk_ref.compute_quotient_polys(w_l, cs_l, z_l, ed.NUM_CONSTANTS, lst("k_is"), lst("betas"), lst("gammas"), lst("alphas"),
+                                            inst["log_len"], ed.RATE_BITS, ed.QUOTIENT_DEGREE_FACTOR, terms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_len", [1, 4])
+def test_reference_symbol_equals_the_oracle(gpu, log_len):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import ed25519_circuit as ed
+
+    inst = random_instance(log_len, seed=9000 + log_len)
+    got, _ = run_symbol(gpu, inst)
+    exp = np.array(oracle_quotient(inst, ed.REFERENCE_PUBLIC_INPUTS_HASH), dtype=np.uint64)
+    assert (got == exp).all()
+    # another proof of the same circuit: its own public-inputs hash (the PublicInput gate reads it)
+    other = [random.Random(5).randrange(P) for _ in range(4)]
+    try:
+        pg.reference_set_public_inputs_hash(other)
+        got2, _ = run_symbol(gpu, inst)
+    finally:
+        pg.reference_set_public_inputs_hash(None)
+    assert (got2 != got).any()
+    assert (got2 == np.array(oracle_quotient(inst, other), dtype=np.uint64)).all()
+    again, _ = run_symbol(gpu, inst)  # default restored
+    assert (again == got).all()
+
+
+@pytest.mark.gpu
+def test_reference_symbol_equals_the_generic_entry_point(gpu):
+    """At 2^13 points: the symbol (compiled-in programs, run-time compiled kernel) against gl_compute_quotient_polys
+    given the same circuit as ARGUMENTS and run by the interpreter — two independent routes through the library."""
+    import ctypes
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib, ed25519_circuit as ed, gate_program as gp
+
+    inst = random_instance(10, seed=9100)
+    got, bufs = run_symbol(gpu, inst)
+    pool = gp.ImmediatePool()
+    prog = pg.GateProgram(gpu, [gp.build_gate(k, p, pool) for k, p in ed.GATES], ed.SELECTOR_INDICES, ed.GROUPS,
+                          ed.REFERENCE_PUBLIC_INPUTS_HASH, immediates=pool.values)
+    a, b, g = (np.ascontiguousarray(inst[k]) for k in ("alphas", "betas", "gammas"))
+    args = _lib.GlQuotientArgs(bufs["wires"].ptr, bufs["cs"].ptr, bufs["zs"].ptr, ed.NUM_WIRES, ed.CONSTANTS_SIGMAS_LEAF_LEN,
+                               ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN, bufs["k_is"].ptr, None, b.ctypes.data, g.ctypes.data, a.ctypes.data,
+                               ed.NUM_CONSTANTS, ed.NUM_ROUTED_WIRES, 2, ed.NUM_GATE_CONSTRAINTS, 10, ed.RATE_BITS,
+                               ed.QUOTIENT_DEGREE_FACTOR, ed.COSET_SHIFT, ctypes.pointer(prog.struct), 0, None, None, None)
+    out = pg.DeviceBuffer(gpu, 2 * inst["n_ext"])
+    _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, gpu.ptr)
+    assert (out.download().reshape(2, -1) == got).all()
+
+
+@pytest.mark.gpu
+def test_reference_symbol_rejects_other_shapes(gpu):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib, ed25519_circuit as ed
+
+    n_ext = 8 << ed.RATE_BITS
+    big = pg.DeviceBuffer(gpu, n_ext * 256)
+    sl = lambda count: _lib.GlDataSlice(big.ptr, count)  # noqa: E731
+    good = dict(poly_num=234, n=8, log_len=3, rate_bits=3, zs=sl(n_ext * 20), cs=sl(n_ext * 88), k_is=sl(80), al=sl(2), be=sl(2), ga=sl(2))
+
+    def call(**kw):
+        import ctypes
+
+        c = dict(good, **kw)
+        ref = ctypes.addressof
+        _lib.call("compute_quotient_polys", big.ptr, c["poly_num"], c["n"], c["log_len"], None, None, c["rate_bits"], 0, ref(c["zs"]),
+                  ref(c["cs"]), big.ptr, big.ptr, None, None, None, ref(c["k_is"]), ref(c["al"]), ref(c["be"]), ref(c["ga"]), gpu.ptr)
+
+    for bad in (dict(poly_num=135), dict(rate_bits=2), dict(n=16), dict(cs=sl(n_ext * 87)), dict(zs=sl(n_ext * 21)), dict(al=sl(3)),
+                dict(k_is=sl(79)), dict(log_len=22, n=1 << 22)):
+        with pytest.raises(pg.Plonky2HipError) as e:
+            call(**bad)
+        assert e.value.code == pg.GL_E_INVALID, bad

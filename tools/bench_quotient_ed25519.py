@@ -14,16 +14,7 @@ import numpy as np  # noqa: E402
 import plonky2_gpu_amd as pg  # noqa: E402
 from plonky2_gpu_amd import gate_program as gp  # noqa: E402
 
-GATES = [("noop", None), ("constant", 2), ("public_input", None), ("base_sum", (2, 32)), ("base_sum", (2, 63)), ("arithmetic", 20),
-         ("base_sum", (4, 16)), ("comparison", (32, 16)),
-         ("u32_add_many", (0, 11)), ("u32_add_many", (11, 5)), ("u32_add_many", (13, 5)), ("u32_add_many", (15, 4)),
-         ("u32_add_many", (16, 4)), ("u32_add_many", (2, 10)), ("u32_add_many", (3, 9)), ("u32_add_many", (5, 9)),
-         ("u32_add_many", (7, 8)), ("u32_add_many", (9, 6)),
-         ("u32_arithmetic", 6), ("u32_range_check", 0), ("u32_range_check", 1), ("u32_range_check", 8), ("u32_subtraction", 11),
-         ("random_access", (4, 4, 2)), ("poseidon", None)]
-GROUPS = [(0, 6), (6, 11), (11, 16), (16, 21), (21, 24), (24, 25)]
-SELECTOR_INDICES = [0] * 6 + [1] * 5 + [2] * 5 + [3] * 5 + [4] * 3 + [5]
-NUM_GATE_CONSTRAINTS = 231
+from plonky2_gpu_amd.ed25519_circuit import GATES, GROUPS, NUM_GATE_CONSTRAINTS, SELECTOR_INDICES  # noqa: E402
 
 
 def rand_cols(rng, cols, n):
@@ -44,9 +35,10 @@ def main():
     t = time.perf_counter()
     prog.compile(NUM_GATE_CONSTRAINTS, 2)
     compile_s = time.perf_counter() - t
-    wires = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 234, n), 3, False, 4, leaf_major=False)
-    cs = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 88, n), 3, False, 4, leaf_major=False)
-    zs = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 20, n), 3, False, 4, leaf_major=False)
+    # leaf_major=True: the commitments also keep the leaf-major copy, the layout the reference's symbol reads
+    wires = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 234, n), 3, False, 4, leaf_major=True)
+    cs = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 88, n), 3, False, 4, leaf_major=True)
+    zs = pg.PolynomialBatch.from_values(ctx, rand_cols(rng, 20, n), 3, False, 4, leaf_major=True)
     d_k = pg.DeviceBuffer.from_host(ctx, np.array([pow(7, j, pg.P) for j in range(80)], dtype=np.uint64))
     ch = [int(x) for x in rng.integers(1, pg.P, size=6, dtype=np.uint64)]
 
@@ -65,6 +57,23 @@ def main():
                         f"234 wires / 80 routed / 8 constants, LDE 2^{db + 3}, random data",
                gate_program_instructions=n_instr, immediates=len(pool.values), hiprtc_compile_s=round(compile_s, 1),
                kernel_source_bytes=len(prog.kernel_source()), compiled_ms=round(min(times[1:]), 3))
+    # the reference's own symbol `compute_quotient_polys` on the same data: circuit compiled into the library,
+    # LEAF-MAJOR reads (its contract), challenges in device memory
+    up = lambda v: pg.DeviceBuffer.from_host(ctx, np.array(v, dtype=np.uint64))  # noqa: E731
+    d_be, d_ga, d_al = up(ch[0:2]), up(ch[2:4]), up(ch[4:6])
+    pg.reference_set_public_inputs_hash([1, 2, 3, 4])
+    sym = []
+    for _ in range(reps + 1):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        d_sym = pg.reference_compute_quotient_polys(ctx, wires.merkle_tree.d_leaves, db, zs.merkle_tree.d_leaves, cs.merkle_tree.d_leaves,
+                                                    d_k, d_al, d_be, d_ga)
+        ctx.synchronize()
+        sym.append((time.perf_counter() - t0) * 1e3)
+    pg.reference_set_public_inputs_hash(None)
+    out["reference_symbol_leaf_major_ms"] = round(min(sym[1:]), 3)
+    out["reference_symbol_first_call_ms"] = round(sym[0], 1)
+    out["reference_symbol_equals_generic"] = bool((d_sym.download() == d_jit.download()).all())
     if interp:
         kernel, prog.kernel = prog.kernel, None  # same programs through the interpreter
         ms, d_int = run(prog)
