@@ -21,9 +21,10 @@
  *     gl_merkle_open_batch and gl_fri_proof_of_work stage through. Because that workspace is
  *     shared, drive each device from ONE host thread / context at a time (the reference's callers
  *     are single-threaded and synchronous, oracle.rs:394-422); use one process per GPU for more.
- *     Two entry points do allocate device memory themselves, because their job is to own a whole
- *     computation: gl_circuit_create (the preprocessed commitment, freed by gl_circuit_destroy) and
- *     gl_prove (every buffer of one proof, freed before it returns).
+ *     Three entry points do allocate device memory themselves: gl_circuit_create (the preprocessed
+ *     commitment, freed by gl_circuit_destroy) and gl_prove (every buffer of one proof), because their
+ *     job is to own a whole computation, and the reference symbol compute_quotient_polys (a staging
+ *     buffer, see there; gl_reference_quotient_release).
  *   - Errors are returned BY VALUE as {code, message}; code 0 = success; `message` is
  *     malloc'ed (strdup) and owned by the caller, who frees it with free() — the convention of
  *     cuda/src/lib.rs:21-35 / cuda/plonky2_gpu.cu:19-31.
@@ -384,8 +385,14 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
  * own compilation cache (~/.cache/comgr, on by default) has seen the source, immediate from
  * $PLONKY2_HIP_KERNEL_CACHE. gl_reference_quotient_prepare() does it ahead of the first proof.
  * The reference also compiles in the hash of one proof's public inputs (plonky2_gpu.cu:686-689); the same value is
- * the default here, and gl_reference_set_public_inputs_hash() replaces it (process-wide; NULL restores the default). */
+ * the default here, and gl_reference_set_public_inputs_hash() replaces it (process-wide; NULL restores the default).
+ * Device memory: the kernels read column-major data 2.5x faster than leaf-major rows (a 1872-byte stride between
+ * the lanes of a wave), so the call first transposes the three inputs into a staging buffer the LIBRARY owns —
+ * (234 + salt_size + 88 + 20) * n_ext * 8 bytes per device (5.7 GB at log_len 18), allocated on first use, kept for
+ * the next proof, freed by gl_reference_quotient_release(). If it cannot be allocated, or with
+ * PLONKY2_HIP_REFERENCE_IN_PLACE=1 in the environment, the rows are read in place (same result, slower). */
 GlError gl_reference_quotient_prepare(void *ctx);
+GlError gl_reference_quotient_release(void);
 GlError gl_reference_set_public_inputs_hash(const uint64_t *h_hash /* 4, host */);
 GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly,
                                int log_len, const uint64_t *d_root_table2, const uint64_t *d_shift_inv_powers,

@@ -165,6 +165,7 @@ SIGNATURES = {
     "build_merkle_tree": (GlError, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "compute_quotient_polys": (GlError, [_vp, _i, _i, _i, _vp, _vp, _i, _i] + [_vp] * 12),
     "gl_reference_quotient_prepare": (GlError, [_vp]),
+    "gl_reference_quotient_release": (GlError, []),
     "gl_reference_set_public_inputs_hash": (GlError, [_vp]),
     "cudaGetErrorString": (ctypes.c_char_p, [_i]),
 }

@@ -52,6 +52,8 @@ struct DeviceState {
     uint64_t coset_tick = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     GateKernel *ed25519_kernel = nullptr;  // the reference symbol compute_quotient_polys' circuit, built on first use
+    uint64_t *ref_staging = nullptr;       // its column-major staging copy of the three leaf-major inputs
+    uint64_t ref_staging_elems = 0;
 };
 constexpr size_t COSET_CACHE_ENTRIES = 64;  // a prover uses a handful (one shift, a few sizes); 80 KiB each at 2^18 x 8
 std::mutex g_mu;
@@ -790,6 +792,43 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
     return ok();
 }
 
+// Column-major staging for compute_quotient_polys: the reference's contract hands over LEAF-MAJOR rows, which the
+// quotient kernels read with the row length (1872 B for the wires) as the stride between the lanes of a wave;
+// transposing first (streaming, through LDS tiles) and reading column-major is 2x faster end to end. One buffer per
+// device, grown on demand, given back by gl_reference_quotient_release(). nullptr = could not allocate, or
+// PLONKY2_HIP_REFERENCE_IN_PLACE=1: read the rows in place.
+uint64_t *get_ref_staging(uint64_t elems) {
+    if (const char *v = getenv("PLONKY2_HIP_REFERENCE_IN_PLACE"))
+        if (v[0] && v[0] != '0') return nullptr;  // the caller would rather not have the staging buffer
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (st.ref_staging_elems < elems) {
+        if (st.ref_staging) (void)hipFree(st.ref_staging);  // synchronises the device: nothing in flight reads it
+        st.ref_staging = nullptr;
+        st.ref_staging_elems = 0;
+        if (hipMalloc(&st.ref_staging, elems * sizeof(uint64_t)) != hipSuccess) {
+            (void)hipGetLastError();  // not an error of the call: fall back to reading the rows in place
+            st.ref_staging = nullptr;
+            return nullptr;
+        }
+        st.ref_staging_elems = elems;
+    }
+    return st.ref_staging;
+}
+
+GlError gl_reference_quotient_release(void) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ref_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (st.ref_staging) HIP_TRY(hipFree(st.ref_staging));
+    st.ref_staging = nullptr;
+    st.ref_staging_elems = 0;
+    return ok();
+}
+
 GlError gl_reference_quotient_prepare(void *ctx) {
     if (!ctx) return fail(GL_E_INVALID, "null pointer");
     const GateKernel *k;
@@ -859,6 +898,14 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
     a.quotient_degree_factor = ED25519_QUOTIENT_DEGREE_FACTOR;
     a.coset_shift = 7;
     a.column_stride = 0;
+    if (uint64_t *stage = get_ref_staging((uint64_t)(a.wires_leaf_len + a.constants_sigmas_leaf_len + a.zs_partial_products_leaf_len) * n_ext)) {
+        uint64_t *w = stage, *c = w + (uint64_t)a.wires_leaf_len * n_ext, *z = c + (uint64_t)a.constants_sigmas_leaf_len * n_ext;
+        HIP_TRY(transpose_to_column_major(a.d_wires_leaves, w, a.wires_leaf_len, n_ext, n_ext, S(ctx)->stream));
+        HIP_TRY(transpose_to_column_major(a.d_constants_sigmas_leaves, c, a.constants_sigmas_leaf_len, n_ext, n_ext, S(ctx)->stream));
+        HIP_TRY(transpose_to_column_major(a.d_zs_partial_products_leaves, z, a.zs_partial_products_leaf_len, n_ext, n_ext, S(ctx)->stream));
+        a.d_wires_leaves = w, a.d_constants_sigmas_leaves = c, a.d_zs_partial_products_leaves = z;
+        a.column_stride = n_ext;
+    }
     a.gate_kernel = kernel;
     a.h_public_inputs_hash = pih;
     a.d_gate_workspace = static_cast<uint64_t *>(d_outs);  // [2][n_ext]: the reference's scratch for the same stage

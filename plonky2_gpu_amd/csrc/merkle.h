@@ -23,5 +23,8 @@ hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64
 // cols[c*col_stride + r] -> rows[r*n_cols + c]
 hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
                                    uint64_t col_stride, hipStream_t stream);
+// rows[r*n_cols + c] -> cols[c*col_stride + r]
+hipError_t transpose_to_column_major(const uint64_t *rows, uint64_t *cols, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
+                                     hipStream_t stream);
 
 }  // namespace plonky2_hip

@@ -228,6 +228,28 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint64_t *__restri
     }
 }
 
+// The way back: [n_rows][n_cols] leaf-major -> [n_cols][col_stride] column-major, same tile, same access widths.
+__global__ __launch_bounds__(256) void transpose_back_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols,
+                                                             uint32_t n_cols, uint64_t n_rows, uint64_t col_stride) {
+    __shared__ uint64_t tile[TP][TP + 1];
+    uint64_t r0 = (uint64_t)blockIdx.x * TP;
+    uint32_t c0 = blockIdx.y * TP;
+    uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < TP; k += 4) {
+        uint64_t r = r0 + ty + k;
+        uint32_t c = c0 + tx;
+        if (c < n_cols && r < n_rows) tile[ty + k][tx] = rows[r * n_cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TP; k += 4) {
+        uint32_t c = c0 + ty + k;
+        uint64_t r = r0 + tx;
+        if (c < n_cols && r < n_rows) cols[(uint64_t)c * col_stride + r] = tile[tx][ty + k];
+    }
+}
+
 unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 // per-device tables of the cooperative permutation, built on first use
@@ -339,6 +361,14 @@ hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64
     const uint64_t subtree_digests = 2 * ((n_leaves >> cap_height) - 1);
     hipLaunchKernelGGL(merkle_open_kernel, dim3(count), dim3(64), 0, stream, leaves, row_stride, elem_stride, leaf_len, digests, num_layers,
                        subtree_digests, d_idx, out_leaves, out_sib);
+    return hipGetLastError();
+}
+
+hipError_t transpose_to_column_major(const uint64_t *rows, uint64_t *cols, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
+                                     hipStream_t stream) {
+    if (n_cols == 0 || n_rows == 0) return hipSuccess;
+    dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
+    hipLaunchKernelGGL(transpose_back_kernel, grid, dim3(256), 0, stream, rows, cols, n_cols, n_rows, col_stride);
     return hipGetLastError();
 }
 

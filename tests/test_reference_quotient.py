@@ -56,6 +56,12 @@ def run_symbol(gpu, inst):
     return out.download().reshape(2, inst["n_ext"]), bufs
 
 
+def _lib_call_release():
+    from plonky2_gpu_amd import _lib
+
+    _lib.call("gl_reference_quotient_release")
+
+
 def oracle_quotient(inst, pih):
     from oracle import plonk_ref, prove_ref, pyref
     from plonky2_gpu_amd import ed25519_circuit as ed
@@ -94,6 +100,17 @@ def test_reference_symbol_equals_the_oracle(gpu, log_len):
     assert (got2 == np.array(oracle_quotient(inst, other), dtype=np.uint64)).all()
     again, _ = run_symbol(gpu, inst)  # default restored
     assert (again == got).all()
+    # the two ways of reading the leaf-major inputs: through the library's column-major staging buffer (default)
+    # and in place
+    os.environ["PLONKY2_HIP_REFERENCE_IN_PLACE"] = "1"
+    try:
+        in_place, _ = run_symbol(gpu, inst)
+    finally:
+        del os.environ["PLONKY2_HIP_REFERENCE_IN_PLACE"]
+    assert (in_place == got).all()
+    _lib_call_release()
+    after_release, _ = run_symbol(gpu, inst)  # the staging buffer comes back on demand
+    assert (after_release == got).all()
 
 
 @pytest.mark.gpu
