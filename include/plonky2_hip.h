@@ -383,7 +383,9 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
  * (csrc/ed25519_gate_program.inc). The first call on a device builds that kernel with hiprtc: about a minute
  * of single-threaded compilation when nothing is cached (72 s measured on the build container), about 2 s when ROCm's
  * own compilation cache (~/.cache/comgr, on by default) has seen the source, immediate from
- * $PLONKY2_HIP_KERNEL_CACHE. gl_reference_quotient_prepare() does it ahead of the first proof.
+ * $PLONKY2_HIP_KERNEL_CACHE or, when that is unset, from the directory kernel_cache/ next to this library, where the
+ * build (__graft_entry__.build()) puts the precompiled code object. gl_reference_quotient_prepare() does it ahead of
+ * the first proof.
  * The reference also compiles in the hash of one proof's public inputs (plonky2_gpu.cu:686-689); the same value is
  * the default here, and gl_reference_set_public_inputs_hash() replaces it (process-wide; NULL restores the default).
  * Device memory: the kernels read column-major data 2.5x faster than leaf-major rows (a 1872-byte stride between

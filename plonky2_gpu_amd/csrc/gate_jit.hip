@@ -19,6 +19,9 @@
 
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -36,6 +39,20 @@ const char *const GL_FIELD_SRC =
 
 enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK };
 constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
+
+// Where compiled code objects are kept: $PLONKY2_HIP_KERNEL_CACHE (empty = no cache), else the directory
+// `kernel_cache` next to this shared library if it exists — the place __graft_entry__.build() precompiles the
+// compiled-in ed25519 gate kernel into, so that it ships with the library like any ahead-of-time kernel.
+std::string kernel_cache_dir() {
+    if (const char *dir = getenv("PLONKY2_HIP_KERNEL_CACHE")) return dir;
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void *>(&kernel_cache_dir), &info) || !info.dli_fname) return "";
+    std::string lib(info.dli_fname);
+    size_t slash = lib.rfind('/');
+    std::string dir = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/kernel_cache";
+    struct stat st;
+    return (stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) ? dir : "";
+}
 }  // namespace
 
 struct GateKernel {
@@ -150,16 +167,16 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         delete k;
         return nullptr;
     }
-    // Optional on-disk cache (PLONKY2_HIP_KERNEL_CACHE=<dir>): the code object is keyed by a hash of the
-    // generated source, so a circuit is compiled once per machine instead of once per process; the
-    // source is stored next to it for inspection.
+    // On-disk cache (kernel_cache_dir()): the code object is keyed by a hash of the generated source, so a
+    // circuit is compiled once per machine instead of once per process; the source is stored next to it for
+    // inspection.
     std::string cache_path;
-    if (const char *dir = getenv("PLONKY2_HIP_KERNEL_CACHE")) {
+    if (std::string dir = kernel_cache_dir(); !dir.empty()) {
         uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
         for (unsigned char ch : k->source) h = (h ^ ch) * 0x100000001b3ull;
         char name[64];
         snprintf(name, sizeof name, "/gate_%016llx", (unsigned long long)h);
-        cache_path = std::string(dir) + name;
+        cache_path = dir + name;
     }
     std::vector<char> code;
     if (!cache_path.empty()) {

@@ -173,6 +173,33 @@ def test_a_2e14_row_proof_is_accepted_by_the_oracle_verifier(gpu):
         prove_ref.verify(vc, pg.serialization.proof_from_bytes(bytes(bad), circuit))
 
 
+def test_synthetic_circuit_with_the_ed25519_gate_table_proof_bytes(gpu):
+    """The kind of circuit bench.py proves (tools/synth_circuit.py gate_table="ed25519": all 25 gates of the ed25519
+    table declared, four kinds instantiated) at 2^4 rows: gl_prove's bytes equal the oracle prover's, with the gates
+    run-time compiled and interpreted."""
+    import os
+    import sys
+
+    import plonky2_gpu_amd as pg
+    from oracle import pyref, serialize_ref
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import synth_circuit
+
+    fp = dict(rate_bits=3, cap_height=1, reduction_arity_bits=[2], proof_of_work_bits=2, num_query_rounds=2)
+    circuit, wires, pis = synth_circuit.make(4, num_wires=234, num_routed=80, num_constants=8, seed=6, fri_params=fp, gate_table="ed25519")
+    synth_circuit.set_public_input_row(wires, pyref.hash_no_pad(pis))
+    oc = dict(circuit, constants=[[int(v) for v in c] for c in circuit["constants"]], sigmas=[[int(v) for v in c] for c in circuit["sigmas"]])
+    oc["constants_sigmas"] = prove_ref.commit_from_values(oc["constants"] + oc["sigmas"], 3, 1)
+    oc["circuit_digest"] = prove_ref.circuit_digest(oc["constants_sigmas"]["cap"], 4)
+    exp = serialize_ref.proof_bytes(prove_ref.prove(oc, [[int(v) for v in c] for c in wires], pis))
+    for compile_gates in (True, False):
+        nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+        assert nc.circuit_digest == oc["circuit_digest"]
+        assert nc.prove_bytes(wires, pis) == exp, compile_gates
+        nc.close()
+
+
 def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
     """gl_prove keeps one proof's working buffers attached to the circuit; proofs are deterministic across
     the recycled buffers (nothing depends on stale contents) and across gl_circuit_trim."""
@@ -205,8 +232,9 @@ def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import synth_circuit
 
-    circuit, wires, pis = synth_circuit.make(18, num_wires=234, num_routed=80, num_constants=8, seed=1)
+    circuit, wires, pis = synth_circuit.make(18, num_wires=234, num_routed=80, num_constants=8, seed=1, gate_table="ed25519")
     assert circuit["fri_params"]["reduction_arity_bits"] == [4, 4, 4, 4]
+    assert len(circuit["gates"]) == 25 and circuit["num_gate_constraints"] == 231  # the whole ed25519 gate table is declared
     synth_circuit.set_public_input_row(wires, hash_no_pad(gpu, pis))
     nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
     d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))

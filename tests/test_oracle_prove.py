@@ -70,6 +70,40 @@ def test_synthetic_circuit_generator_gives_a_provable_circuit():
     assert prove_ref.verify(circuit, prove_ref.prove(circuit, wires, pis))
 
 
+def test_synthetic_circuit_with_the_ed25519_gate_table_is_provable():
+    """gate_table="ed25519": the circuit declares all 25 gates of the ed25519 table (6 selector groups, 231 constraints)
+    and instantiates Noop / Constant / PublicInput / Arithmetic{20} out of it. The oracle prover's quotient must
+    divide (every declared gate is evaluated at every LDE point, the unused ones filtered out on the subgroup by
+    their selector polynomials) and the oracle verifier, which evaluates all 25 gates at zeta in the extension
+    field, must accept; a corrupted arithmetic output must not survive."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import synth_circuit
+
+    from plonky2_gpu_amd import ed25519_circuit as ed
+
+    fp = dict(rate_bits=3, cap_height=1, reduction_arity_bits=[2], proof_of_work_bits=2, num_query_rounds=2)
+    circuit, wires, pis = synth_circuit.make(4, num_wires=234, num_routed=80, num_constants=8, seed=6, fri_params=fp, gate_table="ed25519")
+    assert circuit["gates"] == ed.GATES and circuit["num_gate_constraints"] == 231 and len(circuit["groups"]) == 6
+    used = sorted(set(int(v) for v in circuit["constants"][0]))
+    assert set(used) <= {0, 1, 2, 5} and 5 in used
+    assert all(int(v) == synth_circuit.UNUSED_SELECTOR for c in circuit["constants"][1:6] for v in c)
+    synth_circuit.set_public_input_row(wires, pyref.hash_no_pad(pis))
+    circuit["constants"] = [[int(v) for v in c] for c in circuit["constants"]]
+    circuit["sigmas"] = [[int(v) for v in c] for c in circuit["sigmas"]]
+    wires = [[int(v) for v in c] for c in wires]
+    circuit["constants_sigmas"] = prove_ref.commit_from_values(circuit["constants"] + circuit["sigmas"], 3, 1)
+    circuit["circuit_digest"] = prove_ref.circuit_digest(circuit["constants_sigmas"]["cap"], 4)
+    assert prove_ref.verify(circuit, prove_ref.prove(circuit, wires, pis))
+    row = circuit["constants"][0].index(5)  # an arithmetic row: break its first output
+    bad = [list(c) for c in wires]
+    bad[3][row] = (bad[3][row] + 1) % P
+    with pytest.raises(AssertionError):
+        prove_ref.verify(circuit, prove_ref.prove(circuit, bad, pis))
+
+
 def test_full_gate_list_prove_then_verify():
     """every gate kind of the ed25519 gate list in one circuit (tests/plonk_instance.make_full_circuit)"""
     from plonk_instance import make_full_circuit

@@ -2,10 +2,12 @@
 config 4: n = 2^18, 234 wires / 80 routed, 88 preprocessed polynomials, 2 challenges, rate 8,
 cap_height 4, FRI arities [4,4,4,4], 28 queries, 16 PoW bits). A proof of exactly this shape is checked
 by the oracle's verifier in tests/test_gpu_prove.py (tools/ do not use oracle/); verify=1 here only checks
-the wire-format round trip. The ed25519 circuit itself needs the Rust toolchain; the gate set here is
-Noop/Constant/PublicInput/Arithmetic{20}, so the gate-constraint part of the quotient stage is lighter
-than ed25519's 231-constraint gate list — every other stage runs at the real shape.
-usage: python tools/bench_prove.py [degree_bits=18] [num_wires=234] [reps=3] [verify=1] [native=1]
+the wire-format round trip. The ed25519 circuit itself needs the Rust toolchain: the ROWS here use
+Noop/Constant/PublicInput/Arithmetic{20} only, but the circuit's gate LIST is the real one by default, and the list is
+what the quotient stage's cost depends on — every stage runs at the real shape and cost.
+usage: python tools/bench_prove.py [degree_bits=18] [num_wires=234] [reps=3] [verify=1] [native=1] [gate_table=ed25519|mini]
+gate_table=ed25519 (default at 234 wires): the circuit declares the ed25519 circuit's whole 25-gate table, so the quotient
+stage costs what the real circuit's does (tools/synth_circuit.py); mini: only the four instantiated kinds.
 native=1 times gl_prove (the library's own C++ prover, csrc/prove.hip); native=0 the Python host mirror."""
 import json
 import os
@@ -27,9 +29,10 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     verify = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     native = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    table = sys.argv[6] if len(sys.argv) > 6 else ("ed25519" if num_wires == 234 else "mini")
     ctx = pg.Context(0)
     t = time.perf_counter()
-    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=num_wires, num_routed=80, num_constants=8, seed=1)
+    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=num_wires, num_routed=80, num_constants=8, seed=1, gate_table=table)
     synth_circuit.set_public_input_row(wires, hash_no_pad(ctx, pis))
     gen_s = time.perf_counter() - t
     t = time.perf_counter()
@@ -79,7 +82,8 @@ def main():
     if native:
         proof = pg.serialization.proof_from_bytes(data, circuit)
     best = min(runs, key=lambda d: d["total"])
-    out = dict(workload=f"prove() synthetic circuit n=2^{degree_bits} wires={num_wires} routed=80 preprocessed=88 gates=noop/const/pi/arith20",
+    out = dict(workload=f"prove() synthetic circuit n=2^{degree_bits} wires={num_wires} routed=80 preprocessed=88 gate_table={table} "
+                        f"({len(circuit['gates'])} gates, {circuit['num_gate_constraints']} constraints; rows use noop/const/pi/arith20)",
                reps=reps, witness_gen_s=round(gen_s, 2), circuit_build_s=round(build_s, 2),
                witness_h2d_ms=round(min(h2d), 3), witness_MiB=round(wires.size * 8 / 2**20, 1),
                best_ms={k: round(v, 3) for k, v in best.items()},

@@ -1,7 +1,14 @@
 """Synthetic circuits of a given shape with a satisfying witness, generated with numpy (bench and
-large-size test support; not part of the product). Gates: Noop / Constant{2} / PublicInput /
-Arithmetic{num_routed/4} in one selector group — the gate kinds the ed25519 circuit shares with the
-table-driven quotient kernel; copy constraints are random 2-cycles between arithmetic inputs."""
+large-size test support; not part of the product). Rows instantiate Noop / Constant{2} / PublicInput /
+Arithmetic{num_routed/4}; copy constraints are random 2-cycles between arithmetic inputs.
+
+gate_table="mini": the circuit's gate list is just those four, in one selector group.
+gate_table="ed25519": the circuit DECLARES the whole 25-gate table of the plonky2-ed25519 circuit
+(plonky2_gpu_amd/ed25519_circuit.py: 6 selector groups, 231 gate constraints) and instantiates the same four kinds
+out of it. The quotient stage evaluates every gate of the list at every LDE point whichever gate a row uses (the
+selector filters vanish on the subgroup only), so its cost is exactly that of the real circuit, and the witness is
+still satisfying: the proof is valid. Selector columns follow selector_polynomials (plonk/circuit_builder.rs):
+the row's gate index in its own group's column, UNUSED_SELECTOR = 2^32 - 1 in the others."""
 import numpy as np
 
 P = 0xFFFFFFFF00000001
@@ -49,18 +56,35 @@ def subgroup(degree_bits):
     return out
 
 
-def make(degree_bits, num_wires=135, num_routed=80, num_constants=8, seed=1, num_copy_pairs=None, fri_params=None):
+UNUSED_SELECTOR = (1 << 32) - 1
+
+
+def make(degree_bits, num_wires=135, num_routed=80, num_constants=8, seed=1, num_copy_pairs=None, fri_params=None, gate_table="mini"):
     rng = np.random.default_rng(seed)
     n = 1 << degree_bits
     num_ops = num_routed // 4
     assert num_constants >= 3 and num_wires >= num_routed
+    if gate_table == "ed25519":
+        from plonky2_gpu_amd import ed25519_circuit as ed
+
+        assert (num_wires, num_routed, num_constants) == (ed.NUM_WIRES, ed.NUM_ROUTED_WIRES, ed.NUM_CONSTANTS)
+        table = dict(gates=list(ed.GATES), selector_indices=list(ed.SELECTOR_INDICES), groups=list(ed.GROUPS),
+                     num_gate_constraints=ed.NUM_GATE_CONSTRAINTS)
+        arith_row, first_const = 5, len(ed.GROUPS)  # ArithmeticGate{20} is entry 5; gate constants follow the 6 selectors
+        assert ed.GATES[arith_row] == ("arithmetic", num_ops) and ed.GATES[1] == ("constant", 2)
+    else:
+        assert gate_table == "mini"
+        table = dict(gates=[("noop", None), ("constant", 2), ("public_input", None), ("arithmetic", num_ops)],
+                     selector_indices=[0, 0, 0, 0], groups=[(0, 4)], num_gate_constraints=max(num_ops, 4))
+        arith_row, first_const = 3, 1
     public_inputs = [int(x) for x in np_random(rng, 3)]
     k_is = [pow(7, j, P) for j in range(num_routed)]
     row_gate = rng.choice(np.array([0, 1, 3, 3, 3, 3], dtype=np.int64), size=n)
     row_gate[0] = 2
     constants = np_random(rng, (num_constants, n))
-    constants[0] = row_gate.astype(np.uint64)  # the selector column
-    c0, c1 = constants[1], constants[2]
+    constants[0] = np.where(row_gate == 3, arith_row, row_gate).astype(np.uint64)  # the selector column of group 0
+    constants[1:first_const] = np.uint64(UNUSED_SELECTOR)  # no row uses a gate of the other groups
+    c0, c1 = constants[first_const], constants[first_const + 1]
     wires = np_random(rng, (num_wires, n))
     arith_rows = np.flatnonzero(row_gate == 3)
     # copy constraints: disjoint random pairs of arithmetic input cells
@@ -83,9 +107,7 @@ def make(degree_bits, num_wires=135, num_routed=80, num_constants=8, seed=1, num
     const_rows = np.flatnonzero(row_gate == 1)
     wires[0, const_rows], wires[1, const_rows] = c0[const_rows], c1[const_rows]
     circuit = dict(degree_bits=degree_bits, num_wires=num_wires, num_routed_wires=num_routed, num_constants=num_constants,
-                   num_challenges=2, quotient_degree_factor=8, k_is=k_is,
-                   gates=[("noop", None), ("constant", 2), ("public_input", None), ("arithmetic", num_ops)],
-                   selector_indices=[0, 0, 0, 0], groups=[(0, 4)], num_gate_constraints=max(num_ops, 4), constants=constants, sigmas=sigmas,
+                   num_challenges=2, quotient_degree_factor=8, k_is=k_is, constants=constants, sigmas=sigmas, **table,
                    fri_params=fri_params or dict(rate_bits=3, cap_height=4, reduction_arity_bits=constant_arity_bits(degree_bits, 3, 4),
                                                  proof_of_work_bits=16, num_query_rounds=28))
     return circuit, wires, public_inputs
