@@ -140,6 +140,16 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
  *   2 LOAD_PI dst<-public_inputs_hash[a]  3 LOAD_IMM dst<-d_immediates[a]
  *   4 ADD  5 SUB  6 MUL  dst<-r[a] op r[b]       7 EMIT next constraint of the gate <- r[a]
  *   8 MULK dst<-r[a] * 2^b  (b < 64; a shift in the run-time compiled kernel)
+ *   9 ACC  acc[dst] += r[a] * d_immediates[b]   (4 accumulators, dst = 0..3; the immediate must be < 2^32)
+ *  10 ACCR dst<-acc[a] mod p; acc[a]<-0
+ *     Sums with small constant weights without a modular step per term — limb recombinations sum limb_j * B^j,
+ *     MDS rows — the way plonky2 computes its MDS layer on x86 (hash/poseidon.rs:34-47 uses the same split): an
+ *     accumulator is a pair of plain u64 sums over the low and the high 32-bit halves of the operands, one
+ *     32x32+64 multiply-add each per term, folded as lo + hi*2^32 mod p by ACCR. CONTRACT: between two ACCRs of an
+ *     accumulator, sum of immediates * (2^32 - 1) < 2^63, so that neither half can wrap. gl_gate_kernel_build checks
+ *     this and refuses the program otherwise; the interpreter cannot (its program is in device memory), the
+ *     emitters in plonky2_gpu_amd/gate_program.py enforce it when they generate code. Accumulators start at 0 in
+ *     every gate.
  * (64 registers). Gate g is described by GlGateDesc {row = its index in the circuit's gate list,
  * selector_index, group_start, group_end (selectors_info.groups[selector_index]), prog_start, prog_len}.
  * Constraint k of every gate accumulates into term k, multiplied by the gate's filter. */
@@ -409,7 +419,8 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
 const char *cudaGetErrorString(int code);
 
 /* Test hook: element-wise field op on device arrays (op: 0 add, 1 sub, 2 mul, 3 neg, 4 x^7,
- * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b)); output canonical. d_b may be NULL for unary ops. */
+ * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b), 8-16 internal variants, 17 a + (b mod 2^63) * 2^32); output
+ * canonical. d_b may be NULL for unary ops. */
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx);
 
 /* Library identification: "plonky2_hip <version> gfx950". */

@@ -245,6 +245,7 @@ __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, ui
         case 14: r = gl::dot_finish_generic(dotacc_from(0, x, y)); break;
         case 15: r = gl::dot_finish(dotacc_from(1, x, y)); break;
         case 16: r = gl::dot_finish_generic(dotacc_from(1, x, y)); break;
+        case 17: r = gl::fold96(x, y & 0x7FFFFFFFFFFFFFFFull); break;  // x + (y mod 2^63) * 2^32: the ACC accumulators' fold
         default: r = x; break;
     }
     out[i] = (op >= 8 && op <= 12) ? r : gl::canon(r);  // canonical-domain ops must already be canonical

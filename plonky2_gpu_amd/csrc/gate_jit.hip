@@ -37,7 +37,7 @@ const char *const GL_FIELD_SRC =
 #include "build/gl_field_src.inc"
     ;
 
-enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK };
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK, GP_ACC, GP_ACCR };
 constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
 
 // Where compiled code objects are kept: $PLONKY2_HIP_KERNEL_CACHE (empty = no cache), else the directory
@@ -92,7 +92,17 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
         // challenge, one reduction per gate (gl::DotAcc) instead of a multiply-reduce-add per constraint
         o << "  gl::DotAcc ga[NCH];\n";
         bool used[MAX_REGS] = {};
-        for (uint32_t pc = ps; pc < ps + pl; pc++) used[instrs[4 * pc + 1] & (MAX_REGS - 1)] = true;
+        bool acc_used[4] = {};
+        for (uint32_t pc = ps; pc < ps + pl; pc++) {
+            if (instrs[4 * pc] == GP_ACC)  // its dst field names an accumulator, not a register
+                acc_used[instrs[4 * pc + 1] & 3] = true;
+            else
+                used[instrs[4 * pc + 1] & (MAX_REGS - 1)] = true;
+        }
+        for (int q = 0; q < 4; q++)
+            if (acc_used[q]) o << "  uint64_t acc" << q << "l = 0, acc" << q << "h = 0;\n";
+        // worst case of each accumulator half: sum of imm * (2^32 - 1) since its last ACCR; gl::fold96 needs < 2^63
+        unsigned __int128 acc_bound[4] = {0, 0, 0, 0};
         for (uint32_t r = 0; r < MAX_REGS; r++)
             if (used[r]) o << "  uint64_t r" << r << " = 0;\n";
         uint32_t k = 0;
@@ -128,6 +138,31 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                     if (k < ngc) o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga[c], r" << ra << ", g_apow[c * NGC + " << k << "]);\n";
                     k++;
                     break;
+                case GP_ACC: {  // acc[dst] += r[a] * imm[b]: two 32x32+64 multiply-adds, no modular step
+                    const uint32_t q = instrs[4 * pc + 1] & 3;
+                    if (!used[ra] || b >= num_imms || imms[b] > 0xFFFFFFFFull) {
+                        *error = "ACC: register read before any write, or the immediate is missing / not below 2^32";
+                        return "";
+                    }
+                    acc_bound[q] += (unsigned __int128)imms[b] * 0xFFFFFFFFull;
+                    if (acc_bound[q] >> 63) {
+                        *error = "ACC: the accumulator could reach 2^63 before its ACCR";
+                        return "";
+                    }
+                    o << "  acc" << q << "l += (uint64_t)(uint32_t)r" << ra << " * " << imms[b] << "u; acc" << q << "h += (uint64_t)(uint32_t)(r" << ra << " >> 32) * "
+                      << imms[b] << "u;\n";
+                    break;
+                }
+                case GP_ACCR: {  // r[dst] = acc[a] mod p; acc[a] = 0
+                    const uint32_t q = a & 3;
+                    if (!acc_used[q]) {
+                        *error = "ACCR of an accumulator nothing was added to";
+                        return "";
+                    }
+                    o << "  r" << dst << " = gl::fold96(acc" << q << "l, acc" << q << "h); acc" << q << "l = 0; acc" << q << "h = 0;\n";
+                    acc_bound[q] = 0;
+                    break;
+                }
                 case GP_MULK:
                     if (!used[ra] || b >= 96) {
                         *error = "MULK: register read before any write, or shift >= 96";

@@ -490,8 +490,9 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
     return mul(x3, x4);
 }
 
-// al + ah*2^32 (mod p) for al, ah < 2^63 with ah < 2^43 — the two 64-bit column sums of an MDS row
-// (poseidon.cuh). The compiler's version of "fold into (lo64, hi32), then reduce96" is ~18 issue
+// al + ah*2^32 (mod p) for any al and ah < 2^63 — the two 64-bit column sums of an MDS row (poseidon.cuh) and of
+// the gate programs' ACC accumulators. (h = ah.hi + carry <= 2^31, so after the one possible wrap of
+// l + h*(2^32 - 1) the value is below h*2^32 <= 2^63 and adding 2^32 - 1 cannot wrap again.) The compiler's version of "fold into (lo64, hi32), then reduce96" is ~18 issue
 // slots of double-pumped 64-bit compares and adds; with the carry flags it is 7 single instructions:
 //   l = al + (ah << 32)  ->  l.hi = al.hi + ah.lo (carry c), h = ah.hi + c
 //   r = l + h*(2^32 - 1) as one v_mad_u64_u32, its carry-out adds 2^32 - 1 once more (cannot carry again).

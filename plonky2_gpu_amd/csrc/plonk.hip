@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void perm_finalize_kernel(uint64_t *out, const
 // the circuit is a small register program (see plonky2_gpu_amd/gate_program.py for the instruction set);
 // all lanes of a wavefront execute the same instruction stream, so the interpreter does not diverge.
 constexpr int GP_MAX_REGS = 64, GP_MAX_CONSTRAINTS = 256;
-enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK };
+enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK, GP_ACC, GP_ACCR };
 
 struct GateProgramDev {
     const uint16_t *instrs;  // 4 x u16 per instruction: op, dst, a, b
@@ -173,6 +173,7 @@ __device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *loca
             if (i != row) filt = gl::mul(filt, gl::sub(i, s));
         if (gp.num_selectors > 1) filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));  // UNUSED_SELECTOR, selectors.rs:11
         uint32_t k = 0;
+        uint64_t acc_lo[4] = {0, 0, 0, 0}, acc_hi[4] = {0, 0, 0, 0};  // GP_ACC: plain (wrapping-free by contract) column sums
         for (uint32_t pc = ps; pc < ps + pl; pc++) {
             const uint16_t *in = gp.instrs + 4 * pc;
             const uint16_t op = in[0], dst = in[1] & (GP_MAX_REGS - 1), a = in[2], b = in[3];
@@ -185,6 +186,16 @@ __device__ void eval_gate_program(const GateProgramDev &gp, const uint64_t *loca
                 case GP_SUB: regs[dst] = gl::sub(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
                 case GP_MUL: regs[dst] = gl::mul(regs[a & (GP_MAX_REGS - 1)], regs[b & (GP_MAX_REGS - 1)]); break;
                 case GP_MULK: regs[dst] = gl::mul(regs[a & (GP_MAX_REGS - 1)], 1ull << (b & 63)); break;  // b < 64 here
+                case GP_ACC: {  // acc[dst] += r[a] * imm[b], imm < 2^32: the two 32-bit halves of r[a] in separate u64 sums
+                    const uint64_t x = regs[a & (GP_MAX_REGS - 1)], c = gp.imms[b];
+                    acc_lo[dst & 3] += (x & 0xFFFFFFFFull) * c;
+                    acc_hi[dst & 3] += (x >> 32) * c;
+                    break;
+                }
+                case GP_ACCR:  // r[dst] = acc[a] mod p; acc[a] = 0
+                    regs[dst] = gl::fold96(acc_lo[a & 3], acc_hi[a & 3]);
+                    acc_lo[a & 3] = acc_hi[a & 3] = 0;
+                    break;
                 case GP_EMIT:
                     if (k < gp.num_gate_constraints) acc[k] = gl::add(acc[k], gl::mul(filt, regs[a & (GP_MAX_REGS - 1)]));
                     k++;

@@ -15,7 +15,8 @@ Instruction = 4 x u16 {op, dst, a, b}; registers hold field elements.
 """
 import numpy as np
 
-LOAD_WIRE, LOAD_CONST, LOAD_PI, LOAD_IMM, ADD, SUB, MUL, EMIT, MULK = range(9)
+LOAD_WIRE, LOAD_CONST, LOAD_PI, LOAD_IMM, ADD, SUB, MUL, EMIT, MULK, ACC, ACCR = range(11)
+ACC_LIMIT = 1 << 63  # each half of an accumulator stays below this (gl::fold96's precondition)
 MAX_REGS = 64
 
 
@@ -47,6 +48,7 @@ class GateAsm:
         self.instrs = []
         self.pool = pool
         self._free = list(range(MAX_REGS - 1, -1, -1))
+        self._acc_bound = [0, 0, 0, 0]
 
     def _reg(self):
         if not self._free:
@@ -96,6 +98,39 @@ class GateAsm:
     def emit(self, a):
         self.instrs.append((EMIT, 0, a, 0))
 
+    def acc_fits(self, weight, q=0):
+        """may `r * weight` still be added to accumulator q without either half being able to reach 2^63?"""
+        return 0 <= weight < (1 << 32) and self._acc_bound[q] + weight * 0xFFFFFFFF < ACC_LIMIT
+
+    def acc(self, a, weight=1, q=0):
+        """acc[q] += r[a] * weight, without a modular step (ACC): weight < 2^32, bound checked here"""
+        if self.pool is None:
+            raise ValueError("this gate needs an ImmediatePool")
+        if not self.acc_fits(weight, q):
+            raise ValueError("accumulator %d could overflow: reduce (accr) earlier" % q)
+        self._acc_bound[q] += weight * 0xFFFFFFFF
+        self.instrs.append((ACC, q, a, self.pool.index(weight)))
+
+    def accr(self, q=0, dst=None):
+        """register <- acc[q] mod p; acc[q] <- 0 (ACCR)"""
+        self._acc_bound[q] = 0
+        return self.op(ACCR, q, 0, dst)
+
+    def weighted_sum(self, terms, q=0, dst=None):
+        """sum_i r[reg_i] * weight_i for (reg, weight) pairs with weights < 2^32, through accumulator q; reduces
+        in between (adding the partial sum back with weight 1) only if the static bound demands it"""
+        started = False
+        for reg, w in terms:
+            if started and not self.acc_fits(w, q):
+                part = self.accr(q)
+                self.acc(part, 1, q)
+                self.free(part)
+            self.acc(reg, w, q)
+            started = True
+        if not started:
+            return self.op(LOAD_IMM, self.pool.index(0), 0, dst)
+        return self.accr(q, dst)
+
     # -- helpers shared by several gates ---------------------------------------------------------
     def times(self, acc, base):
         """acc <- acc * base for a small integer base: a shift when base is a power of two"""
@@ -106,23 +141,46 @@ class GateAsm:
             self.mul(acc, b, dst=acc)
             self.free(b)
 
-    def reduce_with_powers(self, terms, base):
-        """sum terms[i] * base^i (plonk_common.rs:116-128) for an integer base; returns a fresh register"""
-        acc = self.imm(0)
-        for t in reversed(terms):
-            self.times(acc, base)
-            self.add(acc, t, dst=acc)
+    def reduce_with_powers(self, terms, base, wires=False, q=0):
+        """sum terms[i] * base^i (plonk_common.rs:116-128) for an integer base; returns a fresh register.
+        `terms` are registers, or with wires=True wire indices that are loaded for the purpose. The sum runs through
+        accumulator q in blocks of consecutive terms whose weights base^j stay below 2^32 and provably fit one
+        accumulation (16 base-4 limbs or 31 bits do); blocks are joined by Horner steps with base^(block length)."""
+        if not terms:
+            return self.imm(0)
+        blocks, i = [], 0
+        while i < len(terms):
+            j, bound = 0, 0
+            while i + j < len(terms) and base ** j < (1 << 32) and bound + base ** j * 0xFFFFFFFF < ACC_LIMIT:
+                bound += base ** j * 0xFFFFFFFF
+                j += 1
+            for k in range(j):
+                t = self.wire(terms[i + k]) if wires else terms[i + k]
+                self.acc(t, base ** k, q)
+                if wires:
+                    self.free(t)
+            blocks.append((self.accr(q), j))
+            i += j
+        acc = blocks[-1][0]
+        for reg, length in reversed(blocks[:-1]):
+            step = base ** length
+            if step & (step - 1) == 0 and step.bit_length() - 1 < 64:
+                self.mulk(acc, step.bit_length() - 1, dst=acc)
+            else:
+                m = self.imm(step % P)
+                self.mul(acc, m, dst=acc)
+                self.free(m)
+            self.add(acc, reg, dst=acc)
+            self.free(reg)
         return acc
 
     def range_product(self, x, small):
         """prod_{k < len(small)} (x - k); `small[k]` = register holding the constant k. The value is what
-        the reference's product computes; for four factors it is formed as y (y + 2) with y = x^2 - 3x
-        (two multiplications instead of three)."""
+        the reference's product computes; for four factors it is formed as y (y + 2) with y = x (x - 3):
+        x (x-1) (x-2) (x-3) = (x^2 - 3x) (x^2 - 3x + 2) — two multiplications instead of three."""
         if len(small) == 4:
-            y = self.mul(x, x)
-            t = self.add(x, x)
-            self.add(t, x, dst=t)
-            self.sub(y, t, dst=y)
+            t = self.sub(x, small[3])
+            y = self.mul(x, t)
             self.add(y, small[2], dst=t)
             self.mul(y, t, dst=y)
             self.free(t)
@@ -172,12 +230,7 @@ def noop_gate():
 def base_sum_gate(B, num_limbs, pool):
     """BaseSumGate<B> { num_limbs } (plonky2/src/gates/base_sum.rs:213-230)"""
     g = GateAsm(pool)
-    acc = g.imm(0)
-    for i in reversed(range(num_limbs)):  # reduce_with_powers(limbs, B)
-        g.times(acc, B)
-        t = g.wire(1 + i)
-        g.add(acc, t, dst=acc)
-        g.free(t)
+    acc = g.reduce_with_powers([1 + i for i in range(num_limbs)], B, wires=True)
     s = g.wire(0)
     g.emit(g.sub(acc, s))
     g.release()
@@ -194,15 +247,17 @@ def _u32_limb_checks(g, first_limb_wire, count, split, small):
     """range-check `count` base-4 limbs (emitting one constraint each, from the LAST limb down like the
     reference's `for j in (0..n).rev()`), and return (low, high) = the limbs below / from `split`
     recombined in base 4"""
-    low, high = g.imm(0), g.imm(0)
     for j in reversed(range(count)):
         limb = g.wire(first_limb_wire + j)
         p = g.range_product(limb, small)
         g.emit(p)
-        acc = low if j < split else high
-        g.mulk(acc, 2, dst=acc)
-        g.add(acc, limb, dst=acc)
+        if j < split:
+            g.acc(limb, 4 ** j, 0)  # the two recombinations run in accumulators 0 and 1 (at most 16 limbs each fit)
+        else:
+            g.acc(limb, 4 ** (j - split), 1)
         g.free(limb, p)
+    low = g.accr(0) if split > 0 else g.imm(0)
+    high = g.accr(1) if count > split else g.imm(0)
     return low, high
 
 
@@ -213,11 +268,18 @@ def u32_add_many_gate(num_addends, num_ops, pool):
         g.release()
         o = (num_addends + 3) * i
         small = [g.imm(k) for k in range(4)]
-        computed = g.wire(o + num_addends)
-        for j in range(num_addends):
-            t = g.wire(o + j)
-            g.add(computed, t, dst=computed)
-            g.free(t)
+        if num_addends >= 3:  # addends + carry-in: plain sums, one fold
+            for j in range(num_addends + 1):
+                t = g.wire(o + j)
+                g.acc(t, 1, 2)
+                g.free(t)
+            computed = g.accr(2)
+        else:
+            computed = g.wire(o + num_addends)
+            for j in range(num_addends):
+                t = g.wire(o + j)
+                g.add(computed, t, dst=computed)
+                g.free(t)
         res, car = g.wire(o + num_addends + 1), g.wire(o + num_addends + 2)
         comb = g.mulk(car, 32)
         g.add(comb, res, dst=comb)
@@ -298,12 +360,7 @@ def comparison_gate(num_bits, num_chunks, pool):
     cb = -(-num_bits // num_chunks)
     nc = num_chunks
     for which in (0, 1):
-        acc = g.imm(0)
-        for i in reversed(range(nc)):
-            g.times(acc, 1 << cb)
-            t = g.wire(4 + which * nc + i)
-            g.add(acc, t, dst=acc)
-            g.free(t)
+        acc = g.reduce_with_powers([4 + which * nc + i for i in range(nc)], 1 << cb, wires=True)
         inp = g.wire(which)
         g.emit(g.sub(acc, inp, dst=acc))
         g.free(acc, inp)
@@ -433,18 +490,14 @@ def poseidon_gate(pool):
         g.free(x2, x4)
 
     def mds_layer():
-        circ = [g.imm(c) for c in T["MDS_CIRC"]]
+        # row r = MDS_DIAG[r] * state[r] + sum_i MDS_CIRC[i] * state[(i + r) % 12]: thirteen weights below 64, so a
+        # row is 26 multiply-adds and one fold instead of 13 modular multiplications and 12 modular additions
         new = []
         for r in range(SW):
-            d = g.imm(T["MDS_DIAG"][r])
-            acc = g.mul(state[r], d)
-            g.free(d)
-            for i in range(SW):
-                t2 = g.mul(state[(i + r) % SW], circ[i])
-                g.add(acc, t2, dst=acc)
-                g.free(t2)
-            new.append(acc)
-        g.free(*circ)
+            terms = [(state[(i + r) % SW], T["MDS_CIRC"][i]) for i in range(SW)]
+            if T["MDS_DIAG"][r]:
+                terms.append((state[r], T["MDS_DIAG"][r]))
+            new.append(g.weighted_sum(terms))
         g.free(*state)
         state[:] = new
 

@@ -113,3 +113,22 @@ def test_dot_finish_including_its_rare_wrap_corrections(gpu):
     assert (a0 & 0xFFFFFFFF) + (((a0 >> 32) + (a1 & 0xFFFFFFFF)) << 32) < w3          # first correction
     a0, a1, a2, k0, k1, k2 = _dotacc(1, 0, 5 << 48)
     assert a0 == a1 == a2 == k0 == k1 == 0 and k2 == 5                                   # last correction: 0 - 5*2^32
+
+
+def test_fold96_over_its_whole_stated_domain(gpu):
+    """gl::fold96(al, ah) = al + ah * 2^32 mod p for ANY al and ah < 2^63 — the reduction of the gate programs' ACC
+    accumulators (and of the Poseidon kernel's MDS column sums, where ah stays below 2^43). The edge operands put the
+    inner carry, the single wrap of l + h * (2^32 - 1) and the follow-up correction at their extremes."""
+    import random
+
+    rng = random.Random(17)
+    lows = edge_operands()
+    highs = sorted(set([0, 1, 2, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, (1 << 43) - 1, 1 << 43, (1 << 62) - 1,
+                        1 << 62, (1 << 63) - (1 << 32), (1 << 63) - (1 << 32) + 1, (1 << 63) - 2, (1 << 63) - 1]
+                       + [rng.randrange(1 << 63) for _ in range(40)]))
+    pairs = list(itertools.product(lows, highs)) + [(rng.randrange(1 << 64), rng.randrange(1 << 63)) for _ in range(20000)]
+    a = np.array([p[0] for p in pairs], dtype=np.uint64)
+    b = np.array([p[1] for p in pairs], dtype=np.uint64)
+    got = run_op(gpu, 17, a, b)
+    for (x, y), g in zip(pairs, got):
+        assert g == (x + (y << 32)) % P, (hex(x), hex(y))
