@@ -76,6 +76,11 @@ GlError gl_free(void *d_ptr);
 GlError gl_malloc_host(void **h_ptr, uint64_t bytes);
 GlError gl_free_host(void *h_ptr);
 GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx);
+/* The same copy queued on ctx->stream2 WITHOUT waiting for it: with h_src page-locked (gl_malloc_host) it runs on
+ * the DMA engines while ctx->stream computes — upload the next proof's witness during gl_prove of the current one
+ * (gl_prove works on ctx->stream and waits for both streams only when it is done), then gl_ctx_synchronize()
+ * before using d_dst. The witness upload (468 MiB, 8.5 ms at the ed25519 shape) disappears from the proof period. */
+GlError gl_memcpy_h2d_async(void *d_dst, const void *h_src, uint64_t bytes, void *ctx);
 GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx);
 GlError gl_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes, void *ctx);
 GlError gl_memset_zero(void *d_dst, uint64_t bytes, void *ctx);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "gl_malloc_host": (GlError, [ctypes.POINTER(_vp), _u64]),
     "gl_free_host": (GlError, [_vp]),
     "gl_memcpy_h2d": (GlError, [_vp, _vp, _u64, _vp]),
+    "gl_memcpy_h2d_async": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2h": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2d": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memset_zero": (GlError, [_vp, _u64, _vp]),

@@ -358,6 +358,12 @@ GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx)
     return ok();
 }
 
+GlError gl_memcpy_h2d_async(void *d_dst, const void *h_src, uint64_t bytes, void *ctx) {
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(ctx)->stream2));
+    return ok();
+}
+
 GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx) {
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(ctx)->stream));

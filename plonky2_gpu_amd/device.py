@@ -57,6 +57,14 @@ class DeviceBuffer:
         if a.size:
             _lib.call("gl_memcpy_h2d", self.ptr + offset * 8, a.ctypes.data, a.size * 8, self.ctx.ptr)
 
+    def upload_async(self, pinned, offset=0):
+        """queue the copy of a PinnedArray (or a numpy array the caller keeps alive and unchanged) on the context's
+        second stream and return at once; ctx.synchronize() before the data is used"""
+        a = pinned.array if isinstance(pinned, PinnedArray) else pinned
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"] and offset + a.size <= self.n
+        if a.size:
+            _lib.call("gl_memcpy_h2d_async", self.ptr + offset * 8, a.ctypes.data, a.size * 8, self.ctx.ptr)
+
     def download(self, offset=0, count=None):
         count = self.n - offset if count is None else int(count)
         out = np.empty(count, dtype=np.uint64)

@@ -243,3 +243,31 @@ def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu):
     vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
     assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
     nc.close()
+
+
+def test_witness_upload_overlapping_a_proof(gpu):
+    """gl_memcpy_h2d_async: the next witness travels on the context's second stream while gl_prove runs on the
+    first; after ctx.synchronize() it is complete and proves to the same bytes as a witness uploaded up front, and
+    the proof that ran meanwhile is unaffected."""
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+
+    circuit, wires, pis = make_circuit(7, seed=71, two_groups=True)
+    other, wires2, pis2 = make_circuit(7, seed=72, two_groups=True)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    flat = np.ascontiguousarray(np.array(wires, dtype=np.uint64).reshape(-1))
+    expect = nc.prove_bytes(wires, pis)
+    staging = pg.PinnedArray(flat.size)
+    staging.array[:] = flat
+    d_a = pg.DeviceBuffer.from_host(gpu, np.array(wires2, dtype=np.uint64).reshape(-1))  # some other witness of the same shape
+    d_b = pg.DeviceBuffer(gpu, flat.size)
+    nc2 = pg.NativeCircuit(gpu, dict(other, circuit_digest=None))
+    meanwhile_expect = nc2.prove_bytes(d_a, pis2)
+    d_b.upload_async(staging)
+    meanwhile = nc2.prove_bytes(d_a, pis2)
+    gpu.synchronize()
+    assert meanwhile == meanwhile_expect
+    assert (d_b.download() == flat).all()
+    assert nc.prove_bytes(d_b, pis) == expect
+    staging.free()
