@@ -226,10 +226,13 @@ __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, u
 //
 // hipcc's lowering of (u128)a*b + reduce128 spends ~24 VALU instructions plus hazard padding: six
 // v_mov to build zero-extended register pairs for the v_mad_u64_u32 addends and compare/select
-// corrections built from double-pumped 64-bit ops. Here (18 VALU):
-//   product:  T = al*bl ; U = al*bh + (T>>32) ; V = ah*bl + (U.lo,0) ; W = ah*bh + (U>>32) + V.hi
-//             -> lo = (T.lo, V.lo), hi = W           (no intermediate can overflow 64 bits)
-//   reduce :  t0 = lo - hh (borrow => -= 2^32-1) ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32
+// corrections built from double-pumped 64-bit ops. Here (16 VALU):
+//   product:  T = al*bl ; U = al*bh ; V = ah*bl + U (carry c1 into an SGPR pair) ; W = ah*bh
+//             -> lo = (T.lo, T.hi + V.lo), hl = W.lo + V.hi + carry, hh = W.hi + carry   (three chained adds)
+//             No multiply-add needs a constructed addend: the only one is U, a pair a previous
+//             v_mad_u64_u32 wrote (a zero-extended half would cost a v_mov each, four in the first version).
+//             c1 has weight 2^96 = -1 (mod p), the weight of hh: it is the BORROW-IN of the subtraction below.
+//   reduce :  t0 = lo - hh - c1 (borrow => -= 2^32-1) ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32
 //             whose carry-out drives the last correction (goldilocks_field.rs:345-358).
 // No wait states are spent between a VALU instruction that writes VCC and the next one that reads it
 // (carry-in, or v_cndmask's mask): gfx950 interlocks VCC. Measured, not assumed: the schedule with and
@@ -238,20 +241,18 @@ __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, u
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
     uint32_t rl, rh;
+    uint64_t c1;
     // LLVM's AMDGPU inline asm has no sub-register operand modifier, so the 64-bit temporaries
     // whose halves are needed live in fixed registers v[116:126] (declared clobbered).
-    asm("v_mad_u64_u32 v[116:117], vcc, %2, %4, 0\n\t"          // T = al*bl
-        "v_mov_b32_e32 v125, 0\n\t"
-        "v_mov_b32_e32 v124, v117\n\t"                          // X = (T.hi, 0)
-        "v_mad_u64_u32 v[118:119], vcc, %2, %5, v[124:125]\n\t" // U = al*bh + T.hi
-        "v_mov_b32_e32 v124, v119\n\t"                          // X = (U.hi, 0)
-        "v_mad_u64_u32 v[122:123], vcc, %3, %5, v[124:125]\n\t" // W = ah*bh + U.hi
-        "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
-        "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo = (lo.hi, carry)
-        "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi   -> hi = (hl, hh) = (v122, v123)
-        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
-        "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh, lo = (v116, v120)
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
+    asm("v_mad_u64_u32 v[116:117], vcc, %3, %5, 0\n\t"          // T = al*bl
+        "v_mad_u64_u32 v[118:119], vcc, %3, %6, 0\n\t"          // U = al*bh
+        "v_mad_u64_u32 v[120:121], %2, %4, %5, v[118:119]\n\t"  // V = ah*bl + U, carry c1 (weight 2^96)
+        "v_mad_u64_u32 v[122:123], vcc, %4, %6, 0\n\t"          // W = ah*bh
+        "v_add_co_u32_e32 v117, vcc, v117, v120\n\t"            // lo.hi = T.hi + V.lo        lo = (v116, v117)
+        "v_addc_co_u32_e32 v122, vcc, v122, v121, vcc\n\t"      // hl = W.lo + V.hi + carry
+        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"         // hh = W.hi + carry (+ c1, applied next)
+        "v_subb_co_u32_e64 v116, vcc, v116, v123, %2\n\t"       // t0 = lo - hh - c1
+        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // borrow: t0 -= 2^32-1
         "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
@@ -259,9 +260,9 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
         "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
         "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
-        : "=&v"(rl), "=&v"(rh)
+        : "=&v"(rl), "=&v"(rh), "=&s"(c1)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
-        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v126");
     return pack64(rl, rh);
 }
 
