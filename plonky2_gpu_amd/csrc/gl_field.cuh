@@ -53,25 +53,35 @@ __device__ __forceinline__ uint64_t sub_generic(uint64_t a, uint64_t b) {
     return d1 - ((d1 > d) ? EPS : 0);
 }
 
-// The same two operations on the carry flag: the compiler's lowering of the `s < a` tests above is ~14
-// issue slots of double-pumped 64-bit compares and adds; these are 8 single instructions each, with the
-// reference's double wrap correction (the second one is rare but non-canonical inputs can need it).
-// VCC-carried dependencies need no wait states on gfx950 (see mul below).
+// The same two operations in hand-scheduled form. What costs on gfx950 is not the instruction count but the
+// carry-flag instructions: v_add_co / v_addc_co / v_sub_co / v_subb_co issue at ~5 cycles per wavefront, as much
+// as a v_mad_u64_u32 (~6) and twice a plain v_mov / v_xor (2.5); a flag-free 64-bit v_lshl_add_u64 is 4.4
+// (tools/ubench_issue.hip). So:
+//   - the FIRST wrap correction of a sum is one multiply-add, r = t*1 + s with t = carry ? 2^32-1 : 0, which also
+//     delivers the carry-out that says whether a second correction is needed;
+//   - the SECOND correction (the reference's double wrap, goldilocks_field.rs:203-256) can only trigger when both
+//     operands are >= p, i.e. non-canonical representatives from a window of 2^32 values: it sits behind a
+//     wave-uniform s_cbranch_vccz — a branch that is essentially never taken costs a scalar instruction, not a
+//     divergent wavefront. (A data-dependent branch that IS sometimes taken would not pay; this one does.)
+// add: 4 VALU (was 8), 26.5 cycles per wavefront (was 37.7); sub: 5 VALU, 26.6 (was 36.2) — tools/ubench_field.hip,
+// which also checks both against big integers on 4.6 M operand pairs including 200 000 with both operands >= p and
+// single-wavefront launches. VCC written by a VALU instruction and read by the next (carry-in, v_cndmask mask,
+// s_cbranch_vccz) needs no wait states on gfx950: measured, see mul below.
 __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
-    uint32_t rl, rh, t;
-    asm("v_add_co_u32_e32 %0, vcc, %3, %5\n\t"
-        "v_addc_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
-        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // overflow: 2^64 = 2^32 - 1
-        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
-        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // and once more (cannot overflow a third time)
-        "v_add_co_u32_e32 %0, vcc, %0, %2\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
-        : "=&v"(rl), "=&v"(rh), "=&v"(t)
+    uint64_t r;
+    asm("v_add_co_u32_e32 v116, vcc, %1, %3\n\t"
+        "v_addc_co_u32_e32 v117, vcc, %2, %4, vcc\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                  // overflow: 2^64 = 2^32 - 1
+        "v_mad_u64_u32 %0, vcc, v126, 1, v[116:117]\n\t"          // r = s + t, carry -> vcc
+        "s_cbranch_vccz 1f\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                  // rare: once more (cannot overflow a third time)
+        "v_mad_u64_u32 %0, vcc, v126, 1, %0\n\t"
+        "1:"
+        : "=&v"(r)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
-        : "vcc");
-    return ((uint64_t)rh << 32) | rl;
+        : "vcc", "v116", "v117", "v126");
+    return r;
 }
 
 __device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
@@ -79,12 +89,14 @@ __device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
     uint32_t rl, rh, t;
     asm("v_sub_co_u32_e32 %0, vcc, %3, %5\n\t"
         "v_subb_co_u32_e32 %1, vcc, %4, %6, vcc\n\t"
-        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"         // borrow: -2^64 = -(2^32 - 1)
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"                    // borrow: -2^64 = -(2^32 - 1)
         "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
         "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
-        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "s_cbranch_vccz 1f\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"                    // rare: once more
         "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
-        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+        "1:"
         : "=&v"(rl), "=&v"(rh), "=&v"(t)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
         : "vcc");
@@ -232,145 +244,61 @@ __device__ __forceinline__ void mul_wide(uint64_t a, uint64_t b, uint64_t &lo, u
 //             No multiply-add needs a constructed addend: the only one is U, a pair a previous
 //             v_mad_u64_u32 wrote (a zero-extended half would cost a v_mov each, four in the first version).
 //             c1 has weight 2^96 = -1 (mod p), the weight of hh: it is the BORROW-IN of the subtraction below.
-//   reduce :  t0 = lo - hh - c1 (borrow => -= 2^32-1) ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32
-//             whose carry-out drives the last correction (goldilocks_field.rs:345-358).
+//   reduce :  t0 = lo - hh - c1 ; r = t0 + hl*(2^32-1) as ONE v_mad_u64_u32 whose carry-out drives the last
+//             correction, itself one multiply-add (t*1 + r) writing the result pair (goldilocks_field.rs:345-358).
+//             The borrow of t0 (lo < hh + c1: probability ~2^-32 on real data, certain for e.g. 2^63 * 2^63) is
+//             corrected behind a wave-uniform branch, like the second correction of add/sub.
+//   12 VALU + a scalar branch, 57.9 cycles per wavefront (16 VALU: 72.7; the first version, 19 VALU: ~77).
 // No wait states are spent between a VALU instruction that writes VCC and the next one that reads it
 // (carry-in, or v_cndmask's mask): gfx950 interlocks VCC. Measured, not assumed: the schedule with and
 // without `s_nop 1` pads agrees on 4M random + all edge-operand pairs, also when a single wavefront
 // runs alone and issues back to back; explicit SGPR-pair carries (dot_term) DO need two wait states.
 __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
-    uint32_t rl, rh;
-    uint64_t c1;
+    uint64_t r, c1;
     // LLVM's AMDGPU inline asm has no sub-register operand modifier, so the 64-bit temporaries
     // whose halves are needed live in fixed registers v[116:126] (declared clobbered).
-    asm("v_mad_u64_u32 v[116:117], vcc, %3, %5, 0\n\t"          // T = al*bl
-        "v_mad_u64_u32 v[118:119], vcc, %3, %6, 0\n\t"          // U = al*bh
-        "v_mad_u64_u32 v[120:121], %2, %4, %5, v[118:119]\n\t"  // V = ah*bl + U, carry c1 (weight 2^96)
-        "v_mad_u64_u32 v[122:123], vcc, %4, %6, 0\n\t"          // W = ah*bh
+    asm("v_mad_u64_u32 v[116:117], vcc, %2, %4, 0\n\t"          // T = al*bl
+        "v_mad_u64_u32 v[118:119], vcc, %2, %5, 0\n\t"          // U = al*bh
+        "v_mad_u64_u32 v[120:121], %1, %3, %4, v[118:119]\n\t"  // V = ah*bl + U, carry c1 (weight 2^96)
+        "v_mad_u64_u32 v[122:123], vcc, %3, %5, 0\n\t"          // W = ah*bh
         "v_add_co_u32_e32 v117, vcc, v117, v120\n\t"            // lo.hi = T.hi + V.lo        lo = (v116, v117)
         "v_addc_co_u32_e32 v122, vcc, v122, v121, vcc\n\t"      // hl = W.lo + V.hi + carry
         "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"         // hh = W.hi + carry (+ c1, applied next)
-        "v_subb_co_u32_e64 v116, vcc, v116, v123, %2\n\t"       // t0 = lo - hh - c1
+        "v_subb_co_u32_e64 v116, vcc, v116, v123, %1\n\t"       // t0 = lo - hh - c1
         "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // borrow: t0 -= 2^32-1
+        "s_cbranch_vccz 1f\n\t"
+        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // rare: borrow => t0 -= 2^32-1 (cannot borrow again)
         "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
         "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+        "1:\n\t"
         "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
         "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
-        "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
-        : "=&v"(rl), "=&v"(rh), "=&s"(c1)
+        "v_mad_u64_u32 %0, vcc, v126, 1, v[116:117]"
+        : "=&v"(r), "=&s"(c1)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
         : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v126");
-    return pack64(rl, rh);
+    return r;
 }
 
 __device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
 
-// acc + x*y (goldilocks_field.rs:119-123); u64 + u64*u64 cannot overflow 128 bits.
-// Same schedule as mul(): the addend's low word rides on the first v_mad_u64_u32 and its high
-// word joins T.hi before the second one (al*bh + T.hi + c.hi <= 2^64 - 1).
-__device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) {
-    uint32_t al = (uint32_t)x, ah = (uint32_t)(x >> 32), bl = (uint32_t)y, bh = (uint32_t)(y >> 32);
-    uint32_t cl = (uint32_t)acc, ch = (uint32_t)(acc >> 32);
-    uint32_t rl, rh;
-    asm("v_mov_b32_e32 v125, 0\n\t"
-        "v_mov_b32_e32 v124, %6\n\t"                            // X = (c.lo, 0)
-        "v_mad_u64_u32 v[116:117], vcc, %2, %4, v[124:125]\n\t" // T = al*bl + c.lo
-        "v_add_co_u32_e32 v124, vcc, v117, %7\n\t"              // X = T.hi + c.hi (33 bits)
-        "v_addc_co_u32_e32 v125, vcc, 0, v125, vcc\n\t"
-        "v_mad_u64_u32 v[118:119], vcc, %2, %5, v[124:125]\n\t" // U = al*bh + X
-        "v_mov_b32_e32 v125, 0\n\t"
-        "v_mov_b32_e32 v124, v119\n\t"                          // X = (U.hi, 0)
-        "v_mad_u64_u32 v[122:123], vcc, %3, %5, v[124:125]\n\t" // W = ah*bh + U.hi
-        "v_mov_b32_e32 v124, v118\n\t"                          // X = (U.lo, 0)
-        "v_mad_u64_u32 v[120:121], vcc, %3, %4, v[124:125]\n\t" // V = ah*bl + U.lo
-        "v_add_co_u32_e32 v122, vcc, v122, v121\n\t"            // W += V.hi
-        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"
-        "v_sub_co_u32_e32 v116, vcc, v116, v123\n\t"            // t0 = lo - hh
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v120, vcc\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
-        "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
-        "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"
-        "v_add_co_u32_e32 %0, vcc, v116, v126\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
-        : "=&v"(rl), "=&v"(rh)
-        : "v"(al), "v"(ah), "v"(bl), "v"(bh), "v"(cl), "v"(ch)
-        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
-    return pack64(rl, rh);
-}
+// acc + x*y (goldilocks_field.rs:119-123): the multiplication followed by the addition, 16 VALU; the fused
+// arrangement this replaced (the addend riding on the first multiply-adds) took 22.
+__device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) { return add(acc, mul(x, y)); }
 
 // Two radix-2 butterflies at once on arbitrary representatives:
 //   s0 = a0 + c0, d0 = x0 - y0, s1 = a1 + c1, d1 = x1 - y1     (x,y = a,c or c,a when NEG)
-// with the reference's double wrap correction (goldilocks_field.rs:197-256) done on the carry
-// flags. The four carry chains are interleaved instruction by instruction, so every
-// VALU-writes-SGPR -> VALU-reads-it dependency has three independent instructions in between
-// (gfx950 needs two wait states) and no s_nop is spent; 32 VALU instructions for what the
-// compiler's compare/select lowering does in ~48 issue slots.
-#define GL_BFLY2_ASM(X0L, X0H, X1L, X1H)                                                          \
-    /* raw 64-bit sums / differences */                                                            \
-    "v_add_co_u32_e64 %0, %12, %16, %18\n\t"                                                       \
-    "v_sub_co_u32_e64 %2, %13, " X0L "\n\t"                                                        \
-    "v_add_co_u32_e64 %4, %14, %20, %22\n\t"                                                       \
-    "v_sub_co_u32_e64 %6, %15, " X1L "\n\t"                                                        \
-    "v_addc_co_u32_e64 %1, %12, %17, %19, %12\n\t"                                                 \
-    "v_subb_co_u32_e64 %3, %13, " X0H ", %13\n\t"                                                  \
-    "v_addc_co_u32_e64 %5, %14, %21, %23, %14\n\t"                                                 \
-    "v_subb_co_u32_e64 %7, %15, " X1H ", %15\n\t" /* first correction: +/- (2^32 - 1) on carry / borrow */ \
-    "v_cndmask_b32_e64 %8, 0, -1, %12\n\t"                                                         \
-    "v_cndmask_b32_e64 %9, 0, -1, %13\n\t"                                                         \
-    "v_cndmask_b32_e64 %10, 0, -1, %14\n\t"                                                        \
-    "v_cndmask_b32_e64 %11, 0, -1, %15\n\t"                                                        \
-    "v_add_co_u32_e64 %0, %12, %0, %8\n\t"                                                         \
-    "v_sub_co_u32_e64 %2, %13, %2, %9\n\t"                                                         \
-    "v_add_co_u32_e64 %4, %14, %4, %10\n\t"                                                        \
-    "v_sub_co_u32_e64 %6, %15, %6, %11\n\t"                                                        \
-    "v_addc_co_u32_e64 %1, %12, 0, %1, %12\n\t"                                                    \
-    "v_subb_co_u32_e64 %3, %13, %3, 0, %13\n\t"                                                    \
-    "v_addc_co_u32_e64 %5, %14, 0, %5, %14\n\t"                                                    \
-    "v_subb_co_u32_e64 %7, %15, %7, 0, %15\n\t" /* second (rare) correction */                     \
-    "v_cndmask_b32_e64 %8, 0, -1, %12\n\t"                                                         \
-    "v_cndmask_b32_e64 %9, 0, -1, %13\n\t"                                                         \
-    "v_cndmask_b32_e64 %10, 0, -1, %14\n\t"                                                        \
-    "v_cndmask_b32_e64 %11, 0, -1, %15\n\t"                                                        \
-    "v_add_co_u32_e64 %0, %12, %0, %8\n\t"                                                         \
-    "v_sub_co_u32_e64 %2, %13, %2, %9\n\t"                                                         \
-    "v_add_co_u32_e64 %4, %14, %4, %10\n\t"                                                        \
-    "v_sub_co_u32_e64 %6, %15, %6, %11\n\t"                                                        \
-    "v_addc_co_u32_e64 %1, %12, 0, %1, %12\n\t"                                                    \
-    "v_subb_co_u32_e64 %3, %13, %3, 0, %13\n\t"                                                    \
-    "v_addc_co_u32_e64 %5, %14, 0, %5, %14\n\t"                                                    \
-    "v_subb_co_u32_e64 %7, %15, %7, 0, %15"
-
+// The first version interleaved the four carry chains with the full double wrap correction in one block of 32
+// carry-flag instructions (~148 cycles per wavefront by tools/ubench_issue.hip's per-instruction costs); built
+// from add / sub above — second correction behind a never-taken branch — it is 18 VALU and ~106 cycles.
 template <bool NEG0, bool NEG1>
 __device__ __forceinline__ void bfly2(uint64_t a0, uint64_t c0, uint64_t a1, uint64_t c1, uint64_t &s0, uint64_t &d0,
                                       uint64_t &s1, uint64_t &d1) {
-    uint32_t a0l = (uint32_t)a0, a0h = (uint32_t)(a0 >> 32), c0l = (uint32_t)c0, c0h = (uint32_t)(c0 >> 32);
-    uint32_t a1l = (uint32_t)a1, a1h = (uint32_t)(a1 >> 32), c1l = (uint32_t)c1, c1h = (uint32_t)(c1 >> 32);
-    uint32_t s0l, s0h, d0l, d0h, s1l, s1h, d1l, d1h, e0, e1, e2, e3;
-    uint64_t k0, k1, k2, k3;
-#define GL_BFLY2_OPERANDS                                                                                        \
-    : "=&v"(s0l), "=&v"(s0h), "=&v"(d0l), "=&v"(d0h), "=&v"(s1l), "=&v"(s1h), "=&v"(d1l), "=&v"(d1h), /* 0-7 */  \
-      "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3),                                                     /* 8-11 */ \
-      "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)                                                      /* 12-15 */ \
-    : "v"(a0l), "v"(a0h), "v"(c0l), "v"(c0h), "v"(a1l), "v"(a1h), "v"(c1l), "v"(c1h)                  /* 16-23 */
-    // difference operands: a - c, or c - a when the twiddle's sign is absorbed (NEG)
-    if constexpr (!NEG0 && !NEG1)
-        asm(GL_BFLY2_ASM("%16, %18", "%17, %19", "%20, %22", "%21, %23") GL_BFLY2_OPERANDS);
-    else if constexpr (NEG0 && !NEG1)
-        asm(GL_BFLY2_ASM("%18, %16", "%19, %17", "%20, %22", "%21, %23") GL_BFLY2_OPERANDS);
-    else if constexpr (!NEG0 && NEG1)
-        asm(GL_BFLY2_ASM("%16, %18", "%17, %19", "%22, %20", "%23, %21") GL_BFLY2_OPERANDS);
-    else
-        asm(GL_BFLY2_ASM("%18, %16", "%19, %17", "%22, %20", "%23, %21") GL_BFLY2_OPERANDS);
-#undef GL_BFLY2_OPERANDS
-    s0 = pack64(s0l, s0h);
-    d0 = pack64(d0l, d0h);
-    s1 = pack64(s1l, s1h);
-    d1 = pack64(d1l, d1h);
+    s0 = add(a0, c0);
+    d0 = NEG0 ? sub(c0, a0) : sub(a0, c0);
+    s1 = add(a1, c1);
+    d1 = NEG1 ? sub(c1, a1) : sub(a1, c1);
 }
 
 // canonical-output product (inputs may be any u64)
@@ -499,18 +427,17 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
 //   r = l + h*(2^32 - 1) as one v_mad_u64_u32, its carry-out adds 2^32 - 1 once more (cannot carry again).
 __device__ __forceinline__ uint64_t fold96(uint64_t al, uint64_t ah) {
     uint32_t all = (uint32_t)al, alh = (uint32_t)(al >> 32), ahl = (uint32_t)ah, ahh = (uint32_t)(ah >> 32);
-    uint32_t rl, rh;
-    asm("v_mov_b32_e32 v116, %2\n\t"
-        "v_add_co_u32_e32 v117, vcc, %3, %4\n\t"
-        "v_addc_co_u32_e32 v118, vcc, 0, %5, vcc\n\t"                   // h
+    uint64_t r;
+    asm("v_mov_b32_e32 v116, %1\n\t"                                     // l = al + (ah << 32): (al.lo, al.hi + ah.lo), carry
+        "v_add_co_u32_e32 v117, vcc, %2, %3\n\t"
+        "v_addc_co_u32_e32 v118, vcc, 0, %4, vcc\n\t"                   // h = ah.hi + carry
         "v_mad_u64_u32 v[116:117], vcc, v118, -1, v[116:117]\n\t"      // l + h*(2^32-1)
         "v_cndmask_b32_e64 v118, 0, -1, vcc\n\t"
-        "v_add_co_u32_e32 %0, vcc, v116, v118\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, v117, vcc"
-        : "=&v"(rl), "=&v"(rh)
+        "v_mad_u64_u32 %0, vcc, v118, 1, v[116:117]"                     // the wrap correction as a multiply-add
+        : "=&v"(r)
         : "v"(all), "v"(alh), "v"(ahl), "v"(ahh)
         : "vcc", "v116", "v117", "v118");
-    return pack64(rl, rh);
+    return r;
 }
 
 // ---- lazy dot products --------------------------------------------------------------------
