@@ -327,35 +327,40 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
         constexpr int Q = K / 32, S = K % 32;
         const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
         if constexpr (S != 0) {
-            // The three lines above on the carry flags (7 / 13 / 9 instructions; the portable form below
+            // The three lines above on the carry flags (6 / 9 / 6 instructions plus rare paths; the portable form below
             // compiles to 64-bit compares and adds that cost about twice as many issue slots). These are
             // the shift twiddles of the radix-16 butterflies: w_16 = 2^12, so K is a multiple of 12.
+            // The wrap correction after a multiply-add is itself a multiply-add (t*1 + r: 6 cycles against 10 for
+            // v_add_co + v_addc_co); the borrow corrections trigger with probability <= 2^(S-32) per lane
+            // (Q = 2) or ~2^(S-64) (Q = 1) and sit behind a wave-uniform branch, as in add / sub / mul.
             uint32_t rl, rh, t;
             if constexpr (Q == 0) {
+                uint64_t r;
                 asm("v_lshlrev_b32_e32 v116, %[s], %[xl]\n\t"                  // w0
                     "v_alignbit_b32 v117, %[xh], %[xl], %[r]\n\t"              // w1
                     "v_lshrrev_b32_e32 %[t], %[r], %[xh]\n\t"                  // w2
                     "v_mad_u64_u32 v[116:117], vcc, %[t], -1, v[116:117]\n\t"  // (w1:w0) + w2*e
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_add_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"
-                    "v_addc_co_u32_e32 %[rh], vcc, 0, v117, vcc"
-                    : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t)
+                    "v_mad_u64_u32 %[out], vcc, %[t], 1, v[116:117]"             // wrapped: + e (cannot wrap again)
+                    : [out] "=&v"(r), [t] "=&v"(t)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
                     : "vcc", "v116", "v117");
+                return r;
             } else if constexpr (Q == 1) {
                 asm("v_mov_b32_e32 v116, 0\n\t"
                     "v_lshlrev_b32_e32 v117, %[s], %[xl]\n\t"                  // (w0:0)
                     "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
                     "v_mad_u64_u32 v[116:117], vcc, %[t], -1, v[116:117]\n\t"  // + w1*e
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_add_co_u32_e32 v116, vcc, v116, %[t]\n\t"
-                    "v_addc_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+                    "v_mad_u64_u32 v[116:117], vcc, %[t], 1, v[116:117]\n\t"   // wrapped: + e
                     "v_lshrrev_b32_e32 %[t], %[r], %[xh]\n\t"                  // w2
-                    "v_sub_co_u32_e32 v116, vcc, v116, %[t]\n\t"               // - w2
-                    "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
-                    "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"
-                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, v117, vcc"
+                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"              // - w2
+                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, v117, vcc\n\t"
+                    "s_cbranch_vccz 1f\n\t"
+                    "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"                   // rare: borrow => - e
+                    "v_sub_co_u32_e32 %[rl], vcc, %[rl], %[t]\n\t"
+                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, %[rh], vcc\n\t"
+                    "1:"
                     : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
                     : "vcc", "v116", "v117");
@@ -365,11 +370,13 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
                     "v_mad_u64_u32 v[116:117], vcc, %[t], -1, 0\n\t"           // w0*e
                     "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
                     "v_lshrrev_b32_e32 %[u], %[r], %[xh]\n\t"                  // w2
-                    "v_sub_co_u32_e32 v116, vcc, v116, %[t]\n\t"               // - (w2:w1)
-                    "v_subb_co_u32_e32 v117, vcc, v117, %[u], vcc\n\t"
-                    "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"
-                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, v117, vcc"
+                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"              // - (w2:w1)
+                    "v_subb_co_u32_e32 %[rh], vcc, v117, %[u], vcc\n\t"
+                    "s_cbranch_vccz 1f\n\t"
+                    "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"                   // rare: borrow => - e
+                    "v_sub_co_u32_e32 %[rl], vcc, %[rl], %[t]\n\t"
+                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, %[rh], vcc\n\t"
+                    "1:"
                     : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t), [u] "=&v"(u)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
                     : "vcc", "v116", "v117");

@@ -10,7 +10,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR };
+enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR, CND32, ADD32, SUB32, ADDE64, MAD1 };
 
 template <int KIND>
 __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
@@ -22,6 +22,11 @@ __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
     if constexpr (KIND == MULLO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(c) : "v"(x));
     if constexpr (KIND == MULHI) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(c) : "v"(x));
     if constexpr (KIND == XOR) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(c) : "v"(x));
+    if constexpr (KIND == CND32) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(c) : "v"(x) : "vcc");   // VOP2: mask implicitly vcc
+    if constexpr (KIND == ADD32) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(c) : "v"(x));                     // no carry-out
+    if constexpr (KIND == SUB32) asm volatile("v_sub_u32_e32 %0, %0, %1" : "+v"(c) : "v"(x));
+    if constexpr (KIND == ADDE64) asm volatile("v_add_co_u32_e64 %0, vcc, %0, %1" : "+v"(c) : "v"(x) : "vcc");    // VOP3 encoding of the carry add
+    if constexpr (KIND == MAD1) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w) : "v"(x) : "vcc");       // multiply-add used as a 64-bit add
 }
 
 template <int MADS, int CHEAP, int KIND>
@@ -78,6 +83,11 @@ int main() {
     run<0, 16, LSHLADD64>("v_lshl_add_u64 only");
     run<0, 16, MULLO>("v_mul_lo_u32 only");
     run<0, 16, MULHI>("v_mul_hi_u32 only");
+    run<0, 16, CND32>("v_cndmask_b32_e32 (VOP2, implicit vcc) only");
+    run<0, 16, ADD32>("v_add_u32 (no carry-out) only");
+    run<0, 16, SUB32>("v_sub_u32 (no carry-out) only");
+    run<0, 16, ADDE64>("v_add_co_u32_e64 (VOP3) only");
+    run<0, 16, MAD1>("v_mad_u64_u32 x*1 + acc only");
     printf("-- the field multiplication's shape: 5 multiply-adds and 11-14 carry-chain instructions\n");
     run<5, 14, ADDC>("old gl::mul shape (5 + 14)");
     run<5, 11, ADDC>("new gl::mul shape (5 + 11)");
