@@ -70,17 +70,17 @@ __device__ __forceinline__ uint64_t sub_generic(uint64_t a, uint64_t b) {
 __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
     uint64_t r;
-    asm("v_add_co_u32_e32 v116, vcc, %1, %3\n\t"
-        "v_addc_co_u32_e32 v117, vcc, %2, %4, vcc\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                  // overflow: 2^64 = 2^32 - 1
-        "v_mad_u64_u32 %0, vcc, v126, 1, v[116:117]\n\t"          // r = s + t, carry -> vcc
+    asm("v_add_co_u32_e32 v32, vcc, %1, %3\n\t"
+        "v_addc_co_u32_e32 v33, vcc, %2, %4, vcc\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                  // overflow: 2^64 = 2^32 - 1
+        "v_mad_u64_u32 %0, vcc, v42, 1, v[32:33]\n\t"          // r = s + t, carry -> vcc
         "s_cbranch_vccz 1f\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                  // rare: once more (cannot overflow a third time)
-        "v_mad_u64_u32 %0, vcc, v126, 1, %0\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                  // rare: once more (cannot overflow a third time)
+        "v_mad_u64_u32 %0, vcc, v42, 1, %0\n\t"
         "1:"
         : "=&v"(r)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
-        : "vcc", "v116", "v117", "v126");
+        : "vcc", "v32", "v33", "v42");
     return r;
 }
 
@@ -257,27 +257,31 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
     uint64_t r, c1;
     // LLVM's AMDGPU inline asm has no sub-register operand modifier, so the 64-bit temporaries
-    // whose halves are needed live in fixed registers v[116:126] (declared clobbered).
-    asm("v_mad_u64_u32 v[116:117], vcc, %2, %4, 0\n\t"          // T = al*bl
-        "v_mad_u64_u32 v[118:119], vcc, %2, %5, 0\n\t"          // U = al*bh
-        "v_mad_u64_u32 v[120:121], %1, %3, %4, v[118:119]\n\t"  // V = ah*bl + U, carry c1 (weight 2^96)
-        "v_mad_u64_u32 v[122:123], vcc, %3, %5, 0\n\t"          // W = ah*bh
-        "v_add_co_u32_e32 v117, vcc, v117, v120\n\t"            // lo.hi = T.hi + V.lo        lo = (v116, v117)
-        "v_addc_co_u32_e32 v122, vcc, v122, v121, vcc\n\t"      // hl = W.lo + V.hi + carry
-        "v_addc_co_u32_e32 v123, vcc, 0, v123, vcc\n\t"         // hh = W.hi + carry (+ c1, applied next)
-        "v_subb_co_u32_e64 v116, vcc, v116, v123, %1\n\t"       // t0 = lo - hh - c1
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+    // whose halves are needed live in fixed registers v[32:42] (declared clobbered). LOW registers on purpose:
+    // a kernel's VGPR allocation is the highest register it touches, and with these at v116-v126 (where they
+    // first were) every kernel reported 127 VGPRs = 4 waves per SIMD whatever it needed; at v32 the NTT passes
+    // take 75-79 (6 waves) and the tree-layer kernel 88 (5). v32+ is above the argument registers of the
+    // device-function calling convention (v0-v31), so the run-time compiled gate functions are unaffected.
+    asm("v_mad_u64_u32 v[32:33], vcc, %2, %4, 0\n\t"          // T = al*bl
+        "v_mad_u64_u32 v[34:35], vcc, %2, %5, 0\n\t"          // U = al*bh
+        "v_mad_u64_u32 v[36:37], %1, %3, %4, v[34:35]\n\t"  // V = ah*bl + U, carry c1 (weight 2^96)
+        "v_mad_u64_u32 v[38:39], vcc, %3, %5, 0\n\t"          // W = ah*bh
+        "v_add_co_u32_e32 v33, vcc, v33, v36\n\t"            // lo.hi = T.hi + V.lo        lo = (v32, v33)
+        "v_addc_co_u32_e32 v38, vcc, v38, v37, vcc\n\t"      // hl = W.lo + V.hi + carry
+        "v_addc_co_u32_e32 v39, vcc, 0, v39, vcc\n\t"         // hh = W.hi + carry (+ c1, applied next)
+        "v_subb_co_u32_e64 v32, vcc, v32, v39, %1\n\t"       // t0 = lo - hh - c1
+        "v_subbrev_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
         "s_cbranch_vccz 1f\n\t"
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // rare: borrow => t0 -= 2^32-1 (cannot borrow again)
-        "v_sub_co_u32_e32 v116, vcc, v116, v126\n\t"
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                // rare: borrow => t0 -= 2^32-1 (cannot borrow again)
+        "v_sub_co_u32_e32 v32, vcc, v32, v42\n\t"
+        "v_subbrev_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
         "1:\n\t"
-        "v_mad_u64_u32 v[116:117], vcc, v122, -1, v[116:117]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
-        "v_cndmask_b32_e64 v126, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
-        "v_mad_u64_u32 %0, vcc, v126, 1, v[116:117]"
+        "v_mad_u64_u32 v[32:33], vcc, v38, -1, v[32:33]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
+        "v_mad_u64_u32 %0, vcc, v42, 1, v[32:33]"
         : "=&v"(r), "=&s"(c1)
         : "v"(al), "v"(ah), "v"(bl), "v"(bh)
-        : "vcc", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v126");
+        : "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v42");
     return r;
 }
 
@@ -336,26 +340,26 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
             uint32_t rl, rh, t;
             if constexpr (Q == 0) {
                 uint64_t r;
-                asm("v_lshlrev_b32_e32 v116, %[s], %[xl]\n\t"                  // w0
-                    "v_alignbit_b32 v117, %[xh], %[xl], %[r]\n\t"              // w1
+                asm("v_lshlrev_b32_e32 v32, %[s], %[xl]\n\t"                  // w0
+                    "v_alignbit_b32 v33, %[xh], %[xl], %[r]\n\t"              // w1
                     "v_lshrrev_b32_e32 %[t], %[r], %[xh]\n\t"                  // w2
-                    "v_mad_u64_u32 v[116:117], vcc, %[t], -1, v[116:117]\n\t"  // (w1:w0) + w2*e
+                    "v_mad_u64_u32 v[32:33], vcc, %[t], -1, v[32:33]\n\t"  // (w1:w0) + w2*e
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_mad_u64_u32 %[out], vcc, %[t], 1, v[116:117]"             // wrapped: + e (cannot wrap again)
+                    "v_mad_u64_u32 %[out], vcc, %[t], 1, v[32:33]"             // wrapped: + e (cannot wrap again)
                     : [out] "=&v"(r), [t] "=&v"(t)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
-                    : "vcc", "v116", "v117");
+                    : "vcc", "v32", "v33");
                 return r;
             } else if constexpr (Q == 1) {
-                asm("v_mov_b32_e32 v116, 0\n\t"
-                    "v_lshlrev_b32_e32 v117, %[s], %[xl]\n\t"                  // (w0:0)
+                asm("v_mov_b32_e32 v32, 0\n\t"
+                    "v_lshlrev_b32_e32 v33, %[s], %[xl]\n\t"                  // (w0:0)
                     "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
-                    "v_mad_u64_u32 v[116:117], vcc, %[t], -1, v[116:117]\n\t"  // + w1*e
+                    "v_mad_u64_u32 v[32:33], vcc, %[t], -1, v[32:33]\n\t"  // + w1*e
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-                    "v_mad_u64_u32 v[116:117], vcc, %[t], 1, v[116:117]\n\t"   // wrapped: + e
+                    "v_mad_u64_u32 v[32:33], vcc, %[t], 1, v[32:33]\n\t"   // wrapped: + e
                     "v_lshrrev_b32_e32 %[t], %[r], %[xh]\n\t"                  // w2
-                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"              // - w2
-                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, v117, vcc\n\t"
+                    "v_sub_co_u32_e32 %[rl], vcc, v32, %[t]\n\t"              // - w2
+                    "v_subbrev_co_u32_e32 %[rh], vcc, 0, v33, vcc\n\t"
                     "s_cbranch_vccz 1f\n\t"
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"                   // rare: borrow => - e
                     "v_sub_co_u32_e32 %[rl], vcc, %[rl], %[t]\n\t"
@@ -363,15 +367,15 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
                     "1:"
                     : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
-                    : "vcc", "v116", "v117");
+                    : "vcc", "v32", "v33");
             } else {
                 uint32_t u;
                 asm("v_lshlrev_b32_e32 %[t], %[s], %[xl]\n\t"                  // w0
-                    "v_mad_u64_u32 v[116:117], vcc, %[t], -1, 0\n\t"           // w0*e
+                    "v_mad_u64_u32 v[32:33], vcc, %[t], -1, 0\n\t"           // w0*e
                     "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
                     "v_lshrrev_b32_e32 %[u], %[r], %[xh]\n\t"                  // w2
-                    "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"              // - (w2:w1)
-                    "v_subb_co_u32_e32 %[rh], vcc, v117, %[u], vcc\n\t"
+                    "v_sub_co_u32_e32 %[rl], vcc, v32, %[t]\n\t"              // - (w2:w1)
+                    "v_subb_co_u32_e32 %[rh], vcc, v33, %[u], vcc\n\t"
                     "s_cbranch_vccz 1f\n\t"
                     "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"                   // rare: borrow => - e
                     "v_sub_co_u32_e32 %[rl], vcc, %[rl], %[t]\n\t"
@@ -379,7 +383,7 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
                     "1:"
                     : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t), [u] "=&v"(u)
                     : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
-                    : "vcc", "v116", "v117");
+                    : "vcc", "v32", "v33");
             }
             return pack64(rl, rh);
         }
@@ -435,15 +439,15 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
 __device__ __forceinline__ uint64_t fold96(uint64_t al, uint64_t ah) {
     uint32_t all = (uint32_t)al, alh = (uint32_t)(al >> 32), ahl = (uint32_t)ah, ahh = (uint32_t)(ah >> 32);
     uint64_t r;
-    asm("v_mov_b32_e32 v116, %1\n\t"                                     // l = al + (ah << 32): (al.lo, al.hi + ah.lo), carry
-        "v_add_co_u32_e32 v117, vcc, %2, %3\n\t"
-        "v_addc_co_u32_e32 v118, vcc, 0, %4, vcc\n\t"                   // h = ah.hi + carry
-        "v_mad_u64_u32 v[116:117], vcc, v118, -1, v[116:117]\n\t"      // l + h*(2^32-1)
-        "v_cndmask_b32_e64 v118, 0, -1, vcc\n\t"
-        "v_mad_u64_u32 %0, vcc, v118, 1, v[116:117]"                     // the wrap correction as a multiply-add
+    asm("v_mov_b32_e32 v32, %1\n\t"                                     // l = al + (ah << 32): (al.lo, al.hi + ah.lo), carry
+        "v_add_co_u32_e32 v33, vcc, %2, %3\n\t"
+        "v_addc_co_u32_e32 v34, vcc, 0, %4, vcc\n\t"                   // h = ah.hi + carry
+        "v_mad_u64_u32 v[32:33], vcc, v34, -1, v[32:33]\n\t"      // l + h*(2^32-1)
+        "v_cndmask_b32_e64 v34, 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, v34, 1, v[32:33]"                     // the wrap correction as a multiply-add
         : "=&v"(r)
         : "v"(all), "v"(alh), "v"(ahl), "v"(ahh)
-        : "vcc", "v116", "v117", "v118");
+        : "vcc", "v32", "v33", "v34");
     return r;
 }
 
@@ -511,23 +515,23 @@ __device__ __forceinline__ uint64_t dot_finish(const DotAcc &d) {
         "v_add_co_u32_e32 %[w2], vcc, %[w2], %[k0]\n\t"
         "v_addc_co_u32_e32 %[w3], vcc, 0, %[w3], vcc\n\t"
         "v_addc_co_u32_e32 %[w4], vcc, 0, %[w4], vcc\n\t"
-        "v_sub_co_u32_e32 v116, vcc, %[a0l], %[w3]\n\t"               // (w0, w1) - w3
-        "v_subbrev_co_u32_e32 v117, vcc, 0, %[w1], vcc\n\t"
+        "v_sub_co_u32_e32 v32, vcc, %[a0l], %[w3]\n\t"               // (w0, w1) - w3
+        "v_subbrev_co_u32_e32 v33, vcc, 0, %[w1], vcc\n\t"
         "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-        "v_sub_co_u32_e32 v116, vcc, v116, %[t]\n\t"
-        "v_subbrev_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
-        "v_mad_u64_u32 v[116:117], vcc, %[w2], -1, v[116:117]\n\t"    // + w2 * (2^32 - 1)
+        "v_sub_co_u32_e32 v32, vcc, v32, %[t]\n\t"
+        "v_subbrev_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
+        "v_mad_u64_u32 v[32:33], vcc, %[w2], -1, v[32:33]\n\t"    // + w2 * (2^32 - 1)
         "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-        "v_add_co_u32_e32 v116, vcc, v116, %[t]\n\t"
-        "v_addc_co_u32_e32 v117, vcc, 0, v117, vcc\n\t"
-        "v_sub_co_u32_e32 v117, vcc, v117, %[w4]\n\t"                 // - w4 * 2^32
+        "v_add_co_u32_e32 v32, vcc, v32, %[t]\n\t"
+        "v_addc_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
+        "v_sub_co_u32_e32 v33, vcc, v33, %[w4]\n\t"                 // - w4 * 2^32
         "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
-        "v_sub_co_u32_e32 %[rl], vcc, v116, %[t]\n\t"
-        "v_subbrev_co_u32_e32 %[rh], vcc, 0, v117, vcc"
+        "v_sub_co_u32_e32 %[rl], vcc, v32, %[t]\n\t"
+        "v_subbrev_co_u32_e32 %[rh], vcc, 0, v33, vcc"
         : [rl] "=&v"(rl), [rh] "=&v"(rh), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [t] "=&v"(t)
         : [a0l] "v"(a0l), [a0h] "v"(a0h), [a1l] "v"(a1l), [a1h] "v"(a1h), [a2l] "v"(a2l), [a2h] "v"(a2h), [k0] "v"(d.k0),
           [k1] "v"(d.k1), [k2] "v"(d.k2)
-        : "vcc", "v116", "v117");
+        : "vcc", "v32", "v33");
     return pack64(rl, rh);
 }
 
