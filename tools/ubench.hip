@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void alu_kernel(uint64_t *out, uint64_t seed) 
     out[i] = a[0] ^ a[1] ^ a[2] ^ a[3];
 }
 
+#ifdef POSEIDON_WAVES
+__attribute__((amdgpu_waves_per_eu(POSEIDON_WAVES, POSEIDON_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void poseidon_kernel(uint64_t *out, uint64_t seed, int perms) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t s[12];
