@@ -82,6 +82,31 @@ def cpu_baseline(log_n):
     }
 
 
+SPLITMIX_SEED = 0x706C6F6E6B7932  # "plonky2" 
+P = 0xFFFFFFFF00000001
+
+
+def splitmix64_field(count, start=0):
+    """`count` uniform elements of [0, p): SplitMix64 from SPLITMIX_SEED, draws >= p rejected (the uniform-canonical
+    contract of Sample::sample, goldilocks_field.rs:61-70); `start` = index of the first draw of the stream to use."""
+    gamma, m1, m2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9), np.uint64(0x94D049BB133111EB)
+    out = np.empty(count, dtype=np.uint64)
+    filled, pos, chunk = 0, int(start), 1 << 22
+    with np.errstate(over="ignore"):
+        while filled < count:
+            k = np.arange(pos + 1, pos + 1 + chunk, dtype=np.uint64)
+            z = np.uint64(SPLITMIX_SEED) + k * gamma
+            z = (z ^ (z >> np.uint64(30))) * m1
+            z = (z ^ (z >> np.uint64(27))) * m2
+            z ^= z >> np.uint64(31)
+            z = z[z < np.uint64(P)]
+            take = min(z.size, count - filled)
+            out[filled:filled + take] = z[:take]
+            filled += take
+            pos += chunk
+    return out
+
+
 def dft_point(x, log_n, k):
     """X[k] = sum_j x[j] * w^(j k) mod p, w = the primitive 2^log_n-th root of unity (field/src/types.rs:268-272;
     fft.rs:242-282 checks fft against exactly this naive evaluation). Vectorised numpy, no oracle."""
@@ -129,10 +154,9 @@ def main():
     log_n, batch = args.log_n, args.batch
     n = 1 << log_n
 
-    # synthetic input, resident in HBM before timing (SplitMix-style seeded uniform field elements)
-    rng = np.random.Generator(np.random.PCG64(0x706C6F6E6B7932 + dist.rank))
-    host = rng.integers(0, 2**64, size=(batch, n), dtype=np.uint64)
-    host = np.where(host >= np.uint64(pg.P), host - np.uint64(pg.P), host)
+    # synthetic input, resident in HBM before timing: SplitMix64 from the seed SURVEY 8(d) prescribes, uniform in
+    # [0, p) by rejection; every rank takes its own segment of the one stream
+    host = splitmix64_field(batch * n, start=dist.rank << 40).reshape(batch, n)
     buf = pg.DeviceBuffer.from_host(ctx, host)
 
     def step():
@@ -170,6 +194,20 @@ def main():
     fwd = float(np.median(fwd_ms))
     alg_bytes = 16.0 * n * batch
     achieved = alg_bytes / (fwd * 1e-3) / 1e9
+    # what a streaming kernel moves on this very device: a 16 B/lane copy of the same 512 MiB, read + write
+    scratch = pg.DeviceBuffer(ctx, batch * n)
+    cev = [pg.Event() for _ in range(2)]
+    copy_ms = []
+    for r in range(6):
+        cev[0].record(ctx)
+        _lib.call("gl_debug_copy", scratch.ptr, buf.ptr, 8 * batch * n, ctx.ptr)
+        cev[1].record(ctx)
+        ctx.synchronize()
+        if r:
+            copy_ms.append(cev[1].elapsed_ms_since(cev[0]))
+    scratch.free()
+    copy_gbs = 2 * 8.0 * batch * n / (min(copy_ms) * 1e-3) / 1e9
+    mulmods = (n // 2) * log_n * batch  # (N/2) lg N butterflies per transform, one mulmod + add + sub each
     traffic = pmc_traffic(log_n, batch)
 
     out = None
@@ -232,6 +270,10 @@ def main():
                                 "wave and pass with the SIMDs ~89% busy (DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
+                "measured_copy_GBps": copy_gbs,
+                "frac_of_measured_copy": achieved / copy_gbs,
+                "algorithmic_butterflies_per_launch_pair": mulmods,
+                "butterflies_per_s": mulmods / (fwd * 1e-3),
             },
             # rank 0 at N = 1 only: at N > 1 the host cores belong to the other ranks' transcripts
             "cpu_baseline": None if (args.no_cpu or dist.world > 1) else cpu_baseline(log_n),
@@ -309,14 +351,11 @@ def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3)
     """PolynomialBatch::from_values on configs[2]; leaf-major copy included (reference contract)."""
     n = 1 << log_n
     n_ext = n << rate_bits
-    rng = np.random.Generator(np.random.PCG64(99))
     d_vals = pg.DeviceBuffer(ctx, cols * n)
     chunk = 16
-    for c0 in range(0, cols, chunk):
+    for c0 in range(0, cols, chunk):  # [cols][n] uniform field elements from the same SplitMix64 stream, segment 2^50
         k = min(chunk, cols - c0)
-        h = rng.integers(0, 2**64, size=(k, n), dtype=np.uint64)
-        h = np.where(h >= np.uint64(pg.P), h - np.uint64(pg.P), h)
-        d_vals.upload(h, c0 * n)
+        d_vals.upload(splitmix64_field(k * n, start=(1 << 50) + c0 * n * 2), c0 * n)
     d_work = pg.DeviceBuffer(ctx, cols * n)
     d_lde = pg.DeviceBuffer(ctx, cols * n_ext)
     d_leaves = pg.DeviceBuffer(ctx, cols * n_ext)

@@ -427,6 +427,9 @@ const char *cudaGetErrorString(int code);
  * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b), 8-16 internal variants, 17 a + (b mod 2^63) * 2^32); output
  * canonical. d_b may be NULL for unary ops. */
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx);
+/* Measurement hook: a plain streaming copy kernel (16 B per lane, asynchronous on ctx->stream) — the bandwidth a
+ * kernel can actually reach on this device, which bench.py reports next to the 8 TB/s specification. */
+GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx);
 
 /* Library identification: "plonky2_hip <version> gfx950". */
 const char *gl_version(void);

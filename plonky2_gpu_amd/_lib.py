@@ -122,6 +122,7 @@ SIGNATURES = {
     "gl_free_host": (GlError, [_vp]),
     "gl_memcpy_h2d": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_h2d_async": (GlError, [_vp, _vp, _u64, _vp]),
+    "gl_debug_copy": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2h": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memcpy_d2d": (GlError, [_vp, _vp, _u64, _vp]),
     "gl_memset_zero": (GlError, [_vp, _u64, _vp]),

@@ -223,6 +223,12 @@ __device__ gl::DotAcc dotacc_from(int mode, uint64_t x, uint64_t y) {
     return d;
 }
 
+// 16 B per lane, grid-stride: what a streaming kernel can move on this device (the measured roof next to the 8 TB/s spec)
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
 __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -706,6 +712,20 @@ GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t lo
     if (e.code) return e;
     return gl_commit_from_coeffs(d_values, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
                                  d_digests, d_cap, ctx);
+}
+
+GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    if (!ctx || !d_dst || !d_src) return fail(GL_E_INVALID, "null pointer");
+    if ((bytes & 15) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) return fail(GL_E_INVALID, "16-byte granularity");
+    if (bytes == 0) return ok();
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)prop.multiProcessorCount * 8), dim3(256), 0, S(ctx)->stream,
+                       static_cast<const uint4 *>(d_src), static_cast<uint4 *>(d_dst), bytes / 16);
+    HIP_TRY(hipGetLastError());
+    return ok();
 }
 
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx) {
