@@ -215,12 +215,15 @@ def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
     assert nc.prove_bytes(wires, pis) == first
 
 
-def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu):
+@pytest.mark.parametrize("degree_bits,proof_bytes", [(18, 204544), (20, 219072)])
+def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu, degree_bits, proof_bytes):
     """The shape bench.py times (BASELINE.json configs[3]: n = 2^18, 234 wires / 80 routed, 88 preprocessed
     polynomials, rate 8, cap height 4, FRI arities [4, 4, 4, 4], 28 queries, 16 proof-of-work bits) proven by
     gl_prove and checked by the oracle's verifier, which recomputes every challenge from the bytes. bench.py
     itself may not use the oracle for this (only its cpu_baseline leg may), so the validity of what it times is
-    established here; the witness comes from the same generator with the same seed as the bench's rank 0."""
+    established here; the witness comes from the same generator with the same seed as the bench's rank 0. The second
+    case, 2^20 rows (LDE 2^23: three-pass transforms, 15.7 GB of wire LDE), is the largest the verifier gets to see;
+    gl_prove itself has been run to 2^21 rows (473 ms)."""
     import os
     import sys
 
@@ -232,14 +235,14 @@ def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import synth_circuit
 
-    circuit, wires, pis = synth_circuit.make(18, num_wires=234, num_routed=80, num_constants=8, seed=1, gate_table="ed25519")
-    assert circuit["fri_params"]["reduction_arity_bits"] == [4, 4, 4, 4]
+    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=234, num_routed=80, num_constants=8, seed=1, gate_table="ed25519")
+    assert circuit["fri_params"]["reduction_arity_bits"] == [4] * ((degree_bits - 2) // 4)
     assert len(circuit["gates"]) == 25 and circuit["num_gate_constraints"] == 231  # the whole ed25519 gate table is declared
     synth_circuit.set_public_input_row(wires, hash_no_pad(gpu, pis))
     nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
     d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))
     data = nc.prove_bytes(d_wires, pis)
-    assert len(data) == 204544
+    assert len(data) == proof_bytes
     vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
     assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
     nc.close()
