@@ -1,7 +1,9 @@
 /* plonky2_hip.h — C ABI of libplonky2_hip.so: the MI355X (gfx950) replacement for the reference's
- * `cuda/` crate (sideprotocol/plonky2-gpu), covering the prover hot path only:
+ * `cuda/` crate (sideprotocol/plonky2-gpu), covering the prover's data-parallel hot path only:
  * Goldilocks NTT / inverse NTT / coset LDE, Poseidon Merkle-cap construction and the
- * PolynomialBatch commit.
+ * PolynomialBatch commit; the permutation argument, the quotient polynomials for any circuit (gates as
+ * register programs), openings and the FRI opening pipeline; and, on top of those, a whole prove() in one call.
+ * No circuit building, witness generation or verification.
  *
  * Two groups of entry points:
  *   (A) the reference's own extern "C" symbols (cuda/src/lib.rs:58-145 <-> cuda/plonky2_gpu.cu),
