@@ -5,7 +5,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from gpu_util import P, gpu  # noqa: F401
+from gpu_util import P, bitrev_perm, gpu  # noqa: F401
 from test_oracle_poseidon import TEST_VECTORS
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +212,57 @@ def test_open_batch_from_the_column_major_lde(gpu):
     lb, sb = b.merkle_tree.open_batch(idx)
     assert (la == lb).all() and (sa == sb).all()
     assert (b.get_lde_values(5) == a.get_lde_values(5)).all()
+
+
+def test_commit_at_the_full_benchmark_size(gpu, oracle):
+    """BASELINE.json configs[2], the shape bench.py's commit leg times: from_values of 135 columns x 2^20 rows, rate 8,
+    cap height 4 — LDE 2^23 x 135 = 8.4 GiB, 2^23 leaves of 17 permutations each. Checked through properties that do not
+    need the whole answer on the host:
+      - three whole columns (first, middle, last): coefficients == the C oracle's ifft of the values, and the LDE
+        column == its 2^23-point coset LDE in bit-reversed order;
+      - from_coeffs on the coefficients builds the same tree (same cap, same sampled digests);
+      - 50 opened leaves and their paths verify against the cap with the oracle's Merkle verifier, and the opened
+        leaves carry the LDE columns' values at those rows."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    n_polys, log_n, rate_bits, h = 135, 20, 3, 4
+    n, n_ext = 1 << log_n, 1 << (log_n + rate_bits)
+    watch = (0, 67, 134)
+    d_vals = pg.DeviceBuffer(gpu, n_polys * n)
+    values = {}
+    for c0 in range(0, n_polys, 15):
+        v = oracle.random_field((15, n), seed=4200 + c0)
+        d_vals.upload(v, c0 * n)
+        for c in watch:
+            if c0 <= c < c0 + 15:
+                values[c] = v[c - c0].copy()
+    a = pg.PolynomialBatch.from_values_device(gpu, d_vals, n_polys, log_n, rate_bits, False, h, leaf_major=False)
+    perm = bitrev_perm(log_n + rate_bits)
+    lde = {}
+    for c in watch:
+        coeffs = a.d_polynomials.download(c * n, n)
+        assert (coeffs == oracle.canon(oracle.ifft(values[c]))).all(), c
+        lde[c] = a.d_lde.download(c * n_ext, n_ext)
+        assert (lde[c] == oracle.canon(oracle.coset_lde(coeffs, rate_bits))[perm]).all(), c
+    cap = a.merkle_tree.cap
+    assert cap.shape == (16, 4)
+
+    rng = np.random.default_rng(77)
+    idx = [0, n_ext - 1] + [int(i) for i in rng.integers(0, n_ext, size=48)]
+    leaves, sib = a.merkle_tree.open_batch(idx)
+    for q, i in enumerate(idx):
+        assert oracle.merkle_verify(leaves[q], i, cap, sib[q]), i
+        for c in watch:
+            assert leaves[q][c] == lde[c][i], (i, c)
+    # a corrupted leaf must not verify (the verifier is not vacuous at this size)
+    bad = leaves[0].copy()
+    bad[5] ^= np.uint64(1)
+    assert not oracle.merkle_verify(bad, idx[0], cap, sib[0])
+
+    d_coeffs = pg.DeviceBuffer(gpu, n_polys * n)
+    _lib.call("gl_memcpy_d2d", d_coeffs.ptr, a.d_polynomials.ptr, 8 * n_polys * n, gpu.ptr)
+    b = pg.PolynomialBatch.from_coeffs_device(gpu, d_coeffs, n_polys, log_n, rate_bits, False, h, leaf_major=False)
+    assert (b.merkle_tree.cap == cap).all()
+    for slot in [0, 1, 2 * (n_ext - 16) - 1] + [int(s) for s in rng.integers(0, 2 * (n_ext - 16), size=200)]:
+        assert (a.merkle_tree.d_digests.download(4 * slot, 4) == b.merkle_tree.d_digests.download(4 * slot, 4)).all(), slot
