@@ -72,3 +72,90 @@ class ProverGroup:
         if self.td:
             self.td.destroy_process_group()
             self.td = None
+
+
+class ShardedCommit:
+    """One rank's part of a commitment whose columns are spread over the ranks (second row):
+    `d_coeffs` / `d_lde` hold this rank's columns [my_cols][n] / [my_cols][n_ext]; `d_leaves` is the column-major
+    block [total_cols][leaves_per_rank] of ALL columns for this rank's leaf range [leaf_lo, leaf_lo + leaves_per_rank);
+    `d_digests` is this rank's contiguous block of the tree's digest buffer (the reference lays the buffer out per
+    cap subtree, hash/merkle_tree.rs:210-244, and the subtrees of a rank are adjacent), starting at digest
+    `digest_lo`; `cap` is the whole tree's cap, identical on every rank."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def sharded_commit_from_values(group, ctx, d_values, col_lo, col_hi, total_cols, log_n, rate_bits, cap_height):
+    """PolynomialBatch::from_values (fri/oracle.rs:709-731) for ONE trace whose columns [col_lo, col_hi) live on this
+    rank (`d_values`: [col_hi - col_lo][2^log_n], transformed in place). Per rank: inverse NTT and coset LDE of its
+    own columns; then the path's ONE exchange — every rank sends, for each of its columns, the leaf range each other
+    rank owns (leaf ranges are contiguous because cap subtrees are), point to point, so that all links work at once
+    on an xGMI mesh; then leaf hashing and the subtrees of its own leaf range; finally an all-gather of the
+    2^cap_height x 32 B cap. With backend "nccl" the exchange runs between device buffers over RCCL; with "gloo" it is
+    staged through host memory (how it is tested with two ranks sharing one GPU)."""
+    from . import _lib
+    from .device import DeviceBuffer
+
+    W, r = group.world, group.rank
+    if W & (W - 1) or W > (1 << cap_height):
+        raise ValueError("the number of ranks must be a power of two and at most 2^cap_height (whole cap subtrees per rank)")
+    n, n_ext = 1 << log_n, 1 << (log_n + rate_bits)
+    mine = col_hi - col_lo
+    bounds = [shard_range(total_cols, W, q) for q in range(W)]
+    if bounds[r] != (col_lo, col_hi):
+        raise ValueError("columns must be sharded contiguously by shard_range(total_cols, world, rank)")
+    L = n_ext // W  # leaves per rank
+    _lib.call("gl_ntt_batch", d_values.ptr, mine, log_n, n, 1, 0, ctx.ptr)
+    d_lde = DeviceBuffer(ctx, mine * n_ext)
+    _lib.call("gl_coset_lde_batch", d_values.ptr, d_lde.ptr, mine, log_n, rate_bits, 7, n, n_ext, ctx.ptr)
+    d_leaves = DeviceBuffer(ctx, total_cols * L)
+    # my own columns of my own leaf range stay on the device
+    for c in range(mine):
+        _lib.call("gl_memcpy_d2d", d_leaves.at((col_lo + c) * L), d_lde.at(c * n_ext + r * L), 8 * L, ctx.ptr)
+    if W > 1:
+        td, torch = group.td, group.torch
+        on_device = group.backend == "nccl"
+        dev = group._dev()
+        send, recv, ops = {}, {}, []
+        for q in range(W):
+            if q == r:
+                continue
+            send[q] = torch.empty(mine * L, dtype=torch.int64, device=dev)
+            recv[q] = torch.empty((bounds[q][1] - bounds[q][0]) * L, dtype=torch.int64, device=dev)
+            for c in range(mine):  # [mine][L]: the slice of every one of my columns that rank q hashes
+                src = d_lde.at(c * n_ext + q * L)
+                if on_device:
+                    _lib.call("gl_memcpy_d2d", send[q].data_ptr() + 8 * c * L, src, 8 * L, ctx.ptr)
+                else:
+                    _lib.call("gl_memcpy_d2h", send[q].data_ptr() + 8 * c * L, src, 8 * L, ctx.ptr)
+        ctx.synchronize()
+        for q in range(W):
+            if q != r:
+                ops.append(td.P2POp(td.isend, send[q], q))
+                ops.append(td.P2POp(td.irecv, recv[q], q))
+        for req in td.batch_isend_irecv(ops):
+            req.wait()
+        if on_device:
+            torch.cuda.synchronize()
+        for q in range(W):
+            if q == r:
+                continue
+            cnt = (bounds[q][1] - bounds[q][0]) * L
+            dst = d_leaves.at(bounds[q][0] * L)
+            if on_device:
+                _lib.call("gl_memcpy_d2d", dst, recv[q].data_ptr(), 8 * cnt, ctx.ptr)
+            else:
+                _lib.call("gl_memcpy_h2d", dst, recv[q].data_ptr(), 8 * cnt, ctx.ptr)
+        ctx.synchronize()
+    local_cap_height = cap_height - (W.bit_length() - 1)
+    n_dig = 2 * (L - (1 << local_cap_height))
+    d_digests = DeviceBuffer(ctx, 4 * max(n_dig, 1))
+    d_cap = DeviceBuffer(ctx, 4 << local_cap_height)
+    _lib.call("gl_merkle_tree_from_columns", d_leaves.ptr, total_cols, L, L, local_cap_height, d_digests.ptr, d_cap.ptr, ctx.ptr)
+    my_cap = d_cap.download(0, 4 << local_cap_height).reshape(-1, 4)
+    cap = np.concatenate(group.gather_caps(my_cap), axis=0)
+    d_cap.free()
+    return ShardedCommit(d_coeffs=d_values, d_lde=d_lde, d_leaves=d_leaves, d_digests=d_digests, cap=cap, col_lo=col_lo, col_hi=col_hi,
+                         total_cols=total_cols, leaf_lo=r * L, leaves_per_rank=L, digest_lo=r * n_dig, num_digests=n_dig,
+                         local_cap_height=local_cap_height)

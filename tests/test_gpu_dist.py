@@ -1,0 +1,36 @@
+"""SURVEY.md §8(e), second row: ONE commitment whose columns are spread over the ranks, with the path's single
+exchange between the LDE and the leaf hashing. Run here with 2 and 4 ranks sharing the one GPU (exchange staged
+through host memory over gloo); every rank checks its part against the oracle's commit of the whole matrix
+(tests/dist_sharded_commit.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from gpu_util import gpu  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,shape", [(2, (24, 10, 3, 4)), (4, (135, 8, 3, 4)), (2, (9, 12, 2, 1)), (4, (20, 6, 3, 2))])
+def test_column_sharded_commit_equals_the_whole_commit(gpu, world, shape):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world * 10 + shape[1]), os.path.join(ROOT, "tests", "dist_sharded_commit.py")] + [str(x) for x in shape]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert p.stdout.count(" ok") == world, p.stdout
+
+
+def test_sharded_commit_argument_errors(gpu):
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd.dist import ProverGroup, sharded_commit_from_values
+
+    g = ProverGroup()  # world 1
+    d = pg.DeviceBuffer(gpu, 4 * 16)
+    with pytest.raises(ValueError):
+        sharded_commit_from_values(g, gpu, d, 1, 5, 5, 4, 3, 2)  # not the slice shard_range assigns
+    sc = sharded_commit_from_values(g, gpu, d, 0, 4, 4, 4, 3, 2)  # world 1: the plain commit
+    assert sc.leaf_lo == 0 and sc.leaves_per_rank == 128 and sc.cap.shape == (4, 4)
