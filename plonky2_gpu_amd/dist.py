@@ -159,3 +159,35 @@ def sharded_commit_from_values(group, ctx, d_values, col_lo, col_hi, total_cols,
     return ShardedCommit(d_coeffs=d_values, d_lde=d_lde, d_leaves=d_leaves, d_digests=d_digests, cap=cap, col_lo=col_lo, col_hi=col_hi,
                          total_cols=total_cols, leaf_lo=r * L, leaves_per_rank=L, digest_lo=r * n_dig, num_digests=n_dig,
                          local_cap_height=local_cap_height)
+
+
+def sharded_open_batch(group, ctx, sc, indices):
+    """MerkleTree::get + prove (hash/merkle_tree.rs:392-440) for GLOBAL leaf indices of a ShardedCommit — what
+    fri_prover_query_round asks of a tree. Each index is answered by the rank that owns its leaf range: the path
+    inside that rank's subtrees is the whole path (log2(N) - cap_height siblings either way). The answers are
+    combined with a sum all-reduce (the other ranks contribute zeros), so every rank returns
+    (leaves [count, total_cols], siblings [count, layers, 4]) for all indices."""
+    from . import _lib
+
+    idx = np.ascontiguousarray(indices, dtype=np.uint64)
+    L = sc.leaves_per_rank
+    layers = (L.bit_length() - 1) - sc.local_cap_height
+    leaves = np.zeros((idx.size, sc.total_cols), dtype=np.uint64)
+    sib = np.zeros((idx.size, layers, 4), dtype=np.uint64)
+    own = np.flatnonzero((idx >= sc.leaf_lo) & (idx < sc.leaf_lo + L))
+    if own.size:
+        local = np.ascontiguousarray(idx[own] - np.uint64(sc.leaf_lo))
+        lv = np.empty((own.size, sc.total_cols), dtype=np.uint64)
+        sb = np.empty((own.size, layers, 4), dtype=np.uint64)
+        _lib.call("gl_merkle_open_batch", sc.d_leaves.ptr, 1, L, sc.total_cols, L, sc.local_cap_height,
+                  sc.d_digests.ptr if layers else None, local, local.size, lv, sb if layers else None, ctx.ptr)
+        leaves[own] = lv
+        if layers:
+            sib[own] = sb
+    if group.td:
+        for arr in (leaves, sib):
+            if arr.size:
+                t = group.torch.from_numpy(arr.view(np.int64).reshape(-1).copy()).to(group._dev())
+                group.td.all_reduce(t, op=group.td.ReduceOp.SUM)
+                arr[...] = t.cpu().numpy().view(np.uint64).reshape(arr.shape)
+    return leaves, sib

@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 
 import plonky2_gpu_amd as pg  # noqa: E402
 from oracle import oracle as o  # noqa: E402
-from plonky2_gpu_amd.dist import ProverGroup, shard_range, sharded_commit_from_values  # noqa: E402
+from plonky2_gpu_amd.dist import ProverGroup, shard_range, sharded_commit_from_values, sharded_open_batch  # noqa: E402
 
 
 def check_against_single_device_commit(g, ctx, sc, vals, total_cols, log_n, rate_bits, cap_height):
@@ -48,11 +48,22 @@ def main():
     d_vals = pg.DeviceBuffer.from_host(ctx, np.ascontiguousarray(vals[lo:hi]))
     sc = sharded_commit_from_values(g, ctx, d_vals, lo, hi, total_cols, log_n, rate_bits, cap_height)
 
+    # openings: every rank asks for the same global leaves (first, last, one per rank's range, random ones) and gets
+    # leaf + path from whichever rank owns it; each must verify against the gathered cap with the oracle's verifier
+    rng = np.random.default_rng(99)
+    idx = [0, n_ext - 1] + [q * (n_ext // g.world) + 3 % (n_ext // g.world) for q in range(g.world)] + [int(x) for x in rng.integers(0, n_ext, size=20)]
+    op_leaves, op_sib = sharded_open_batch(g, ctx, sc, idx)
+    for k, i in enumerate(idx):
+        assert o.merkle_verify(op_leaves[k], i, sc.cap, op_sib[k]), ("opening", i)
+    bad = op_leaves[0].copy()
+    bad[0] ^= np.uint64(1)
+    assert not o.merkle_verify(bad, idx[0], sc.cap, op_sib[0])
     if total_cols * n_ext > (1 << 26):
         return check_against_single_device_commit(g, ctx, sc, vals, total_cols, log_n, rate_bits, cap_height)
     exp = o.commit_from_values(vals, rate_bits, cap_height, threads=2)
     coeffs, leaves, digests, cap = (o.canon(exp[k]) for k in ("coeffs", "leaves", "digests", "cap"))
     assert (sc.cap == cap).all(), "cap"
+    assert (op_leaves == leaves[idx]).all(), "opened leaves"
     assert (sc.d_coeffs.download(0, (hi - lo) * n).reshape(hi - lo, n) == coeffs[lo:hi]).all(), "coefficients"
     assert (sc.d_lde.download(0, (hi - lo) * n_ext).reshape(hi - lo, n_ext) == leaves.T[lo:hi]).all(), "LDE columns"
     L = sc.leaves_per_rank
