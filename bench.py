@@ -266,8 +266,10 @@ def main():
                                   "tools/pmc_summary.py into profiles/r01_pmc_traffic.json (gfx950 x2 correction on the "
                                   "row pass's wide reads only); null when that file is absent",
                 "kernel": "forward batch NTT = ntt_pass_kernel<10,true> + ntt_pass_kernel<10,false>",
-                "binding_roof": "integer VALU issue, not HBM: rocprofv3 SQ counters give ~3300 VALU instructions per "
-                                "wave and pass with the SIMDs ~89% busy (DESIGN.md 3.1)",
+                "binding_roof": "not HBM peak: two passes move 2x the algorithmic bytes (traffic), and with the field "
+                                "arithmetic replaced by xor/add the same launches still take 0.64 of 0.76 ms - the "
+                                "load / LDS-exchange / barrier / store skeleton of a pass runs at ~3.3 TB/s where a copy "
+                                "kernel reaches measured_copy_GBps; arithmetic is the remaining 15% (DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
                 "measured_copy_GBps": copy_gbs,
