@@ -20,9 +20,14 @@
  *     per device, a few hundred KiB of twiddle tables and one 128 MiB workspace (created by
  *     gl_ctx_create()/init() or on first use) that the natural-order transforms, the scans
  *     (partial products, divide_by_linear), the opening partial sums, gl_sponge_absorb,
- *     gl_merkle_open_batch and gl_fri_proof_of_work stage through. Because that workspace is
- *     shared, drive each device from ONE host thread / context at a time (the reference's callers
- *     are single-threaded and synchronous, oracle.rs:394-422); use one process per GPU for more.
+ *     gl_merkle_open_batch and gl_fri_proof_of_work stage through. That workspace (like the event
+ *     pair of the commit and the constant tables of a compiled gate kernel) exists once per device.
+ *     Several contexts or host threads on one device are SAFE but not concurrent: every entry point
+ *     that takes a ctx serialises its enqueue phase per device and, when the stream changes from one
+ *     call to the next, makes the new stream wait for what the previous one has queued, so contexts
+ *     take turns. The reference's callers are single-threaded and synchronous (oracle.rs:394-422);
+ *     for throughput use one context per device and one process per GPU. A circuit handle and its
+ *     buffer pool (gl_circuit_create) belong to one thread at a time.
  *     Three entry points do allocate device memory themselves: gl_circuit_create (the preprocessed
  *     commitment, freed by gl_circuit_destroy) and gl_prove (every buffer of one proof), because their
  *     job is to own a whole computation, and the reference symbol compute_quotient_polys (a staging

@@ -52,6 +52,10 @@ struct DeviceState {
     uint64_t coset_tick = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     GateKernel *ed25519_kernel = nullptr;  // the reference symbol compute_quotient_polys' circuit, built on first use
+    // DeviceCall: contexts take turns on this device's shared state
+    std::recursive_mutex call_mu;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t order_event = nullptr;
     uint64_t *ref_staging = nullptr;       // its column-major staging copy of the three leaf-major inputs
     uint64_t ref_staging_elems = 0;
 };
@@ -181,6 +185,42 @@ GlError get_ed25519_kernel(const GateKernel **out) {
 }
 
 Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
+
+// The workspace, the event pair and the gate kernels' constant tables exist once per device. The reference's callers
+// are single-threaded, but a second context on the same device must not be able to corrupt results silently: every
+// entry point that takes a ctx holds this guard while it enqueues. It (1) serialises the enqueue phase of calls on
+// one device across host threads (recursive: entry points call each other), and (2) when the call's stream differs
+// from the previous call's, makes the new stream wait for everything queued on the previous one. Contexts therefore
+// take turns — correct, not concurrent; use one process per GPU, or one context, for throughput.
+class DeviceCall {
+public:
+    explicit DeviceCall(void *ctx) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        st_ = &g_dev[dev & 63];
+        st_->call_mu.lock();
+        hipStream_t s = ctx ? S(ctx)->stream : nullptr;
+        if (!s) return;
+        if (st_->last_stream && st_->last_stream != s) {
+            bool ok = st_->order_event || hipEventCreateWithFlags(&st_->order_event, hipEventDisableTiming) == hipSuccess;
+            if (ok) ok = hipEventRecord(st_->order_event, st_->last_stream) == hipSuccess;
+            if (ok) ok = hipStreamWaitEvent(s, st_->order_event, 0) == hipSuccess;
+            if (!ok) (void)hipGetLastError();  // the other stream is gone: nothing of it is left to wait for
+        }
+        st_->last_stream = s;
+    }
+    ~DeviceCall() {
+        if (st_) st_->call_mu.unlock();
+    }
+    DeviceCall(const DeviceCall &) = delete;
+    DeviceCall &operator=(const DeviceCall &) = delete;
+
+private:
+    DeviceState *st_ = nullptr;
+};
 
 __global__ void bit_reverse_columns_kernel(uint64_t *v, uint32_t log_n, uint64_t total) {
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,6 +362,17 @@ void *gl_ctx_create(int device) {
 }
 
 void gl_ctx_destroy(void *ctx) {
+    {  // the device must not try to order later calls after a stream that no longer exists
+        int dev = 0;
+        if (ctx && hipGetDevice(&dev) == hipSuccess) {
+            DeviceState &st = g_dev[dev & 63];
+            std::lock_guard<std::recursive_mutex> lk(st.call_mu);
+            if (st.last_stream == S(ctx)->stream) {
+                (void)hipStreamSynchronize(st.last_stream);
+                st.last_stream = nullptr;
+            }
+        }
+    }
     if (!ctx) return;
     (void)hipStreamDestroy(S(ctx)->stream);
     (void)hipStreamDestroy(S(ctx)->stream2);
@@ -358,6 +409,7 @@ GlError gl_free_host(void *h_ptr) {
 }
 
 GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(ctx)->stream));
     HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
@@ -365,12 +417,14 @@ GlError gl_memcpy_h2d(void *d_dst, const void *h_src, uint64_t bytes, void *ctx)
 }
 
 GlError gl_memcpy_h2d_async(void *d_dst, const void *h_src, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, S(ctx)->stream2));
     return ok();
 }
 
 GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, S(ctx)->stream));
     HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
@@ -378,12 +432,14 @@ GlError gl_memcpy_d2h(void *h_dst, const void *d_src, uint64_t bytes, void *ctx)
 }
 
 GlError gl_memcpy_d2d(void *d_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, S(ctx)->stream));
     return ok();
 }
 
 GlError gl_memset_zero(void *d_dst, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null ctx");
     HIP_TRY(hipMemsetAsync(d_dst, 0, bytes, S(ctx)->stream));
     return ok();
@@ -416,6 +472,7 @@ void gl_event_destroy(void *event) {
 
 GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, int inverse,
                      int bit_reversed, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
     if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24 is not supported by this build");
     if (stride < (1ull << log_n)) return fail(GL_E_INVALID, "stride smaller than the polynomial");
@@ -432,6 +489,7 @@ GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint
 
 GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t poly_num, uint32_t log_n,
                            uint32_t rate_bits, uint64_t shift, uint64_t src_stride, uint64_t dst_stride, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || ((!d_coeffs || !d_out) && poly_num)) return fail(GL_E_INVALID, "null pointer");
     if (log_n > 24 || rate_bits > 8) return fail(GL_E_INVALID, "log_n > 24 or rate_bits > 8 not supported");
     const uint64_t n = 1ull << log_n;
@@ -448,6 +506,7 @@ GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t p
 
 GlError gl_coset_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint64_t stride, uint64_t shift, int inverse,
                            void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || (!d_values && poly_num)) return fail(GL_E_INVALID, "null pointer");
     if (shift % glh::P == 0) return fail(GL_E_INVALID, "shift must be non-zero");
     CosetLease ct;
@@ -469,6 +528,7 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
                                         uint64_t sigmas_stride, const uint64_t *d_k_is, const uint64_t *h_betas,
                                         const uint64_t *h_gammas, uint32_t num_challenges, uint32_t num_routed,
                                         uint32_t quotient_degree_factor, uint32_t log_n, uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_wires || !d_sigmas || !d_k_is || !h_betas || !h_gammas || !d_out) return fail(GL_E_INVALID, "null pointer");
     if (num_challenges == 0 || num_challenges > 4) return fail(GL_E_INVALID, "num_challenges must be 1..4");
     if (quotient_degree_factor < 2 || num_routed == 0) return fail(GL_E_INVALID, "bad num_routed / quotient_degree_factor");
@@ -500,6 +560,7 @@ void gl_gate_kernel_destroy(void *kernel) { gate_kernel_destroy(static_cast<Gate
 const char *gl_gate_kernel_source(const void *kernel) { return kernel ? gate_kernel_source(static_cast<const GateKernel *>(kernel)) : ""; }
 
 GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotient_polys, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !args || !d_quotient_polys) return fail(GL_E_INVALID, "null pointer");
     if (!args->d_wires_leaves || !args->d_constants_sigmas_leaves || !args->d_zs_partial_products_leaves || !args->d_k_is ||
         !args->h_betas || !args->h_gammas || !args->h_alphas)
@@ -565,6 +626,7 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
 
 GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint64_t stride, const uint64_t *h_points,
                            uint32_t num_points, uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !h_points || !d_out || (!d_coeffs && poly_num)) return fail(GL_E_INVALID, "null pointer");
     if (num_points == 0 || num_points > 4) return fail(GL_E_INVALID, "num_points must be 1..4");
     if (poly_num > 65535) return fail(GL_E_INVALID, "poly_num > 65535");
@@ -579,6 +641,7 @@ GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t
 
 GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t num_polys, uint64_t n, const uint64_t *h_alpha,
                                  uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_poly_ptrs || !h_alpha || !d_out) return fail(GL_E_INVALID, "null pointer");
     if (num_polys == 0 || num_polys > (1u << 20) || n == 0) return fail(GL_E_INVALID, "bad sizes");
     const NttTables *tb;
@@ -589,6 +652,7 @@ GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t nu
 
 GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint64_t *h_point, const uint64_t *h_scale, int accumulate,
                                 uint64_t *d_final, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_composition || !h_point || !h_scale || !d_final) return fail(GL_E_INVALID, "null pointer");
     if (n < 2 || n > (1ull << 30)) return fail(GL_E_INVALID, "bad length");
     const NttTables *tb;
@@ -600,6 +664,7 @@ GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint6
 }
 
 GlError gl_fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *h_beta, uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_coeffs || !h_beta || !d_out) return fail(GL_E_INVALID, "null pointer");
     hipError_t e = fri_fold(d_coeffs, len, arity_bits, h_beta, d_out, S(ctx)->stream);
     if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "bad arity / length");
@@ -608,12 +673,14 @@ GlError gl_fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits,
 }
 
 GlError gl_ext2_interleave(const uint64_t *d_planes, uint64_t len, uint64_t *d_rows, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_planes || !d_rows) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(fri_interleave(d_planes, len, d_rows, S(ctx)->stream));
     return ok();
 }
 
 GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint32_t min_leading_zeros, uint64_t *h_witness, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !h_state || !h_witness) return fail(GL_E_INVALID, "null pointer");
     if (witness_pos >= 8 || min_leading_zeros > 40) return fail(GL_E_INVALID, "bad witness position / difficulty");
     const NttTables *tb;
@@ -623,12 +690,14 @@ GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint
 }
 
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || (!d_states && count)) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(poseidon_permute_batch(d_states, count, S(ctx)->stream));
     return ok();
 }
 
 GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n_blocks, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !h_state || (!h_inputs && n_blocks)) return fail(GL_E_INVALID, "null pointer");
     const NttTables *tb;
     HIP_TRY(get_tables(&tb));
@@ -646,6 +715,7 @@ GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n
 GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
                              uint32_t cap_height, const uint64_t *d_digests, const uint64_t *h_indices, uint32_t count,
                              uint64_t *h_out_leaves, uint64_t *h_out_siblings, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_leaves || !h_indices || !h_out_leaves || (!h_out_siblings && (n_leaves >> cap_height) > 1))
         return fail(GL_E_INVALID, "null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || cap_height > 63 || (1ull << cap_height) > n_leaves)
@@ -672,6 +742,7 @@ GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint
 
 GlError gl_merkle_tree_from_columns(const uint64_t *d_cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
                                     uint32_t cap_height, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_cols || !d_cap) return fail(GL_E_INVALID, "null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return fail(GL_E_INVALID, "n_leaves must be a power of two");
     if ((1ull << cap_height) > n_leaves || cap_height > 63)
@@ -682,6 +753,7 @@ GlError gl_merkle_tree_from_columns(const uint64_t *d_cols, uint32_t leaf_len, u
 
 GlError gl_merkle_tree_from_leaves(const uint64_t *d_rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
                                    uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_rows || !d_cap) return fail(GL_E_INVALID, "null pointer");
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return fail(GL_E_INVALID, "n_leaves must be a power of two");
     if ((1ull << cap_height) > n_leaves || cap_height > 63)
@@ -692,6 +764,7 @@ GlError gl_merkle_tree_from_leaves(const uint64_t *d_rows, uint32_t leaf_len, ui
 
 GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
                      void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_cols || !d_rows) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(transpose_to_leaf_major(d_cols, d_rows, n_cols, n_rows, col_stride, S(ctx)->stream));
     return ok();
@@ -700,6 +773,7 @@ GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, 
 GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                               uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    DeviceCall device_call(ctx);
     if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24 is not supported by this build");
     return commit_from_coeffs_impl(d_coeffs, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
                                    d_digests, d_cap, S(ctx), false);
@@ -708,6 +782,7 @@ GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint3
 GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
                               uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                               uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, void *ctx) {
+    DeviceCall device_call(ctx);
     GlError e = gl_ntt_batch(d_values, poly_num, log_n, 1ull << log_n, 1, 0, ctx);
     if (e.code) return e;
     return gl_commit_from_coeffs(d_values, poly_num, log_n, rate_bits, cap_height, salt_size, shift, d_lde, d_leaves,
@@ -715,6 +790,7 @@ GlError gl_commit_from_values(uint64_t *d_values, uint64_t poly_num, uint32_t lo
 }
 
 GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_dst || !d_src) return fail(GL_E_INVALID, "null pointer");
     if ((bytes & 15) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) return fail(GL_E_INVALID, "16-byte granularity");
     if (bytes == 0) return ok();
@@ -729,6 +805,7 @@ GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx)
 }
 
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_a || !d_out) return fail(GL_E_INVALID, "null pointer");
     if (n == 0) return ok();
     hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(ctx)->stream, op, d_a, d_b,
@@ -749,6 +826,7 @@ void init(void) {
 
 GlError ifft(uint64_t *d_values_flatten, int poly_num, int values_num_per_poly, int log_len,
              const uint64_t *d_root_table, const uint64_t *n_inv, void *ctx) {
+    DeviceCall device_call(ctx);
     (void)d_root_table;
     if (poly_num < 0 || log_len < 0 || values_num_per_poly != (1 << log_len)) return fail(GL_E_INVALID, "bad sizes");
     if (n_inv) {
@@ -765,6 +843,7 @@ GlError merkle_tree_from_coeffs(uint64_t *d_values_flatten, uint64_t *d_ext_valu
                                 int values_num_per_poly, int log_len, const uint64_t *d_root_table,
                                 const uint64_t *d_root_table2, const uint64_t *d_shift_powers, int rate_bits,
                                 int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    DeviceCall device_call(ctx);
     (void)d_root_table;
     (void)d_root_table2;
     (void)d_shift_powers;
@@ -791,6 +870,7 @@ GlError merkle_tree_from_values(uint64_t *d_values_flatten, uint64_t *d_ext_valu
                                 int values_num_per_poly, int log_len, const uint64_t *d_root_table,
                                 const uint64_t *d_root_table2, const uint64_t *d_shift_powers, const uint64_t *n_inv,
                                 int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    DeviceCall device_call(ctx);
     GlError e = ifft(d_values_flatten, poly_num, values_num_per_poly, log_len, d_root_table, n_inv, ctx);
     if (e.code) return e;
     return merkle_tree_from_coeffs(d_values_flatten, d_ext_values_flatten, poly_num, values_num_per_poly, log_len,
@@ -800,6 +880,7 @@ GlError merkle_tree_from_values(uint64_t *d_values_flatten, uint64_t *d_ext_valu
 
 GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly, int log_len,
                           int rate_bits, int salt_size, int cap_height, int pad_extvalues_len, void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx || !d_ext_values_flatten) return fail(GL_E_INVALID, "null pointer");
     if (poly_num <= 0 || log_len < 0 || rate_bits < 0 || salt_size < 0 || cap_height < 0 || pad_extvalues_len < 0 ||
         values_num_per_poly != (1 << log_len) || cap_height > log_len + rate_bits)
@@ -857,6 +938,7 @@ GlError gl_reference_quotient_release(void) {
 }
 
 GlError gl_reference_quotient_prepare(void *ctx) {
+    DeviceCall device_call(ctx);
     if (!ctx) return fail(GL_E_INVALID, "null pointer");
     const GateKernel *k;
     return get_ed25519_kernel(&k);
@@ -878,6 +960,7 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
                                const GlDataSlice *points, const GlDataSlice *z_h_on_coset_evals,
                                const GlDataSlice *z_h_on_coset_inverses, const GlDataSlice *k_is, const GlDataSlice *alphas,
                                const GlDataSlice *betas, const GlDataSlice *gammas, void *ctx) {
+    DeviceCall device_call(ctx);
     (void)d_root_table2, (void)d_shift_inv_powers, (void)points, (void)z_h_on_coset_evals, (void)z_h_on_coset_inverses;
     const GlDataSlice *zs = zs_partial_products_commitment_leaves, *cs = constants_sigmas_commitment_leaves;
     if (!ctx || !d_ext_values_flatten || !zs || !cs || !d_outs || !d_quotient_polys || !k_is || !alphas || !betas || !gammas)

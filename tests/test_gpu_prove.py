@@ -274,3 +274,47 @@ def test_witness_upload_overlapping_a_proof(gpu):
     assert (d_b.download() == flat).all()
     assert nc.prove_bytes(d_b, pis) == expect
     staging.free()
+
+
+def test_two_host_threads_with_their_own_contexts_on_one_device(gpu):
+    """The per-device workspace, event pair and gate-kernel constant tables exist once; a second context on the same
+    device used to be forbidden by the header and would corrupt results silently. Now every entry point takes turns
+    per device (capi.hip DeviceCall): two threads, each with its own context, circuit and data, hammering
+    natural-order transforms (which stage through the workspace), commits with the leaf-major copy (the event pair)
+    and whole proofs at the same time must each get exactly the results they get alone."""
+    import threading
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+
+    def work(ctx, seed, rounds, out):
+        rng = np.random.default_rng(seed)
+        x = rng.integers(0, prove_ref.P, size=(3, 1 << 13), dtype=np.uint64)
+        vals = rng.integers(0, prove_ref.P, size=(5, 1 << 9), dtype=np.uint64)
+        circuit, wires, pis = make_circuit(6, seed=80 + seed, two_groups=bool(seed & 1))
+        nc = pg.NativeCircuit(ctx, dict(circuit, circuit_digest=None))
+        for _ in range(rounds):
+            f = pg.fft_with_options(ctx, x)
+            back = pg.ifft_with_options(ctx, f)
+            b = pg.PolynomialBatch.from_values(ctx, vals, 3, False, 2, leaf_major=True)
+            out.append((f.tobytes(), back.tobytes(), b.merkle_tree.cap.tobytes(), b.merkle_tree.digests.tobytes(), nc.prove_bytes(wires, pis)))
+        nc.close()
+
+    other = pg.Context(0)
+    try:
+        alone = [[], []]
+        work(gpu, 1, 1, alone[0])
+        work(other, 2, 1, alone[1])
+        together = [[], []]
+        threads = [threading.Thread(target=work, args=(c, s, 6, o)) for c, s, o in ((gpu, 1, together[0]), (other, 2, together[1]))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for who in (0, 1):
+            assert len(together[who]) == 6
+            for got in together[who]:
+                assert got == alone[who][0], who
+    finally:
+        other.close()
