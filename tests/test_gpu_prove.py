@@ -318,3 +318,50 @@ def test_two_host_threads_with_their_own_contexts_on_one_device(gpu):
                 assert got == alone[who][0], who
     finally:
         other.close()
+
+
+def test_device_memory_does_not_grow_over_proofs_circuits_and_commits(gpu):
+    """A prover is a long-lived process: free device memory must be the same after many proofs on one circuit
+    (the per-circuit buffer pool recycles), after creating and destroying circuits, and after commits of changing
+    shapes (coset-table cache churn) as it was after the first few."""
+    import ctypes
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        gpu.synchronize()
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    circuit, wires, pis = make_circuit(6, seed=90, two_groups=True)
+    base = None
+    for i in range(24):
+        nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+        nc.prove_bytes(wires, pis)
+        nc.close()
+        if i == 3:
+            base = free_bytes()
+    assert free_bytes() == base, "circuits leak device memory"
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    first = nc.prove_bytes(wires, pis)
+    base = free_bytes()
+    for _ in range(100):
+        assert nc.prove_bytes(wires, pis) == first
+    assert free_bytes() == base, "proofs leak device memory"
+    nc.close()
+    rng = np.random.default_rng(4)
+    base = None
+    for i in range(80):
+        log_n, cols = int(rng.integers(3, 11)), int(rng.integers(1, 12))
+        pg.PolynomialBatch.from_values(gpu, rng.integers(0, prove_ref.P, size=(cols, 1 << log_n), dtype=np.uint64), int(rng.integers(1, 4)), False, 1)
+        if i == 40:
+            base = free_bytes()
+    import gc
+
+    gc.collect()
+    assert free_bytes() >= base, "commits leak device memory"
