@@ -354,6 +354,19 @@ def test_device_memory_does_not_grow_over_proofs_circuits_and_commits(gpu):
         assert nc.prove_bytes(wires, pis) == first
     assert free_bytes() == base, "proofs leak device memory"
     nc.close()
+    # the error path gives its buffers back too, and leaves the circuit usable
+    c5, w5, p5 = make_circuit(6, seed=91, two_groups=True, quotient_degree_factor=5)
+    nc = pg.NativeCircuit(gpu, dict(c5, circuit_digest=None))
+    good = nc.prove_bytes(w5, p5)
+    base = free_bytes()
+    bad = [list(c) for c in w5]
+    bad[3][7] = (bad[3][7] + 1) % prove_ref.P
+    for _ in range(5):
+        with pytest.raises(pg.Plonky2HipError, match="not divisible by Z_H"):
+            nc.prove_bytes(bad, p5)
+        assert nc.prove_bytes(w5, p5) == good
+    assert free_bytes() == base, "failing proofs leak device memory"
+    nc.close()
     rng = np.random.default_rng(4)
     base = None
     for i in range(80):
