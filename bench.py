@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6300
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a copy kernel reaches is measured in the run
 LOG_N = 20
 BATCH = 64
 
@@ -137,19 +137,67 @@ def pmc_traffic(log_n, batch):
     return d["forward_chunk_total_bytes"] * (batch / 16.0)  # the summary is per 16-column chunk
 
 
+def launch_ranks(n, argv=None, script=None, extra_env=None):
+    """`bench.py --gpus N` started by hand (no torchrun, WORLD_SIZE unset): this process — which has not loaded the
+    HIP library and never will — starts N copies of the script, one per rank, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, waits for all of them and returns the
+    worst exit code. Children are fresh processes (no fork of GPU state, no exec from a process that touched the GPU).
+    Rank 0's stdout carries the JSON line; the other ranks print nothing on stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+    finally:
+        for p in procs:  # a rank that died leaves the others in a barrier: end exactly the children started here
+            if p.poll() is None:
+                p.kill()
+    bad = [c for c in codes if c != 0]
+    return 0 if not bad else (max(bad) if max(bad) > 0 else 1)
+
+
+def pick_backend(world, ndev):
+    """RCCL ("nccl") when every rank has a GPU of its own; gloo when ranks share a device (RCCL refuses two ranks on
+    one GPU) or there is one rank. PLONKY2_DIST_BACKEND overrides."""
+    forced = os.environ.get("PLONKY2_DIST_BACKEND")
+    if forced:
+        return forced
+    return "nccl" if (world > 1 and ndev >= world) else "gloo"
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # nothing below has run yet: no HIP call in this process
     import plonky2_gpu_amd as pg
     from plonky2_gpu_amd.dist import ProverGroup
-
-    # barrier / max-reduce only: gloo on CPU tensors by default (no data-path collective exists);
-    # PLONKY2_DIST_BACKEND=nccl routes them over RCCL/xGMI instead.
-    dist = ProverGroup(backend=os.environ.get("PLONKY2_DIST_BACKEND", "gloo"))
     from plonky2_gpu_amd import _lib
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ndev = pg.load().gl_device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # barrier / max-reduce / cap gather only (no data-path collective exists): over RCCL/xGMI when each rank has its
+    # own GPU, over gloo when the ranks share one (the one-GPU box)
+    dist = ProverGroup(backend=pick_backend(world, ndev), device_index=int(os.environ.get("LOCAL_RANK", "0")) % ndev)
     ctx = pg.Context(dist.local_rank % ndev)
     log_n, batch = args.log_n, args.batch
     n = 1 << log_n
@@ -254,6 +302,9 @@ def main():
                 "batch_columns": batch,
                 "log_n": log_n,
                 "parallelism": f"columns sharded over {dist.world} GPU(s), no collective",
+                "ranks": dist.world,
+                "devices_visible": ndev,
+                "rank_sync_backend": dist.backend or "none (one rank)",
             },
             "roofline": {
                 "bound": "hbm",

