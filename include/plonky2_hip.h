@@ -49,6 +49,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#pragma GCC visibility push(default)
 
 /* == cuda::Error (cuda/src/lib.rs:21-25) / RustError (cuda/plonky2_gpu.cu:19-31) */
 typedef struct GlError {
@@ -75,8 +77,12 @@ void *gl_ctx_create(int device); /* NULL on failure; also makes `device` current
 void gl_ctx_destroy(void *ctx);
 GlError gl_ctx_synchronize(void *ctx); /* waits for both streams */
 
-/* Thin device-memory helpers for hosts without a HIP binding (synchronous). */
+/* Thin device-memory helpers for hosts without a HIP binding (synchronous). gl_malloc allocates on the calling
+ * thread's CURRENT device; gl_ctx_malloc on the device of `ctx` (and makes it current) — what a host with several
+ * contexts, or with threads that never called hipSetDevice, should use. Every entry point that takes a ctx runs on
+ * the ctx's device in the same way, whatever the thread's current device was. */
 GlError gl_malloc(void **d_ptr, uint64_t bytes);
+GlError gl_ctx_malloc(void **d_ptr, uint64_t bytes, void *ctx);
 GlError gl_free(void *d_ptr);
 /* Page-locked host staging memory — the reference's MyAllocator (plonky2/src/fri/oracle.rs:49-73,
  * cudaHostAlloc): transfers from it run at link speed and do not stage through a bounce buffer. */
@@ -441,6 +447,7 @@ GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx)
 /* Library identification: "plonky2_hip <version> gfx950". */
 const char *gl_version(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,7 @@ class DeviceBuffer {
     DeviceBuffer() = default;
     DeviceBuffer(const Context &ctx, uint64_t n) : ctx_(&ctx), n_(n) {
         void *p = nullptr;
-        check(gl_malloc(&p, n * 8));
+        check(gl_ctx_malloc(&p, n * 8, ctx.get()));
         ptr_ = static_cast<uint64_t *>(p);
     }
     DeviceBuffer(const Context &ctx, const std::vector<uint64_t> &host) : DeviceBuffer(ctx, host.size()) { upload(host); }

@@ -303,6 +303,57 @@ void glo_fft_batch(uint64_t *v, size_t n_polys, size_t n, int inverse, int n_thr
     root_table_free(&rt);
 }
 
+/* cpu_baseline of bench.py: forward + inverse transforms of `cols_per_thread` columns of length n on each of
+ * `n_threads` threads, measured the way the reference's prover meets this work: the root table exists before the
+ * timed region (fft_root_table is built once per circuit, circuit_builder.rs:849-851, and handed to every
+ * fft_with_options call), each thread allocates and fills its own columns (first touch on its own NUMA node, as rayon
+ * workers that produced the witness columns would have), one column per task (oracle.rs:720). The clock runs inside
+ * the parallel region between two barriers, so thread start-up, allocation and the table are outside it.
+ * Returns seconds for the 2 * n_threads * cols_per_thread transforms; *checksum defeats dead-code elimination and
+ * lets the caller see that ifft(fft(x)) == x held (0 = every column came back unchanged). */
+double glo_fft_bench(size_t n, int n_threads, int cols_per_thread, uint64_t seed, uint64_t *checksum) {
+    if (n_threads < 1) n_threads = 1;
+    if (cols_per_thread < 1) cols_per_thread = 1;
+    root_table_t rt = root_table_new(n);
+    double t0 = 0, t1 = 0;
+    uint64_t bad = 0;
+#pragma omp parallel num_threads(n_threads) reduction(| : bad)
+    {
+        int tid = omp_get_thread_num();
+        uint64_t *v = (uint64_t *)malloc((size_t)cols_per_thread * n * sizeof(uint64_t));
+        uint64_t *ref = (uint64_t *)malloc(n * sizeof(uint64_t));
+        uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(tid + 1);
+        for (size_t i = 0; i < (size_t)cols_per_thread * n; i++) { /* SplitMix64, rejected to [0, p) */
+            uint64_t z;
+            do {
+                x += 0x9E3779B97F4A7C15ull;
+                z = x;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+            } while (z >= GL_P);
+            v[i] = z;
+        }
+        memcpy(ref, v, n * sizeof(uint64_t));
+#pragma omp barrier
+#pragma omp master
+        t0 = omp_get_wtime();
+        for (int c = 0; c < cols_per_thread; c++) {
+            fft_with_table(v + (size_t)c * n, n, 0, &rt);
+            ifft_with_table(v + (size_t)c * n, n, &rt);
+        }
+#pragma omp barrier
+#pragma omp master
+        t1 = omp_get_wtime();
+        for (size_t i = 0; i < n; i++) bad |= glo_canon(v[i]) ^ ref[i];
+        free(v);
+        free(ref);
+    }
+    root_table_free(&rt);
+    if (checksum) *checksum = bad;
+    return t1 - t0;
+}
+
 /* ------------------------------------------------------------------ Poseidon */
 
 #define W 12

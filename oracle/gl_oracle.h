@@ -101,6 +101,8 @@ int glo_commit_from_coeffs(const uint64_t *coeffs, size_t n_polys, size_t n, uns
 
 /* batch helpers used by the cpu_baseline timing (one task per column, like rayon par_iter) */
 void glo_fft_batch(uint64_t *v, size_t n_polys, size_t n, int inverse, int n_threads);
+/* timed inside C, root table prebuilt, thread-local first-touched columns: see gl_oracle.c */
+double glo_fft_bench(size_t n, int n_threads, int cols_per_thread, uint64_t seed, uint64_t *checksum);
 int glo_hardware_threads(void);
 
 #ifdef __cplusplus

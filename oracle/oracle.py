@@ -68,6 +68,7 @@ def lib():
             ("glo_commit_from_values", i, [_u64p, sz, sz, ui, ui, _u64p, _u64p, _u64p, _u64p, i]),
             ("glo_commit_from_coeffs", i, [_u64p, sz, sz, ui, ui, _u64p, _u64p, _u64p, i]),
             ("glo_fft_batch", None, [_u64p, sz, sz, i, i]),
+            ("glo_fft_bench", ctypes.c_double, [sz, i, i, ctypes.c_uint64, _u64p]),
             ("glo_hardware_threads", i, []),
         ]:
             f = getattr(L, name)
@@ -126,6 +127,17 @@ def fft_batch(v, inverse=False, threads=1):
     out = _arr(v).copy()
     lib().glo_fft_batch(_p(out), out.shape[0], out.shape[1], int(inverse), threads)
     return out
+
+
+def fft_bench(n, threads, cols_per_thread=1, seed=0x706C6F6E6B7932):
+    """Seconds for threads * cols_per_thread forward + inverse transforms of length n (2x that many NTTs), clocked
+    inside C: root table prebuilt, every thread working on columns it allocated and filled itself. Raises if any
+    column failed to come back unchanged."""
+    bad = np.zeros(1, dtype=np.uint64)
+    dt = lib().glo_fft_bench(n, threads, cols_per_thread, seed, _p(bad))
+    if int(bad[0]):
+        raise AssertionError("ifft(fft(x)) != x in the CPU restatement")
+    return dt
 
 
 def root_table_concat(n):

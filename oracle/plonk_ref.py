@@ -30,6 +30,15 @@ def quotient_chunk_products(quotient_values, max_degree):
     return out
 
 
+def partial_products_and_z_gx(z_x, chunk_products):
+    """partial_products.rs:28-37: running products of the chunk quotients starting from Z(x); the last one is Z(gx)."""
+    acc, out = z_x % P, []
+    for c in chunk_products:
+        acc = acc * c % P
+        out.append(acc)
+    return out
+
+
 def num_partial_products(n, max_degree):
     """partial_products.rs:41-48"""
     return -(-n // max_degree) - 1
@@ -50,10 +59,7 @@ def wires_permutation_partial_products_and_zs(wires, sigmas, k_is, beta, gamma, 
             den = (w + beta * sigmas[j][i] + gamma) % P
             q.append(num * inv(den) % P)
         chunks = quotient_chunk_products(q, degree)
-        acc, row = z_x, []
-        for c in chunks:  # partial_products_and_z_gx, partial_products.rs:28-37
-            acc = acc * c % P
-            row.append(acc)
+        row = partial_products_and_z_gx(z_x, chunks)
         z_x, row[num_prods] = row[num_prods], z_x  # prover.rs:777-778: the last slot holds Z(x), not Z(gx)
         rows.append(row)
     return [[rows[i][k] for i in range(n)] for k in range(num_prods + 1)]

@@ -117,6 +117,7 @@ SIGNATURES = {
     "gl_ctx_destroy": (None, [_vp]),
     "gl_ctx_synchronize": (GlError, [_vp]),
     "gl_malloc": (GlError, [ctypes.POINTER(_vp), _u64]),
+    "gl_ctx_malloc": (GlError, [ctypes.POINTER(_vp), _u64, _vp]),
     "gl_free": (GlError, [_vp]),
     "gl_malloc_host": (GlError, [ctypes.POINTER(_vp), _u64]),
     "gl_free_host": (GlError, [_vp]),

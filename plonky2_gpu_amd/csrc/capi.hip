@@ -9,7 +9,7 @@
 #include <string.h>
 
 #include "../../include/plonky2_hip.h"
-#include "gl_field.cuh"
+#include "gl_field.h"
 #include "merkle.h"
 #include "ntt.h"
 #include "plonk.h"
@@ -186,6 +186,20 @@ GlError get_ed25519_kernel(const GateKernel **out) {
 
 Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
 
+// Device of a context = device of its first stream; makes it the calling thread's current device.
+bool ctx_device(void *ctx, int *dev) {
+    if (ctx && S(ctx)->stream) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(S(ctx)->stream, &d) != hipSuccess) return false;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return false;
+        if (cur != (int)d && hipSetDevice((int)d) != hipSuccess) return false;
+        *dev = (int)d;
+        return true;
+    }
+    return hipGetDevice(dev) == hipSuccess;
+}
+
 // The workspace, the event pair and the gate kernels' constant tables exist once per device. The reference's callers
 // are single-threaded, but a second context on the same device must not be able to corrupt results silently: every
 // entry point that takes a ctx holds this guard while it enqueues. It (1) serialises the enqueue phase of calls on
@@ -195,8 +209,12 @@ Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
 class DeviceCall {
 public:
     explicit DeviceCall(void *ctx) {
+        // The call runs on the device its context's streams belong to, whatever device the calling thread has current:
+        // tables, workspace, guard and every allocation made inside the call follow it (a context created on device 1
+        // and used from a thread whose current device is still 0 must not touch device 0's state). The device comes
+        // from the stream itself, so a caller-built {stream, stream2} pair (the reference's CudaInnerContext) works too.
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) {
+        if (!ctx_device(ctx, &dev)) {
             (void)hipGetLastError();
             return;
         }
@@ -235,7 +253,7 @@ __global__ void bit_reverse_columns_kernel(uint64_t *v, uint32_t log_n, uint64_t
 }
 
 
-// Element-wise field ops, exported only so that the parity tests can drive gl_field.cuh with the
+// Element-wise field ops, exported only so that the parity tests can drive gl_field.h with the
 // reference's edge operands (field/src/prime_field_testing.rs:7-17).
 template <int K>
 __device__ uint64_t pow2_case(uint64_t x, int k) {
@@ -364,7 +382,7 @@ void *gl_ctx_create(int device) {
 void gl_ctx_destroy(void *ctx) {
     {  // the device must not try to order later calls after a stream that no longer exists
         int dev = 0;
-        if (ctx && hipGetDevice(&dev) == hipSuccess) {
+        if (ctx && ctx_device(ctx, &dev)) {
             DeviceState &st = g_dev[dev & 63];
             std::lock_guard<std::recursive_mutex> lk(st.call_mu);
             if (st.last_stream == S(ctx)->stream) {
@@ -388,6 +406,14 @@ GlError gl_ctx_synchronize(void *ctx) {
 
 GlError gl_malloc(void **d_ptr, uint64_t bytes) {
     if (!d_ptr) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return ok();
+}
+
+GlError gl_ctx_malloc(void **d_ptr, uint64_t bytes, void *ctx) {
+    if (!d_ptr || !ctx) return fail(GL_E_INVALID, "null pointer");
+    int dev = 0;
+    if (!ctx_device(ctx, &dev)) return fail(GL_E_INVALID, "the context's stream has no device");
     HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
     return ok();
 }
@@ -905,7 +931,7 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
 // transposing first (streaming, through LDS tiles) and reading column-major is 2x faster end to end. One buffer per
 // device, grown on demand, given back by gl_reference_quotient_release(). nullptr = could not allocate, or
 // PLONKY2_HIP_REFERENCE_IN_PLACE=1: read the rows in place.
-uint64_t *get_ref_staging(uint64_t elems) {
+static uint64_t *get_ref_staging(uint64_t elems) {
     if (const char *v = getenv("PLONKY2_HIP_REFERENCE_IN_PLACE"))
         if (v[0] && v[0] != '0') return nullptr;  // the caller would rather not have the staging buffer
     int dev = 0;

@@ -14,7 +14,7 @@
 // it becomes: scale by z^k, SUFFIX SUM (additions only — a plain parallel scan), scale by z^-(i+1).
 #include "fri.h"
 
-#include "poseidon.cuh"
+#include "poseidon.h"
 
 namespace plonky2_hip {
 namespace {

@@ -18,6 +18,14 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
 void gate_kernel_destroy(GateKernel *k);
 uint32_t gate_kernel_num_challenges(const GateKernel *k);
 uint32_t gate_kernel_num_constraints(const GateKernel *k);
+uint32_t gate_kernel_wires_needed(const GateKernel *k);      // 1 + the largest wire index a gate loads
+uint32_t gate_kernel_constants_needed(const GateKernel *k);  // 1 + the largest constants column a gate reads (selectors included)
+
+// The checks shared by the compiled kernel and the interpreter's callers: descriptors in range, immediates in range, no gate
+// emitting more than num_gate_constraints constraints; reports the wire / constant columns the programs need.
+bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates, uint32_t num_imms,
+                            uint32_t num_selectors, uint32_t num_gate_constraints, uint32_t *wires_needed,
+                            uint32_t *constants_needed, std::string *error);
 const char *gate_kernel_source(const GateKernel *k);
 
 // out[c*lde_size + t] = sum_k alpha_c^k * (sum_g filter_g * constraint_{g,k}) at the point held by leaf t, for

@@ -21,6 +21,7 @@
 
 #include <dlfcn.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +29,7 @@
 #include <sstream>
 #include <vector>
 
-#include "gl_field.cuh"
+#include "gl_field.h"
 
 namespace plonky2_hip {
 
@@ -39,6 +40,7 @@ const char *const GL_FIELD_SRC =
 
 enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK, GP_ACC, GP_ACCR };
 constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
+const char *const JIT_ARCH = "gfx950";
 
 // Where compiled code objects are kept: $PLONKY2_HIP_KERNEL_CACHE (empty = no cache), else the directory
 // `kernel_cache` next to this shared library if it exists — the place __graft_entry__.build() precompiles the
@@ -61,8 +63,55 @@ struct GateKernel {
     uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
     uint64_t *d_pih = nullptr;   // the module's g_pih[4]
     uint32_t num_challenges = 0, num_constraints = 0;
+    uint32_t wires_needed = 0, constants_needed = 0;  // 1 + the largest wire / constant column any gate loads
     std::string source;
 };
+
+// What every consumer of gate programs checks before running them (the compiled kernel when it is generated, the
+// interpreter's callers through gl_gate_program_validate): a gate must not emit more constraints than the circuit
+// declares — the reference asserts "num_constraints() gave too low of a number" (plonk/vanishing_poly.rs:256-262,
+// 296-303); silently dropping the surplus would leave those constraints unenforced — and the columns it loads must
+// exist. Returns false and fills `error`.
+bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates, uint32_t num_imms,
+                            uint32_t num_selectors, uint32_t ngc, uint32_t *wires_needed, uint32_t *constants_needed,
+                            std::string *error) {
+    uint32_t wn = 0, cn = num_selectors;
+    for (uint32_t g = 0; g < num_gates; g++) {
+        const uint32_t *d = gates + 6 * g;
+        const uint32_t si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
+        if ((uint64_t)ps + pl > num_instrs || si >= num_selectors || gs > ge) {
+            *error = "gate descriptor out of range";
+            return false;
+        }
+        uint32_t emitted = 0;
+        for (uint32_t pc = ps; pc < ps + pl; pc++) {
+            const uint16_t op = instrs[4 * pc], a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
+            if (op == GP_LOAD_WIRE && (uint32_t)a + 1 > wn) wn = (uint32_t)a + 1;
+            if (op == GP_LOAD_CONST && num_selectors + a + 1 > cn) cn = num_selectors + a + 1;
+            if (op == GP_LOAD_IMM && a >= num_imms) {
+                *error = "LOAD_IMM index out of range";
+                return false;
+            }
+            if (op == GP_ACC && b >= num_imms) {
+                *error = "ACC immediate index out of range";
+                return false;
+            }
+            if (op == GP_EMIT) emitted++;
+            if (op > GP_ACCR) {
+                *error = "unknown opcode";
+                return false;
+            }
+        }
+        if (emitted > ngc) {
+            *error = "gate " + std::to_string(g) + " emits " + std::to_string(emitted) + " constraints but num_gate_constraints is " +
+                     std::to_string(ngc) + " (num_constraints() gave too low of a number)";
+            return false;
+        }
+    }
+    if (wires_needed) *wires_needed = wn;
+    if (constants_needed) *constants_needed = cn;
+    return true;
+}
 
 static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
                                    const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
@@ -135,7 +184,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                         *error = "register read before any write";
                         return "";
                     }
-                    if (k < ngc) o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga[c], r" << ra << ", g_apow[c * NGC + " << k << "]);\n";
+                    o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga[c], r" << ra << ", g_apow[c * NGC + " << k << "]);\n";  // k < ngc: validated
                     k++;
                     break;
                 case GP_ACC: {  // acc[dst] += r[a] * imm[b]: two 32x32+64 multiply-adds, no modular step
@@ -196,6 +245,11 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
     GateKernel *k = new GateKernel();
     k->num_challenges = num_challenges;
     k->num_constraints = num_gate_constraints;
+    if (!gate_programs_validate(instrs, num_instrs, gates, num_gates, num_imms, num_selectors, num_gate_constraints, &k->wires_needed,
+                                &k->constants_needed, error)) {
+        delete k;
+        return nullptr;
+    }
     k->source = generate_source(instrs, num_instrs, gates, num_gates, imms, num_imms, num_selectors, num_gate_constraints,
                                 num_challenges, error);
     if (k->source.empty()) {
@@ -205,54 +259,94 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
     // On-disk cache (kernel_cache_dir()): the code object is keyed by a hash of the generated source, so a
     // circuit is compiled once per machine instead of once per process; the source is stored next to it for
     // inspection.
+    // The key also covers what turns the same source into a different code object: the hiprtc version and the target.
     std::string cache_path;
     if (std::string dir = kernel_cache_dir(); !dir.empty()) {
+        int rtc_major = 0, rtc_minor = 0;
+        (void)hiprtcVersion(&rtc_major, &rtc_minor);
+        const std::string salt = "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + JIT_ARCH + "\n";
         uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
+        for (unsigned char ch : salt) h = (h ^ ch) * 0x100000001b3ull;
         for (unsigned char ch : k->source) h = (h ^ ch) * 0x100000001b3ull;
         char name[64];
         snprintf(name, sizeof name, "/gate_%016llx", (unsigned long long)h);
         cache_path = dir + name;
     }
+    auto compile = [&](std::vector<char> &code) -> bool {
+        hiprtcProgram prog;
+        hiprtcResult r = hiprtcCreateProgram(&prog, k->source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
+        if (r != HIPRTC_SUCCESS) {
+            *error = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+            return false;
+        }
+        const std::string arch = std::string("--offload-arch=") + JIT_ARCH;
+        const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+        r = hiprtcCompileProgram(prog, 3, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t ls = 0;
+            hiprtcGetProgramLogSize(prog, &ls);
+            std::string log(ls, '\0');
+            if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            *error = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000);
+            hiprtcDestroyProgram(&prog);
+            return false;
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(prog, &cs);
+        code.resize(cs);
+        hiprtcGetCode(prog, code.data());
+        hiprtcDestroyProgram(&prog);
+        if (!cache_path.empty()) {
+            // Several processes (one per GPU) may build the same circuit at once: each writes a file of its own and
+            // renames it into place, so a reader sees either nothing or a whole code object.
+            const std::string tmp = cache_path + ".tmp." + std::to_string((long long)getpid());
+            std::ofstream(cache_path + ".hip." + std::to_string((long long)getpid())) << k->source;
+            (void)rename((cache_path + ".hip." + std::to_string((long long)getpid())).c_str(), (cache_path + ".hip").c_str());
+            bool written = false;
+            {
+                std::ofstream f(tmp, std::ios::binary);
+                f.write(code.data(), (std::streamsize)code.size());
+                f.flush();
+                written = f.good();
+            }
+            if (!written || rename(tmp.c_str(), (cache_path + ".hsaco").c_str()) != 0) (void)remove(tmp.c_str());
+        }
+        return true;
+    };
+    auto load = [&](const std::vector<char> &code) -> hipError_t {
+        hipError_t e = hipModuleLoadData(&k->module, code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "gate_constraints_kernel");
+        size_t bytes = 0;
+        if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_apow), &bytes, k->module, "g_apow");
+        if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_pih), &bytes, k->module, "g_pih");
+        return e;
+    };
     std::vector<char> code;
+    bool from_cache = false;
     if (!cache_path.empty()) {
         std::ifstream f(cache_path + ".hsaco", std::ios::binary);
         if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        from_cache = !code.empty();
     }
-    if (code.empty()) {
-    hiprtcProgram prog;
-    hiprtcResult r = hiprtcCreateProgram(&prog, k->source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
-    if (r != HIPRTC_SUCCESS) {
-        *error = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+    if (code.empty() && !compile(code)) {
         delete k;
         return nullptr;
     }
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    r = hiprtcCompileProgram(prog, 3, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t ls = 0;
-        hiprtcGetProgramLogSize(prog, &ls);
-        std::string log(ls, '\0');
-        if (ls) hiprtcGetProgramLog(prog, &log[0]);
-        *error = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000);
-        hiprtcDestroyProgram(&prog);
-        delete k;
-        return nullptr;
+    hipError_t e = load(code);
+    int ndev = 0;
+    if (e != hipSuccess && from_cache && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+        // a cached object that does not load (written by another ROCm, damaged): drop it and compile
+        (void)hipGetLastError();
+        if (k->module) (void)hipModuleUnload(k->module);
+        k->module = nullptr;
+        (void)remove((cache_path + ".hsaco").c_str());
+        code.clear();
+        if (!compile(code)) {
+            delete k;
+            return nullptr;
+        }
+        e = load(code);
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    code.resize(cs);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
-    if (!cache_path.empty()) {
-        std::ofstream(cache_path + ".hip") << k->source;
-        std::ofstream(cache_path + ".hsaco", std::ios::binary).write(code.data(), (std::streamsize)code.size());
-    }
-    }
-    hipError_t e = hipModuleLoadData(&k->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "gate_constraints_kernel");
-    size_t bytes = 0;
-    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_apow), &bytes, k->module, "g_apow");
-    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_pih), &bytes, k->module, "g_pih");
     if (e != hipSuccess) {
         *error = std::string("loading the compiled gate kernel: ") + hipGetErrorString(e);
         gate_kernel_destroy(k);
@@ -269,6 +363,8 @@ void gate_kernel_destroy(GateKernel *k) {
 
 uint32_t gate_kernel_num_challenges(const GateKernel *k) { return k->num_challenges; }
 uint32_t gate_kernel_num_constraints(const GateKernel *k) { return k->num_constraints; }
+uint32_t gate_kernel_wires_needed(const GateKernel *k) { return k->wires_needed; }
+uint32_t gate_kernel_constants_needed(const GateKernel *k) { return k->constants_needed; }
 const char *gate_kernel_source(const GateKernel *k) { return k->source.c_str(); }
 
 hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64_t w_rs, uint64_t w_es, const uint64_t *cs,

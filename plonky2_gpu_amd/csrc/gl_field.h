@@ -1,4 +1,4 @@
-// gl_field.cuh — Goldilocks field arithmetic for gfx950 device code.
+// gl_field.h — Goldilocks field arithmetic for gfx950 device code.
 //
 // p = 2^64 - 2^32 + 1. Values are plain-domain u64; like the reference
 // (field/src/goldilocks_field.rs:26) every u64 is a legal representative inside a kernel and
@@ -430,7 +430,7 @@ __device__ __forceinline__ uint64_t pow7(uint64_t x) {
     return mul(x3, x4);
 }
 
-// al + ah*2^32 (mod p) for any al and ah < 2^63 — the two 64-bit column sums of an MDS row (poseidon.cuh) and of
+// al + ah*2^32 (mod p) for any al and ah < 2^63 — the two 64-bit column sums of an MDS row (poseidon.h) and of
 // the gate programs' ACC accumulators. (h = ah.hi + carry <= 2^31, so after the one possible wrap of
 // l + h*(2^32 - 1) the value is below h*2^32 <= 2^63 and adding 2^32 - 1 cannot wrap again.) The compiler's version of "fold into (lo64, hi32), then reduce96" is ~18 issue
 // slots of double-pumped 64-bit compares and adds; with the carry flags it is 7 single instructions:

@@ -20,8 +20,8 @@
 
 #include <mutex>
 
-#include "poseidon.cuh"
-#include "poseidon_coop.cuh"
+#include "poseidon.h"
+#include "poseidon_coop.h"
 
 namespace plonky2_hip {
 
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void permute_batch_kernel(uint64_t *states, ui
 }
 
 // The transcript's sponge (iop/challenger.rs:131-149 run over several full rate blocks): serial by
-// definition, so ONE wavefront computes each permutation cooperatively (poseidon_coop.cuh); state[0..8)
+// definition, so ONE wavefront computes each permutation cooperatively (poseidon_coop.h); state[0..8)
 // is overwritten by each block, then permuted.
 __global__ __launch_bounds__(64) void sponge_absorb_kernel(uint64_t *state, const uint64_t *inputs, uint32_t n_blocks,
                                                            poseidon_coop::Tables tb) {

@@ -26,9 +26,11 @@
 //    (fft.rs:92-101) folded into the last pass's store addresses.
 #include "ntt.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
-#include "gl_field.cuh"
+#include "gl_field.h"
 
 namespace plonky2_hip {
 
@@ -39,7 +41,9 @@ constexpr int LOGE = 13;           // tile = 8192 elements
 constexpr int E = 1 << LOGE;
 constexpr int LDS_DATA = E + E / 16;  // padded tile
 
-enum : uint32_t { F_LOAD_ROWS = 1, F_STORE_ROWS = 2, F_NATURAL = 4, F_INVERSE = 8, F_COSET = 16 };
+enum : uint32_t { F_LOAD_ROWS = 1, F_STORE_ROWS = 2, F_NATURAL = 4, F_INVERSE = 8, F_COSET = 16,
+                  F_WIDE = 32,
+                  F_RAW_OUT = 64 };  // the pass feeds another pass: its output need not be canonical (any u64 representative is a legal input)  // F_WIDE: the planner laid the pass out for tiles of 2^(LOGE+1) elements (ntt_pass_wave_kernel, LOGW = 4)
 
 struct PassParams {
     const uint64_t *src;
@@ -89,6 +93,25 @@ __device__ __forceinline__ uint64_t wpow(const PassParams &p, uint64_t x) {
     return lo ? gl::mul(h, p.twl[lo]) : h;
 }
 
+// Inter-pass twiddle of the thread that holds, after the pass's last radix-16 round, the outputs
+// k1 = bitrev4(i)*(R/16) + kr of column L: w^(L*k1) = c * step^bitrev4(i) with c = w^(L*kr) (times the coset power
+// s_r^L and the inverse's 1/n where they apply) and step = w^(L*R/16). Four table look-ups in global memory.
+template <int LOGT, int LOGR>
+__device__ __forceinline__ void twiddle_chain(const PassParams &p, uint32_t tid, uint32_t b, uint32_t z, uint64_t &c, uint64_t &step) {
+    constexpr uint32_t TMASK = (1u << LOGT) - 1;
+    uint32_t l = tid & TMASK, rest = tid >> LOGT;
+    uint64_t L = (uint64_t)b * (1u << LOGT) + l;
+    uint32_t kr = brev_rt(rest, LOGR - 4);
+    c = wpow(p, L * kr);
+    if (p.flags & F_COSET) {
+        // fold s_r^L (coset shift power of the low index) into the chain start
+        uint64_t sl = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[z * 1024 + (uint32_t)(L & 1023)]);
+        c = gl::mul(c, sl);
+    }
+    if (p.chain_scale != 1) c = gl::mul(c, p.chain_scale);
+    step = wpow(p, L << (LOGR - 4));
+}
+
 // In-register radix-2^D DIF butterfly on v[BASE .. BASE+2^D): output slot i holds frequency
 // bitrev_D(i). Stage twiddles w_{2^(s+1)}^j = 2^(39*j*(32>>s)) are multiply-free.
 template <int D, int BASE>
@@ -126,10 +149,28 @@ __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
 // group is (group base) + i * (compile-time stride): bits [SH, SH+D) of m are zero in the base, so
 // neither the index nor its pad term (idx >> (4+LOGT)) << LOGT can carry — every ds_read/ds_write
 // of the round uses one base VGPR and an immediate offset.
-template <int LOGR, int D, int SH, bool TWIDDLE>
+// The tile the round works on has 2^LOGE_ elements and NT_ = 2^LOGE_ / 16 threads: the whole workgroup's tile
+// (NT_ = NT = 512) or one wavefront's private tile (NT_ = 64), see ntt_pass_wave_kernel.
+template <int NT_>
+__device__ __forceinline__ void tile_sync() {
+    if constexpr (NT_ == 64) {
+        // One wavefront owns the tile. The LDS executes a wavefront's operations in program order, so a later
+        // ds_read of another lane's slot sees the earlier ds_write without any wait; what is needed is only that the
+        // compiler keeps the program order of the accesses (it must: the indices may alias) and does not schedule
+        // across this point.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int LOGE_, int NT_, int LOGR, int D, int SH, bool TWIDDLE>
 __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
-                                            uint32_t b) {
-    constexpr int RD = 1 << D, G = 16 >> D, LOGT = LOGE - LOGR;
+                                            uint32_t b, uint32_t z, const uint64_t *chain = nullptr) {
+    static_assert((1 << LOGE_) == 16 * NT_, "sixteen elements per thread");
+    constexpr int NT = NT_;
+    constexpr int RD = 1 << D, G = 16 >> D, LOGT = LOGE_ - LOGR;
     constexpr uint32_t TMASK = (1u << LOGT) - 1;
     static_assert(SH == 0 || SH >= 4, "digits below the top one are radix-16");
     // element stride in the padded image
@@ -148,7 +189,7 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
             v[g * RD + i] = data[base[g] + i * STRIDE];
         });
     });
-    if (natural) __syncthreads();  // slots are permuted on write-back: everyone must have read
+    if (natural) tile_sync<NT_>();  // slots are permuted on write-back: everyone must have read
     static_for<0, G>([&](auto G_) { radix_dif<D, decltype(G_)::value * RD>(v); });
 
     if constexpr (SH > 0) {
@@ -167,18 +208,12 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
     } else if constexpr (TWIDDLE) {
         // inter-pass twiddle w_{2^tw_hi}^(L * k1), k1 = bitrev4(i)*(R/16) + kr  (G == 1, D == 4)
         static_assert(D == 4 || !TWIDDLE, "twiddled passes end with a radix-16 round");
-        uint32_t l = tid & TMASK, rest = tid >> LOGT;
-        uint64_t L = (uint64_t)b * (1u << LOGT) + l;
-        uint32_t kr = brev_rt(rest, LOGR - 4);
-        uint64_t c = wpow(p, L * kr);
-        if (p.flags & F_COSET) {
-            // fold s_r^L (coset shift power of the low index) into the chain start
-            uint32_t r = blockIdx.z;
-            uint64_t sl = gl::mul(p.cs_hi[r * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[r * 1024 + (uint32_t)(L & 1023)]);
-            c = gl::mul(c, sl);
+        uint64_t c, step;
+        if (chain) {
+            c = chain[0], step = chain[1];
+        } else {
+            twiddle_chain<LOGT, LOGR>(p, tid, b, z, c, step);
         }
-        if (p.chain_scale != 1) c = gl::mul(c, p.chain_scale);
-        uint64_t step = wpow(p, L << (LOGR - 4));
         static_for<0, 16>([&](auto J_) {
             constexpr int j = decltype(J_)::value;
             constexpr int i = brev_c(j, 4);
@@ -215,16 +250,28 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
     }
 }
 
-template <int LOGR, int SH, bool TWIDDLE>
+template <int LOGE_, int NT_, int LOGR, int SH, bool TWIDDLE>
 __device__ __forceinline__ void radix16_rounds(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
-                                               uint32_t b) {
+                                               uint32_t b, uint32_t z, const uint64_t *chain) {
     if constexpr (SH >= 0) {
-        radix_round<LOGR, 4, SH, TWIDDLE>(data, tw, p, tid, b);
+        radix_round<LOGE_, NT_, LOGR, 4, SH, TWIDDLE>(data, tw, p, tid, b, z, chain);
         if constexpr (SH > 0) {
-            __syncthreads();
-            radix16_rounds<LOGR, SH - 4, TWIDDLE>(data, tw, p, tid, b);
+            tile_sync<NT_>();
+            radix16_rounds<LOGE_, NT_, LOGR, SH - 4, TWIDDLE>(data, tw, p, tid, b, z, chain);
         }
     }
+}
+
+// The R-point DIF of a tile: a short first digit (radix 2/4/8) absorbs LOGR mod 4, radix-16 digits follow.
+template <int LOGE_, int NT_, int LOGR, bool TWIDDLE>
+__device__ __forceinline__ void tile_transform(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid, uint32_t b,
+                                               uint32_t z, const uint64_t *chain = nullptr) {
+    constexpr int D0 = LOGR % 4;
+    if constexpr (D0 != 0) {
+        radix_round<LOGE_, NT_, LOGR, D0, LOGR - D0, TWIDDLE>(data, tw, p, tid, b, z, chain);
+        if constexpr (LOGR - D0 > 0) tile_sync<NT_>();
+    }
+    radix16_rounds<LOGE_, NT_, LOGR, LOGR - D0 - 4, TWIDDLE>(data, tw, p, tid, b, z, chain);
 }
 
 struct alignas(16) u64x2 {
@@ -291,12 +338,7 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
     __syncthreads();
 
     // ---- R-point DIF in LDS/registers ------------------------------------------------------
-    constexpr int D0 = LOGR % 4;
-    if constexpr (D0 != 0) {
-        radix_round<LOGR, D0, LOGR - D0, TWIDDLE>(data, tw, p, tid, b);
-        if constexpr (LOGR - D0 > 0) __syncthreads();
-    }
-    radix16_rounds<LOGR, LOGR - D0 - 4, TWIDDLE>(data, tw, p, tid, b);
+    tile_transform<LOGE, NT, LOGR, TWIDDLE>(data, tw, p, tid, b, z);
     __syncthreads();
 
     // ---- store tile ------------------------------------------------------------------------
@@ -355,6 +397,355 @@ __global__ __launch_bounds__(NT) void ntt_pass_kernel(const PassParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass with the tile split into eight wavefront-private sub-tiles (R <= 1024).
+//
+// ntt_pass_kernel above synchronises its eight wavefronts four or five times per tile, and a CU holds two
+// such workgroups: the waves of a workgroup run their load, their rounds and their store in lockstep, and the
+// counters show it (rocprofv3, 2^20: vector ALU ~70 % busy, memory ~65 % busy, waves parked 65 % of their
+// lifetime — profiles/r02_*). Here a wavefront owns 1024 elements of the tile — TW = 1024/R whole columns
+// (rows in a row pass) — in its own padded LDS buffer and runs all radix rounds of its R-point transforms by
+// itself: between rounds it needs no barrier at all, because the LDS executes one wavefront's reads and writes in
+// program order (tile_sync<64>). Workgroup barriers remain only where the eight waves exchange data through LDS
+// to make global accesses wide: a column-pass load (T adjacent columns per row = one T*8-byte segment; the
+// segment is spread over the wave buffers on arrival), a column-pass store and the transposed natural-order
+// store of a row pass. A row pass that reads and writes whole rows (every pass of the bit-reversed transforms of
+// the LDE / commit path) has no barrier after the twiddle table is in place, and its waves drift apart: while
+// one waits for its row, the other three of its SIMD compute.
+//
+// LDS: 8 buffers of 1024 + 64 pad + 2 skew words, + the twiddle table of w_R = 77,952 bytes: two workgroups per CU,
+// four waves per SIMD, as before. Grid, tile geometry and PassParams are those of ntt_pass_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int WT = 64;                    // threads of a wave tile
+constexpr int LOGEW = 10;                 // wave tile = 1024 elements
+constexpr int EW = 1 << LOGEW;
+constexpr int WIDE_MIN_LOGR = 7;           // wide (16-wave) tiles are instantiated for R >= 128
+constexpr int WBUF = EW + EW / 16 + 2;    // padded wave buffer; the skew of 2 words spreads the eight buffers over
+                                          // the banks for the cooperative (cross-buffer) accesses
+
+// Workgroup barrier that waits for this wave's LDS traffic only. __syncthreads() also drains vmcnt (hipcc puts
+// s_waitcnt vmcnt(0) in front of it), which would stall on the NEXT tile's global loads that are meant to stay in
+// flight across the whole transform of the current one.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LOGW = log2 of the wavefronts per workgroup: 3 (tile of 8192 elements, two workgroups per CU) or 4 (16384 elements, one
+// workgroup per CU): the wide tile doubles the segments of the cooperative accesses to 128 bytes — whole cache lines —
+// which the memory system moves ~25 % faster than 64-byte halves (tools/ubench_mem.hip, profiles/r02_ubench_mem.txt).
+template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW>
+__global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pass_wave_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t total) {
+    static_assert(LOGR <= LOGEW, "a wave tile holds whole R-point columns");
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    constexpr int R = 1 << LOGR;
+    constexpr int NT = 64 << LOGW, WAVES = 1 << LOGW, LOGE = LOGEW + LOGW;  // this kernel's workgroup geometry
+    constexpr uint32_t logt = LOGE - LOGR, T = 1u << logt;        // columns of the workgroup tile
+    constexpr uint32_t logtw = LOGEW - LOGR, TW = 1u << logtw;    // columns of a wave tile
+    static_assert(T >= 2, "16-byte accesses");
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint64_t *data = lds + wave * WBUF;   // this wave's tile
+    uint64_t *tw = lds + WAVES * WBUF;
+    // slot of element (row m, column t) of the workgroup tile
+    auto slot = [&](uint32_t m, uint32_t t) -> uint32_t {
+        return (t >> logtw) * WBUF + phys((m << logtw) + (t & (TW - 1)), logtw);
+    };
+    constexpr bool rows_in = ROWS_IN, rows_out = ROWS_OUT;  // F_LOAD_ROWS / F_STORE_ROWS, fixed at compile time
+    const bool coset = p.flags & F_COSET, inverse = p.flags & F_INVERSE, do_scale = p.scale != 1;
+
+    // tile id -> (b, a, z) of the grid the planner describes (b fastest)
+    auto decode = [&](uint32_t id, uint32_t &b, uint32_t &a, uint32_t &z) {
+        b = id % gx;
+        const uint32_t q = id / gx;
+        a = q % gy;
+        z = q / gy;
+    };
+    // the tile's global loads, 8 x 16 B per thread, left in flight
+    auto issue_loads = [&](uint32_t id, u64x2 (&pre)[8]) {
+        uint32_t b, a, z;
+        decode(id, b, a, z);
+        const uint64_t in_base = a * p.in_sa + b * p.in_sb + z * p.in_sz;
+        // Every tile is full (the planner sends ragged ones to ntt_pass_kernel): no bounds checks, straight-line code,
+        // all eight loads in flight at once.
+        if constexpr (!rows_in) {
+            // column pass: T adjacent columns of a row are one segment; 16 B per lane = two columns
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = tid + it * NT;
+                uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                pre[it] = *reinterpret_cast<const u64x2 *>(p.src + in_base + t + (uint64_t)m * p.in_m);
+            }
+        } else {
+            // row pass: a wave reads its own TW rows, 16 B per lane along the row
+            const uint64_t az_base = a * p.in_sa + z * p.in_sz;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = lane + it * WT;
+                uint32_t tl = c & (TW - 1), t = wave * TW + tl, m = (c >> logtw) * 2;
+                // inverse natural-order row pass: the row tile is rotated by one (t_limit is a power of two there)
+                const uint32_t shifted = (b * T + t + p.row_shift) & (p.t_limit - 1);
+                const uint64_t off = p.row_shift ? az_base + (uint64_t)shifted * p.in_t : in_base + (uint64_t)t * p.in_t;
+                pre[it] = *reinterpret_cast<const u64x2 *>(p.src + off + m);
+            }
+        }
+    };
+
+    if constexpr (LOGR >= 5)
+        for (uint32_t e = tid; e < (uint32_t)R; e += NT) tw[e] = p.twh[e << (12 - LOGR)];
+
+    // A workgroup walks the tiles id = blockIdx.x, + gridDim.x, ...; the loads of tile k+1 are issued as soon as
+    // tile k sits in LDS and land while its radix rounds run: without this every CU of the chip loads, then
+    // computes, then stores in step with all the others, and neither the memory system nor the vector ALU is busy
+    // for more than two thirds of the time.
+    // registers -> LDS for tile `id` whose loads are in flight in `pre`
+    auto land = [&](uint32_t id, u64x2 (&pre)[8]) {
+        uint32_t z = id / (gx * gy);
+        uint32_t tid_i = tid, lane_i = lane;
+        asm volatile("" : "+v"(tid_i), "+v"(lane_i));
+        if constexpr (!rows_in) {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = tid_i + it * NT;
+                uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                u64x2 val = pre[it];
+                if (coset) {
+                    // input scale (s_r^N2)^m = s_r^(m * in_m), through the two-level table (exponents add)
+                    uint64_t ex = (uint64_t)m * p.in_m;
+                    uint64_t sc = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(ex >> 10)], p.cs_lo[z * 1024 + (uint32_t)(ex & 1023)]);
+                    val.x = gl::mul(val.x, sc);
+                    val.y = gl::mul(val.y, sc);
+                }
+                if constexpr (TW >= 2) {
+                    *reinterpret_cast<u64x2 *>(&lds[slot(m, t)]) = val;
+                } else {
+                    lds[slot(m, t)] = val.x;
+                    lds[slot(m, t + 1)] = val.y;
+                }
+            }
+            lds_barrier();  // the segments are spread over the wave buffers
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = lane_i + it * WT;
+                uint32_t tl = c & (TW - 1), m = (c >> logtw) * 2;
+                data[phys((m << logtw) + tl, logtw)] = pre[it].x;
+                data[phys(((m + 1) << logtw) + tl, logtw)] = pre[it].y;
+            }
+            tile_sync<WT>();
+        }
+    };
+
+    // One iteration works on tile k, whose elements sit in LDS, while the loads of tile k+1 (issued at the end of the
+    // previous iteration) and the stores of tile k-1 are in flight:
+    //     radix rounds of k -> results of k from LDS into registers -> tile k+1: wait for its loads, registers -> LDS,
+    //     twiddle-chain look-ups of k+1 -> stores of k -> loads of k+2 issued.
+    // Order matters for the waits: vmcnt counts loads and stores together in issue order, and the compiler's counted
+    // waits for the prefetched registers do not discount younger stores — so the stores of k are issued only AFTER
+    // tile k+1 has landed (its loads are then the youngest operations and the wait is exact), and they have all of the
+    // next tile's radix rounds to drain.
+    u64x2 pre[8];
+    uint64_t chain[2] = {1, 1};
+    uint32_t id = blockIdx.x;
+    const uint32_t G = gridDim.x;
+    auto chain_of = [&](uint32_t tile) {
+        if constexpr (TWIDDLE) {
+            uint32_t b, a, z;
+            decode(tile, b, a, z);
+            uint32_t lane_i = lane;
+            asm volatile("" : "+v"(lane_i));
+            twiddle_chain<logtw, LOGR>(p, lane_i, b * WAVES + wave, z, chain[0], chain[1]);
+        }
+    };
+    if (id < total) issue_loads(id, pre);
+    lds_barrier();  // the twiddle table
+    if (id < total) {
+        land(id, pre);
+        chain_of(id);
+        if (id + G < total) issue_loads(id + G, pre);
+    }
+
+    for (; id < total; id += G) {
+        const uint32_t nid = id + G;
+        uint32_t b, a, z;
+        decode(id, b, a, z);
+        // Per-thread slot and address arithmetic is the same for every tile; left to itself the compiler hoists all of it
+        // out of this loop and keeps it in registers next to the prefetched tile (128 VGPRs, then scratch). Recomputing
+        // it per tile costs a few dozen integer instructions.
+        uint32_t tid_i = tid, lane_i = lane;
+        asm volatile("" : "+v"(tid_i), "+v"(lane_i));
+
+        // ---- R-point DIFs of this wave's TW columns, no workgroup barrier ------------------------
+        tile_transform<LOGEW, WT, LOGR, TWIDDLE>(data, tw, p, lane_i, b * WAVES + wave, z, TWIDDLE ? chain : nullptr);
+
+        // ---- results: LDS -> registers ----------------------------------------------------------------
+        u64x2 res[8];
+        if constexpr (!rows_out) {
+            lds_barrier();  // segments are gathered across the wave buffers
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = tid_i + it * NT;
+                uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                if constexpr (TW >= 2) {
+                    res[it] = *reinterpret_cast<const u64x2 *>(&lds[slot(m, t)]);
+                } else {
+                    res[it].x = lds[slot(m, t)];
+                    res[it].y = lds[slot(m, t + 1)];
+                }
+            }
+        } else {
+            tile_sync<WT>();
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                uint32_t c = lane_i + it * WT;
+                uint32_t tl = c & (TW - 1), m = (c >> logtw) * 2;
+                res[it].x = data[phys((m << logtw) + tl, logtw)];
+                res[it].y = data[phys(((m + 1) << logtw) + tl, logtw)];
+            }
+        }
+        // the next tile's arrival overwrites buffers that a cooperative load / store lets other waves touch
+        if constexpr (!(rows_in && rows_out))
+            lds_barrier();
+        else
+            tile_sync<WT>();
+
+        // ---- tile k+1 lands ---------------------------------------------------------------------------
+        if (nid < total) {
+            land(nid, pre);
+            chain_of(nid);
+        }
+
+        // ---- stores of tile k -------------------------------------------------------------------------
+        const uint32_t zo = coset ? brev_rt(z, p.rate_bits) : z;
+        const uint64_t out_base = a * p.out_sa + b * p.out_sb + zo * p.out_sz;
+        auto finish = [&](u64x2 val) {
+            if (do_scale) {
+                val.x = gl::mul(val.x, p.scale);
+                val.y = gl::mul(val.y, p.scale);
+            }
+            if (!(p.flags & F_RAW_OUT)) {
+                val.x = gl::canon(val.x);
+                val.y = gl::canon(val.y);
+            }
+            return val;
+        };
+        if constexpr (!rows_out) {
+            if (!inverse) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    uint32_t c = tid_i + it * NT;
+                    uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                    *reinterpret_cast<u64x2 *>(p.dst + out_base + t + (uint64_t)m * p.out_m) = finish(res[it]);
+                }
+            } else if (p.row_shift) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    uint32_t c = tid_i + it * NT;
+                    uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                    u64x2 val = finish(res[it]);
+                    uint64_t ob = a * p.out_sa + zo * p.out_sz + (uint64_t)m * p.out_m;
+                    uint32_t r0 = (b * T + t + p.row_shift) & (p.t_limit - 1), r1 = (b * T + t + 1 + p.row_shift) & (p.t_limit - 1);
+                    p.dst[flip_index(ob + r0, p.log_n)] = val.x;
+                    p.dst[flip_index(ob + r1, p.log_n)] = val.y;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    uint32_t c = tid_i + it * NT;
+                    uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);
+                    u64x2 val = finish(res[it]);
+                    uint64_t o = out_base + t + (uint64_t)m * p.out_m;
+                    p.dst[flip_index(o, p.log_n)] = val.x;
+                    p.dst[flip_index(o + 1, p.log_n)] = val.y;
+                }
+            }
+        } else {
+            if (!inverse) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    uint32_t c = lane_i + it * WT;
+                    uint32_t tl = c & (TW - 1), t = wave * TW + tl, m = (c >> logtw) * 2;
+                    *reinterpret_cast<u64x2 *>(p.dst + out_base + (uint64_t)t * p.out_t + m) = finish(res[it]);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    uint32_t c = lane_i + it * WT;
+                    uint32_t tl = c & (TW - 1), t = wave * TW + tl, m = (c >> logtw) * 2;
+                    u64x2 val = finish(res[it]);
+                    uint64_t o = out_base + (uint64_t)t * p.out_t + m;
+                    p.dst[flip_index(o, p.log_n)] = val.x;
+                    p.dst[flip_index(o + 1, p.log_n)] = val.y;
+                }
+            }
+        }
+        // ---- loads of tile k+2 ------------------------------------------------------------------------
+        if (nid + G < total && nid + G > nid) issue_loads(nid + G, pre);
+    }
+}
+
+// PLONKY2_NTT_KERNEL=tile selects the workgroup-tile kernel for every size (A/B measurements, tests of both)
+static bool use_wave_kernel() {
+    static const bool v = [] {
+        const char *e = getenv("PLONKY2_NTT_KERNEL");
+        return !(e && e[0] == 't');
+    }();
+    return v;
+}
+
+// Two workgroups per CU (the LDS holds no more), each walking its share of the tiles
+static uint32_t persistent_workgroups() {
+    static const uint32_t v = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        if (const char *e = getenv("PLONKY2_NTT_WG_PER_CU")) {
+            int k = atoi(e);
+            if (k >= 1 && k <= 8) return (uint32_t)(cus * k);
+        }
+        return (uint32_t)(2 * cus);
+    }();
+    return v;
+}
+
+template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW = 3>
+hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t stream) {
+    size_t lds_bytes = (size_t)((WBUF << LOGW) + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+    if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t resident = persistent_workgroups() >> (LOGW - 3);  // the LDS holds two 8-wave or one 16-wave workgroup per CU
+    const uint32_t wgs = (uint32_t)(total < resident ? total : resident);
+    const PassParams &p = p_in;
+    hipLaunchKernelGGL((ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW>), dim3(wgs), dim3(64 << LOGW), lds_bytes, stream, p,
+                       (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)total);
+    return hipGetLastError();
+}
+
+// The planner's passes come in three shapes: column pass (segments in, segments out), row pass with transposed
+// natural-order output (rows in, segments out), row pass in place (rows in, rows out).
+template <int LOGR, bool TWIDDLE>
+hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) {
+    const bool ri = p.flags & F_LOAD_ROWS, ro = p.flags & F_STORE_ROWS;
+    if constexpr (LOGR >= WIDE_MIN_LOGR) {
+        if (p.flags & F_WIDE) {
+            if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false, 4>(p, grid, stream);
+            if constexpr (!TWIDDLE)
+                if (ri && !ro) return launch_pass_wave_mode<LOGR, false, true, false, 4>(p, grid, stream);
+            return hipErrorInvalidValue;
+        }
+    }
+    if (p.flags & F_WIDE) return hipErrorInvalidValue;
+    if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false>(p, grid, stream);
+    if constexpr (!TWIDDLE) {  // row passes carry no inter-pass twiddle
+        if (ri && !ro) return launch_pass_wave_mode<LOGR, false, true, false>(p, grid, stream);
+        if (ri && ro) return launch_pass_wave_mode<LOGR, false, true, true>(p, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int LOGR, bool TWIDDLE>
 hipError_t launch_pass(const PassParams &p, dim3 grid, hipStream_t stream) {
     size_t lds_bytes = (size_t)(LDS_DATA + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
@@ -371,6 +762,30 @@ hipError_t launch_pass(const PassParams &p, dim3 grid, hipStream_t stream) {
 
 template <bool TWIDDLE>
 hipError_t dispatch_pass(int logr, const PassParams &p, dim3 grid, hipStream_t stream) {
+    const int loge = LOGE + ((p.flags & F_WIDE) ? 1 : 0);
+    const bool full_tiles = logr <= loge && (p.t_limit & ((1u << (loge - logr)) - 1)) == 0;  // ragged tiles keep the bounds-checked kernel
+    if (!full_tiles && (p.flags & F_WIDE)) return hipErrorInvalidValue;  // the planner checks before it asks for wide tiles
+    if (use_wave_kernel() && full_tiles) {
+        // a column pass / transposed store of a wave kernel needs >= 2 columns per tile (16-byte accesses): R <= 4096
+        // holds for every planned pass; wave tiles exist for R <= 1024
+        switch (logr) {
+#define CASE(L) \
+    case L:     \
+        return launch_pass_wave<L, TWIDDLE>(p, grid, stream);
+            CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+            default:
+                break;
+        }
+        if constexpr (!TWIDDLE) {
+            switch (logr) {
+                case 1: return launch_pass_wave<1, false>(p, grid, stream);
+                case 2: return launch_pass_wave<2, false>(p, grid, stream);
+                case 3: return launch_pass_wave<3, false>(p, grid, stream);
+                default: break;
+            }
+        }
+    }
     switch (logr) {
 #define CASE(L) \
     case L:     \
@@ -405,6 +820,18 @@ static void base_params(PassParams &p, const NttTables &tb) {
     p.twh = tb.twh;
     p.scale = 1;
     p.chain_scale = 1;
+}
+
+// Passes whose global accesses are segments of T elements (column passes, transposed natural-order stores) use tiles of
+// 2^(LOGE+1) elements when the wave kernel can take them: T doubles, and so do the segments (64 -> 128 bytes at 2^20).
+// PLONKY2_NTT_WIDE=0 keeps the 8192-element tiles (A/B measurements).
+static bool wide_ok(uint32_t logr, uint64_t t_limit) {
+    static const bool enabled = [] {
+        const char *e = getenv("PLONKY2_NTT_WIDE");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && use_wave_kernel() && logr >= (uint32_t)WIDE_MIN_LOGR && logr <= (uint32_t)LOGEW &&
+           (t_limit & ((1ull << (LOGE + 1 - logr)) - 1)) == 0;
 }
 
 hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, uint64_t n_polys, uint32_t log_n,
@@ -451,7 +878,9 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass)
         const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
-        const uint32_t logtA = LOGE - la, TA = 1u << logtA, logtB = LOGE - lb, TB = 1u << logtB;
+        // measured at 2^20 on one device: wide tiles make the column pass 6 % faster and the transposed-store row pass 4 % slower
+        const bool wideA = wide_ok(la, N2), wideB = false;
+        const uint32_t logtA = LOGE + wideA - la, TA = 1u << logtA, logtB = LOGE + wideB - lb, TB = 1u << logtB;
         if (inverse && !natural) return hipErrorInvalidValue;  // bit-reversed inverse is not on the path
         if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
         // Bit-reversed order: both passes rewrite exactly the addresses they read -> in place.
@@ -463,6 +892,10 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
             chunk = tb.scratch_elems / n;
             if (chunk > 65535) chunk = 65535;
+        }
+        if (const char *ev = getenv("PLONKY2_NTT_CHUNK_COLS")) {  // tuning knob (tools/ntt_chunk_sweep.py)
+            uint64_t c = strtoull(ev, nullptr, 10);
+            if (c >= 1 && c < chunk) chunk = c;
         }
         for (uint64_t off = 0; off < n_polys; off += chunk) {
             const uint64_t cnt = n_polys - off < chunk ? n_polys - off : chunk;
@@ -482,7 +915,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.out_sb = TA;
             p.out_t = 1;
             p.out_m = N2;
-            p.flags = natural ? F_NATURAL : 0;
+            p.flags = (natural ? F_NATURAL : 0) | (wideA ? F_WIDE : 0) | F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = log_n;
             p.chain_scale = n_inv;  // the inverse's n^-1 rides on the twiddle chain (1 multiply per thread)
@@ -504,7 +937,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
                 p.out_sb = TB;
                 p.out_t = 1;
                 p.out_m = N1;
-                p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0);
+                p.flags = F_LOAD_ROWS | F_NATURAL | (inverse ? F_INVERSE : 0) | (wideB ? F_WIDE : 0);
                 p.row_shift = inverse ? 1 : 0;
             } else {
                 p.out_sb = (uint64_t)TB * N2;
@@ -552,7 +985,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.out_sb = T1;
             p.out_t = 1;
             p.out_m = N23;
-            p.flags = natural ? F_NATURAL : 0;
+            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = log_n;
             p.chain_scale = n_inv;
@@ -573,7 +1006,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.out_sz = N23;
             p.out_t = 1;
             p.out_m = N3;
-            p.flags = natural ? F_NATURAL : 0;
+            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = lb + lc;
             e = dispatch_pass<true>(lb, p, dim3((unsigned)(N3 / T2), (unsigned)cnt, (unsigned)N1), stream);
@@ -772,7 +1205,7 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
             p.out_sz = n;
             p.out_t = 1;
             p.out_m = N23;
-            p.flags = F_COSET;
+            p.flags = F_COSET | F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = log_n;
             hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N23 / T1), (unsigned)cnt, (unsigned)n_cosets), stream);
@@ -792,6 +1225,7 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
             p.out_sz = N23;
             p.out_t = 1;
             p.out_m = N3;
+            p.flags = F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = lb + lc;
             e = dispatch_pass<true>(lb, p, dim3((unsigned)(N3 / T2), (unsigned)(cnt * n_cosets), (unsigned)N1), stream);
@@ -825,7 +1259,8 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
         uint64_t cnt = n_polys - off < 65535 ? n_polys - off : 65535;
         PassParams p;
         base_params(p, tb);
-        uint32_t logtA = LOGE - la, TA = 1u << logtA;
+        const bool wideA = wide_ok(la, N2);
+        uint32_t logtA = LOGE + wideA - la, TA = 1u << logtA;
         p.src = coeffs + off * src_stride;
         p.dst = dst + off * dst_stride;
         p.cs_hi = ct.hi;
@@ -844,7 +1279,7 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
         p.out_sz = n;
         p.out_t = 1;
         p.out_m = N2;
-        p.flags = F_COSET;
+        p.flags = F_COSET | F_RAW_OUT | (wideA ? F_WIDE : 0);
         p.log_n = log_n;
         p.tw_hi = log_n;
         hipError_t e = dispatch_pass<true>(la, p, dim3((unsigned)(N2 / TA), (unsigned)cnt, (unsigned)n_cosets), stream);

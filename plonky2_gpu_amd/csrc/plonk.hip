@@ -14,7 +14,7 @@
 // exactly in the reference's order (plonk_common.rs:97-114).
 #include "plonk.h"
 
-#include "gl_field.cuh"
+#include "gl_field.h"
 
 namespace plonky2_hip {
 
@@ -361,6 +361,9 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
     if (a.gate_kernel) {
         if (a.gate_terms || a.gate_program || !a.gate_partial_workspace || !a.public_inputs_hash) return hipErrorInvalidValue;
         if (gate_kernel_num_challenges(a.gate_kernel) != a.num_challenges) return hipErrorInvalidValue;
+        // the compiled programs index wire and constant columns by literal: they must exist in the leaves handed over
+        if (gate_kernel_wires_needed(a.gate_kernel) > a.wires_len || gate_kernel_constants_needed(a.gate_kernel) > a.num_constants)
+            return hipErrorInvalidValue;
         hipError_t ge = gate_kernel_launch(a.gate_kernel, a.wires_leaves, p.w_rs, p.w_es, a.cs_leaves, p.c_rs, p.c_es, a.alphas,
                                            a.public_inputs_hash, 1ull << (a.degree_bits + qdb), a.gate_partial_workspace, stream);
         if (ge != hipSuccess) return ge;

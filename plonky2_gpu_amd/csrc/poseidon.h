@@ -1,4 +1,4 @@
-// poseidon.cuh — Poseidon permutation over Goldilocks (width 12, 4+22+4 rounds, x^7) for gfx950.
+// poseidon.h — Poseidon permutation over Goldilocks (width 12, 4+22+4 rounds, x^7) for gfx950.
 //
 // Same permutation as Poseidon::poseidon (plonky2/src/hash/poseidon.rs:602-616) with the "fast"
 // partial rounds (poseidon.rs:312-365, 400-427), restructured in blocks of eleven rounds (see
@@ -7,7 +7,7 @@
 // s_load / literals, not per-lane loads.
 // Integer modular arithmetic only — no MFMA use is possible or attempted.
 #pragma once
-#include "gl_field.cuh"
+#include "gl_field.h"
 
 #define POSEIDON_CONST __device__ const
 #include "poseidon_constants.h"
@@ -54,7 +54,7 @@ __device__ __forceinline__ void full_round(uint64_t (&s)[W], const uint64_t *__r
     mds_layer(s, rc_next);
 }
 
-// lazy dot products (one reduction per sum): gl::DotAcc / dot_term / dot_finish in gl_field.cuh
+// lazy dot products (one reduction per sum): gl::DotAcc / dot_term / dot_finish in gl_field.h
 using gl::DotAcc;
 using gl::dot_finish;
 using gl::dot_term;

@@ -1,6 +1,6 @@
-// poseidon_coop.cuh — ONE Poseidon permutation computed by a whole wavefront (latency version).
+// poseidon_coop.h — ONE Poseidon permutation computed by a whole wavefront (latency version).
 //
-// The thread-per-permutation kernel (poseidon.cuh) is built for throughput: ~20k dependent VALU
+// The thread-per-permutation kernel (poseidon.h) is built for throughput: ~20k dependent VALU
 // instructions per lane, i.e. ~60 us of latency. That is what a Fiat-Shamir transcript (serial by
 // definition, iop/challenger.rs) and the top layers of a Merkle tree (a handful of nodes per
 // layer) pay per permutation. Here the twelve state words live in twelve lanes:
@@ -16,7 +16,7 @@
 // ~4k instructions per permutation instead of ~20k; same permutation bit for bit (tests compare
 // with the reference's known answers).
 #pragma once
-#include "poseidon.cuh"
+#include "poseidon.h"
 
 namespace poseidon_coop {
 

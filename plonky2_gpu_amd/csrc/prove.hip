@@ -17,7 +17,8 @@
 #include <vector>
 
 #include "../../include/plonky2_hip.h"
-#include "gl_field.cuh"
+#include "gate_jit.h"
+#include "gl_field.h"
 
 namespace {
 
@@ -305,6 +306,18 @@ GlError gl_circuit_create(const GlCircuitDesc *d, void **circuit, void *ctx) {
     if (d->num_gates) {
         if (!d->h_instrs || !d->h_gates) return bail(fail("null gate program"));
         c->num_gates = d->num_gates, c->num_selectors = d->num_selectors;
+        {
+            std::string verr;
+            uint32_t wires_needed = 0, constants_needed = 0;
+            if (!plonky2_hip::gate_programs_validate(reinterpret_cast<const uint16_t *>(d->h_instrs), d->num_instrs, reinterpret_cast<const uint32_t *>(d->h_gates),
+                                        d->num_gates, d->num_immediates, d->num_selectors, d->num_gate_constraints, &wires_needed,
+                                        &constants_needed, &verr))
+                return bail(fail("gate programs: " + verr));
+            if (wires_needed > c->num_wires || constants_needed > c->num_constants)
+                return bail(fail("gate programs load wire " + std::to_string(wires_needed ? wires_needed - 1 : 0) + " / constant column " +
+                                 std::to_string(constants_needed ? constants_needed - 1 : 0) + " but the circuit has " + std::to_string(c->num_wires) +
+                                 " wires and " + std::to_string(c->num_constants) + " constants"));
+        }
         if (d->compile_gates) {
             CTRY(gl_gate_kernel_build(d->h_instrs, d->num_instrs, d->h_gates, d->num_gates, d->h_immediates, d->num_immediates,
                                       d->num_selectors, d->num_gate_constraints, d->num_challenges, &c->gate_kernel));

@@ -35,13 +35,13 @@ class Context:
 
 
 class DeviceBuffer:
-    """n_elems u64 field elements in HBM (hipMalloc through gl_malloc)."""
+    """n_elems u64 field elements in HBM, on the device of `ctx` (hipMalloc through gl_ctx_malloc)."""
 
     def __init__(self, ctx, n_elems):
         self.ctx = ctx
         self.n = int(n_elems)
         p = ctypes.c_void_p()
-        _lib.call("gl_malloc", ctypes.byref(p), self.n * 8)
+        _lib.call("gl_ctx_malloc", ctypes.byref(p), self.n * 8, ctx.ptr)
         self.ptr = p.value
 
     @classmethod

@@ -36,7 +36,19 @@ class ProverGroup:
             self.device_index = self.local_rank if device_index is None else int(device_index)
             if self.backend == "nccl":
                 torch.cuda.set_device(self.device_index)
-            td.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
+            # gloo announces its connections on the C++ stdout; rank 0's stdout carries the one JSON line of bench.py, so
+            # the file descriptor (not just sys.stdout) points at stderr while the group is being formed
+            import sys
+
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                td.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
+                td.barrier()
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
             self.td, self.torch = td, torch
 
     def _dev(self):

@@ -40,6 +40,19 @@ def test_header_symbols_are_exported(lib):
         assert n in names
 
 
+def test_only_the_header_is_exported(lib):
+    """Built with -fvisibility=hidden: the dynamic symbol table holds the header's functions and nothing else of ours
+    (no C++ internals, no helper that happens to be non-static)."""
+    import subprocess
+
+    so = os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtWwBbDdVv"}
+    exported = {n for n in exported if not n.startswith(("__hip_", "_init", "_fini", "__bss", "_edata", "_end", "__odr", "__cxa"))}
+    extra = sorted(exported - set(declared_symbols()))
+    assert not extra, f"exported but not declared in include/plonky2_hip.h: {extra[:20]}"
+
+
 def test_version_and_error_strings(lib):
     assert lib.gl_version().startswith(b"plonky2_hip")
     assert b"invalid" in lib.cudaGetErrorString(-1)
@@ -50,7 +63,7 @@ def test_product_never_imports_oracle():
     """③: only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "plonky2_gpu_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 # ("oracles" is also FRI's own word for committed polynomial batches, fri/oracle.rs)
                 for needle in ("import oracle", "from oracle", "oracle/", "oracle.", "gl_oracle", "pyref", "_ref import", "fri_ref", "plonk_ref"):

@@ -1,4 +1,4 @@
-"""gl_field.cuh against Python big ints on the reference's edge operands
+"""gl_field.h against Python big ints on the reference's edge operands
 (field/src/prime_field_testing.rs:7-17, 79-125). Bit-exact after canonicalisation."""
 import itertools
 

@@ -41,6 +41,38 @@ def test_partial_products_and_zs(gpu, num_routed, degree_bits, qdf, num_ch):
     assert (got == cols(exp)).all()
 
 
+@pytest.mark.parametrize("qdf,expected_pps", [(2, [2, 24]), (3, [6])])
+def test_partial_products_reference_known_answer(gpu, qdf, expected_pps):
+    """plonky2/src/util/partial_products.rs:114-142 on the device: wires and sigmas chosen so that every row's
+    numerators are [1..6] and its denominators 1 (beta = 1, gamma = 0: w_j = v_j - k_j x, sigma_j = 1 - w_j). Row 0 must
+    hold the reference's partial products ([2, 24] for degree 2, [6] for degree 3) and Z(g x_0) = 720; every later row the
+    same values times 720^row."""
+    import plonky2_gpu_amd as pg
+
+    degree_bits, num_routed = 3, 6
+    n = 1 << degree_bits
+    w = pow(7, (P - 1) >> degree_bits, P)
+    subgroup = [pow(w, i, P) for i in range(n)]
+    k_is = [pow(7, j, P) for j in range(num_routed)]
+    v = [1, 2, 3, 4, 5, 6]
+    wires = [[(v[j] - k_is[j] * x) % P for x in subgroup] for j in range(num_routed)]
+    sigmas = [[(1 - wires[j][i]) % P for i in range(n)] for j in range(num_routed)]
+    exp = plonk_ref.zs_partial_products(wires, sigmas, k_is, [1], [0], qdf, subgroup)
+    d_w = pg.DeviceBuffer.from_host(gpu, cols(wires))
+    d_s = pg.DeviceBuffer.from_host(gpu, cols(sigmas))
+    d_k = pg.DeviceBuffer.from_host(gpu, cols(k_is))
+    out, n_cols = pg.all_wires_permutation_partial_products(gpu, d_w, n, d_s, n, d_k, [1], [0], num_routed, qdf, degree_bits)
+    got = out.download().reshape(n_cols, n)
+    assert n_cols == 1 + len(expected_pps)
+    z, pps = got[0], got[1:]
+    assert int(z[0]) == 1 and int(z[1]) == 720
+    assert [int(c[0]) for c in pps] == expected_pps
+    for i in range(n):
+        assert int(z[i]) == pow(720, i, P)
+        assert [int(c[i]) for c in pps] == [e * pow(720, i, P) % P for e in expected_pps]
+    assert (got == cols(exp)).all()
+
+
 def test_partial_products_argument_errors(gpu):
     import plonky2_gpu_amd as pg
 

@@ -126,3 +126,23 @@ def test_mini_circuit_with_gates_satisfies_the_verifier_identity(two_groups):
         red = plonk_ref.reduce_with_powers_multi(terms, inst["alphas"])
         for c in range(2):
             assert red[c] == zh * poly_eval(t[c], zeta) % P
+
+
+def test_reference_known_answer_for_partial_products():
+    """The reference's one known answer for this stage (plonky2/src/util/partial_products.rs:114-142, test_partial_products):
+    v = [1..6], denominators 1, Z(x) = 1, Z(gx) = 720."""
+    v, ones = [1, 2, 3, 4, 5, 6], [1] * 6
+    q2 = plonk_ref.quotient_chunk_products(v, 2)
+    assert q2 == [2, 12, 30]
+    pz2 = plonk_ref.partial_products_and_z_gx(1, q2)
+    assert pz2 == [2, 24, 720]
+    assert len(pz2) - 1 == plonk_ref.num_partial_products(len(v), 2) == 2
+    assert all(t == 0 for t in plonk_ref.check_partial_products(v, ones, pz2[:-1], 1, 720, 2))
+    q3 = plonk_ref.quotient_chunk_products(v, 3)
+    assert q3 == [6, 120]
+    pz3 = plonk_ref.partial_products_and_z_gx(1, q3)
+    assert pz3 == [6, 720]
+    assert len(pz3) - 1 == plonk_ref.num_partial_products(len(v), 3) == 1
+    assert all(t == 0 for t in plonk_ref.check_partial_products(v, ones, pz3[:-1], 1, 720, 3))
+    # and a wrong accumulator is caught
+    assert any(t != 0 for t in plonk_ref.check_partial_products(v, ones, [2, 25], 1, 720, 2))

@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "poseidon.cuh"
+#include "poseidon.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 

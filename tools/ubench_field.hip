@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "gl_field.cuh"
+#include "gl_field.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
