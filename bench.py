@@ -135,14 +135,46 @@ def dft_point(x, log_n, k):
     return int(terms[0])
 
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
+
+
+def pmc_summary():
+    return json.load(open(PMC_SUMMARY)) if os.path.exists(PMC_SUMMARY) else None
+
+
 def pmc_traffic(log_n, batch):
-    """HBM-side bytes per forward batch transform from the committed PMC summary (measured with
-    rocprofv3 in separate counter passes; bench.py cannot read counters while it runs)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if log_n != 20 or not os.path.exists(path):
+    """HBM-side bytes per forward batch transform from the committed counter summary (rocprofv3 FETCH_SIZE and WRITE_SIZE
+    in separate passes of this command, FETCH_SIZE x 2 on every kernel as the gfx950 note of MI355X_MICROARCH.md prescribes;
+    the copy kernel of the same passes — a known 512 MiB each way — calibrates it). bench.py cannot read counters while it runs."""
+    d = pmc_summary()
+    if log_n != 20 or not d:
         return None
-    d = json.load(open(path))
-    return d["forward_chunk_total_bytes"] * (batch / 16.0)  # the summary is per 16-column chunk
+    total = 0.0
+    for name, e in d["kernels"].items():
+        if name.startswith("ntt_pass_wave_kernel<10,") and name.endswith("grid=262144") and ",true,true," not in name:
+            total += e["derived"].get("read_bytes (FETCH_SIZE KiB x 1024 x 2)", 0) + e["derived"].get("write_bytes (WRITE_SIZE KiB x 1024)", 0)
+    return total * (batch / 16.0) if total else None  # the launches are per 16-column chunk
+
+
+def poseidon_issue_bound():
+    """What the counters say bounds the leaf hashing: the permutation kernel issues VALU instructions back to back
+    (SQ_INSTS_VALU x 4 cycles = the kernel's cycles x 1024 SIMDs), so permutations/s <= 64 lanes x 1024 SIMDs x clock /
+    (VALU instructions per wavefront-permutation x 4)."""
+    d = pmc_summary()
+    if not d:
+        return None
+    e = d["kernels"].get("permute_batch_kernel grid=4194304")
+    if not e:
+        return None
+    insts = e["derived"]["valu_insts_per_wave"]
+    cycles = e["derived"]["kernel_cycles"]
+    rate = json.load(open(os.path.join(ROOT, "profiles", "r02_poseidon_rate.json")))
+    clock = cycles / (rate["ms"] * 1e-3)
+    return {"valu_insts_per_wavefront_permutation": insts, "issue_cycles_per_valu_inst": 4,
+            "valu_issue_frac_of_kernel_cycles": e["derived"]["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"],
+            "clock_GHz_during_kernel": clock / 1e9, "bound_permutations_per_s": 64 * 1024 * clock / (insts * 4.0),
+            "standalone_permutations_per_s": rate["permutations_per_s"],
+            "source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVES, GRBM_GUI_ACTIVE on tools/bench_poseidon.py), profiles/r02_poseidon_rate.json"}
 
 
 def launch_ranks(n, argv=None, script=None, extra_env=None):
@@ -283,6 +315,10 @@ def main():
     extra = {}
     if not args.no_commit and dist.rank == 0:
         extra = bench_commit(pg, _lib, ctx, args.commit_cols, args.commit_log_n)
+        bound = poseidon_issue_bound()
+        if bound:
+            bound["commit_permutations_per_s_frac_of_bound"] = extra["poseidon_permutations_per_s"] / bound["bound_permutations_per_s"]
+            extra["poseidon_valu_issue_bound"] = bound
 
     if not args.no_prove:
         pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
@@ -322,13 +358,14 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summarised by "
-                                  "tools/pmc_summary.py into profiles/r01_pmc_traffic.json (gfx950 x2 correction on the "
-                                  "row pass's wide reads only); null when that file is absent",
-                "kernel": "forward batch NTT = ntt_pass_kernel<10,true> + ntt_pass_kernel<10,false>",
-                "binding_roof": "not HBM peak: two passes move 2x the algorithmic bytes (traffic), and with the field "
-                                "arithmetic replaced by xor/add the same launches still take 0.64 of 0.76 ms - the "
-                                "load / LDS-exchange / barrier / store skeleton of a pass runs at ~3.3 TB/s where a copy "
-                                "kernel reaches measured_copy_GBps; arithmetic is the remaining 15% (DESIGN.md 3.1)",
+                                  "tools/pmc_summary.py into profiles/r02_pmc_summary.json (gfx950 x2 correction on every "
+                                  "kernel's FETCH_SIZE, calibrated on the copy kernel of the same passes); null when absent",
+                "kernel": "forward batch NTT = ntt_pass_wave_kernel<10,true,..> (column pass) + ntt_pass_wave_kernel<10,false,..> (row pass)",
+                "binding_roof": "two passes move 2x the algorithmic bytes (traffic); the passes are latency-bound, not "
+                                "bandwidth- or ALU-bound: counters give VALU issue 51 % (column pass) / 62 % (row pass) of "
+                                "the kernel cycles and waves parked at s_waitcnt/barrier 47-54 % of their lifetime; the same "
+                                "instruction stream with its traffic served from L2 runs 30 % faster, with no global memory "
+                                "at all 35 % faster (profiles/r02_ntt_*_experiment.jsonl, DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
                 "measured_copy_GBps": copy_gbs,

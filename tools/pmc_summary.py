@@ -1,31 +1,34 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-commit --no-cpu`
-into profiles/<tag>_pmc_traffic.json (per-launch HBM-side bytes of the two NTT pass kernels).
+"""Summarise the rocprofv3 passes of tools/scratch/pmc.sh (one directory per counter set, each a run of
+`bench.py --no-prove --no-cpu` or of tools/bench_poseidon.py) into profiles/<tag>_pmc_summary.json.
 
-Usage: python tools/pmc_summary.py <fetch_dir> <write_dir> <tag>
-Corrections (MI355X_MICROARCH.md §HBM): counters are in KiB; on gfx950 FETCH_SIZE tallies the
-128-B requests of a wide coalesced 16 B/lane stream at 64 B, i.e. reads exactly half — that
-applies to the row pass (whole contiguous rows), not to the column pass whose 64-B segments are
-single 64-B requests (calibrated: the column pass reads 128 MiB per launch and the counter says
-130 MiB including twiddle tables). WRITE_SIZE is exact for 16 B/lane stores.
-"""
+Usage: python tools/pmc_summary.py <gpurun_out/r02pmc> <tag>
+
+Per kernel and grid size: the median of every counter over the launches, the average duration from the un-instrumented
+--kernel-trace --stats pass, and derived figures. Unit notes (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* /
+SQ_ACTIVE_INST_* count quad-cycles; FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of
+a 16 B/lane streaming read at 64 bytes, i.e. reports half the bytes — the x2 correction is applied to EVERY kernel here
+(all global reads of these kernels are 16 B/lane), and the copy kernel of the same run (a known byte count) is listed as
+the calibration."""
 import collections
 import csv
 import glob
 import json
+import os
 import sys
 
+SIMDS = 1024  # 256 CUs x 4
 
-def collect(d, counter):
-    agg = collections.defaultdict(list)
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            name = r["Kernel_Name"]
-            key = "pass_A<10,true>" if "<10, true>" in name else "pass_B<10,false>" if "<10, false>" in name else name[:60]
-            agg[(key, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    return agg
+
+def short(name):
+    for key in ("ntt_pass_wave_kernel", "ntt_pass_kernel", "hash_leaves_kernel", "tree_layer_coop_kernel", "tree_layer_kernel",
+                "transpose_kernel", "permute_batch_kernel", "copy16_kernel", "coset_tables_kernel"):
+        if key in name:
+            if "ntt_pass" in name:
+                args = name[name.index("<") + 1:name.index(">")].replace(" ", "")
+                return f"{key}<{args}>"
+            return key
+    return name[:48]
 
 
 def med(v):
@@ -34,28 +37,54 @@ def med(v):
 
 
 def main():
-    fetch_dir, write_dir, tag = sys.argv[1:4]
-    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    out = {"unit": "bytes per launch (16-column chunk of 2^20-point columns = 128 MiB of field elements)", "kernels": {}}
-    total = 0.0
-    for key in sorted(fe):
-        k, grid = key
-        f_kib, w_kib = med(fe[key]), min(wr.get(key, [0.0]))  # min = forward launches (aligned stores)
-        corr = 2.0 if "pass_B" in k else 1.0
-        rd, wrb = f_kib * 1024 * corr, w_kib * 1024
-        out["kernels"][f"{k} grid={grid}"] = {
-            "FETCH_SIZE_KiB_median": f_kib, "fetch_correction": corr, "read_bytes": rd,
-            "WRITE_SIZE_KiB_forward": w_kib, "WRITE_SIZE_KiB_median_all": med(wr.get(key, [0.0])), "write_bytes": wrb,
-            "launches": len(fe[key]),
-        }
-        if grid == 1048576:
-            total += rd + wrb
-    out["forward_chunk_total_bytes"] = total
-    out["algorithmic_bytes_per_chunk"] = 16.0 * (1 << 20) * 16
-    out["traffic_over_algorithmic"] = total / out["algorithmic_bytes_per_chunk"]
-    path = f"profiles/{tag}_pmc_traffic.json"
+    root, tag = sys.argv[1], sys.argv[2]
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            key = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+            counters[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, "stats_*", "*", "*kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {"units": "counter medians per launch; durations in microseconds from the un-instrumented kernel trace", "kernels": {}}
+    for key in sorted(counters):
+        name, grid = key
+        c = {k: med(v) for k, v in counters[key].items()}
+        e = {"grid_threads": grid, "launches_in_counter_passes": max(len(v) for v in counters[key].values()), "counters": c}
+        if dur.get(key):
+            e["avg_us"] = sum(dur[key]) / len(dur[key]) / 1e3
+            e["timed_launches"] = len(dur[key])
+        d = {}
+        if c.get("SQ_WAVES"):
+            d["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"]
+        if c.get("SQ_WAVE_CYCLES"):
+            d["wave_parked_frac (s_waitcnt / barrier)"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
+            d["wave_issue_stall_frac"] = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+            d["wave_active_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU"):
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            d["kernel_cycles"] = cyc
+            d["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"] = c["SQ_INSTS_VALU"] * 4.0 / (SIMDS * cyc)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
+        if "FETCH_SIZE" in c:
+            d["read_bytes (FETCH_SIZE KiB x 1024 x 2)"] = c["FETCH_SIZE"] * 1024 * 2
+            d["read_bytes_uncorrected"] = c["FETCH_SIZE"] * 1024
+        if "WRITE_SIZE" in c:
+            d["write_bytes (WRITE_SIZE KiB x 1024)"] = c["WRITE_SIZE"] * 1024
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+            d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        e["derived"] = d
+        out["kernels"][f"{name} grid={grid}"] = e
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_pmc_summary.json")
     json.dump(out, open(path, "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    # brief table
+    for k, e in out["kernels"].items():
+        d = e["derived"]
+        print(f"{k[:64]:64s} us={e.get('avg_us', 0):9.1f} valu/wave={d.get('valu_insts_per_wave', 0):8.0f} "
+              f"parked={d.get('wave_parked_frac (s_waitcnt / barrier)', 0):.2f} valu>={d.get('valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)', 0):.2f} "
+              f"ldsconf={d.get('lds_bank_conflict_frac', 0):.2f} rd={d.get('read_bytes (FETCH_SIZE KiB x 1024 x 2)', 0) / 2**20:8.1f}MiB wr={d.get('write_bytes (WRITE_SIZE KiB x 1024)', 0) / 2**20:8.1f}MiB")
 
 
 if __name__ == "__main__":
