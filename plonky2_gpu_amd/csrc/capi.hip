@@ -281,10 +281,30 @@ __device__ gl::DotAcc dotacc_from(int mode, uint64_t x, uint64_t y) {
     return d;
 }
 
-// 16 B per lane, grid-stride: what a streaming kernel can move on this device (the measured roof next to the 8 TB/s spec)
-__global__ __launch_bounds__(256) void copy16_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = in[i];
+// What a streaming kernel can move on this device (the measured roof next to the 8 TB/s specification): 16 B per lane,
+// eight independent pieces per thread in flight, non-temporal loads and stores (the bytes are touched once: default-policy
+// accesses reach 4.9-5.6 TB/s in the same shape, non-temporal ones 6.2 TB/s = the guide's 6.3 figure;
+// tools/ubench_mem.hip, profiles/r02_ubench_mem.txt).
+constexpr int COPY_UNROLL = 8;
+__global__ __launch_bounds__(256) void copy16_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n16) {
+    const uint64_t base = (uint64_t)blockIdx.x * (256 * COPY_UNROLL) + threadIdx.x;
+    uint64_t v[COPY_UNROLL][2];
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; u++) {
+        const uint64_t i = base + (uint64_t)u * 256;
+        if (i < n16) {
+            v[u][0] = __builtin_nontemporal_load(in + 2 * i);
+            v[u][1] = __builtin_nontemporal_load(in + 2 * i + 1);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; u++) {
+        const uint64_t i = base + (uint64_t)u * 256;
+        if (i < n16) {
+            __builtin_nontemporal_store(v[u][0], out + 2 * i);
+            __builtin_nontemporal_store(v[u][1], out + 2 * i + 1);
+        }
+    }
 }
 
 __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
@@ -820,12 +840,9 @@ GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx)
     if (!ctx || !d_dst || !d_src) return fail(GL_E_INVALID, "null pointer");
     if ((bytes & 15) || (((uintptr_t)d_dst | (uintptr_t)d_src) & 15)) return fail(GL_E_INVALID, "16-byte granularity");
     if (bytes == 0) return ok();
-    hipDeviceProp_t prop;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipGetDeviceProperties(&prop, dev));
-    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)prop.multiProcessorCount * 8), dim3(256), 0, S(ctx)->stream,
-                       static_cast<const uint4 *>(d_src), static_cast<uint4 *>(d_dst), bytes / 16);
+    const uint64_t n16 = bytes / 16, per_block = 256ull * COPY_UNROLL;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + per_block - 1) / per_block)), dim3(256), 0, S(ctx)->stream,
+                       static_cast<const uint64_t *>(d_src), static_cast<uint64_t *>(d_dst), n16);
     HIP_TRY(hipGetLastError());
     return ok();
 }

@@ -85,6 +85,38 @@ def test_native_prover_gl_prove(gpu, which, compile_gates):
     assert timing["wires commitment"] > 0
 
 
+@pytest.mark.parametrize("which,degree_bits,arity_bits,cap_height,compile_gates", [
+    ("mini", 10, (4, 4), 4, True), ("mini2", 11, (3, 2, 1), 3, False), ("mini", 12, (4, 4, 4), 2, True), ("full", 10, (4, 4), 4, True)])
+def test_proof_bytes_equal_the_oracle_at_2e10_to_2e12_rows(gpu, which, degree_bits, arity_bits, cap_height, compile_gates):
+    """Byte equality with the CPU restatement of prove() (plonk/prover.rs:41-237) beyond toy sizes: 2^10..2^12 rows, FRI
+    arities [4,4] / [3,2,1] / [4,4,4], 28 query rounds, two-pass NTT sizes on the device (LDE 2^13..2^15), the 13-gate
+    circuit with every gate kind of the ed25519 list at 2^10 rows. The oracle's Poseidon / Merkle / NTT come from the C
+    restatement (oracle/accel.py; same proofs as the pure model, tests/test_oracle_prove.py::test_c_backend_gives_the_same_proof).
+    Both provers: the native gl_prove and the Python mirror."""
+    import plonky2_gpu_amd as pg
+    from oracle import accel, serialize_ref
+    from plonk_instance import make_full_circuit
+
+    with accel.c_backend():
+        if which == "full":
+            circuit, wires, pis = make_full_circuit(degree_bits, seed=5, arity_bits=arity_bits, cap_height=cap_height, num_queries=28)
+        else:
+            circuit, wires, pis = make_circuit(degree_bits, seed=40 + degree_bits, two_groups=which == "mini2", arity_bits=arity_bits,
+                                               cap_height=cap_height, num_queries=28, pow_bits=8)
+        exp = prove_ref.prove(circuit, wires, pis)
+        assert prove_ref.verify(circuit, exp)
+    exp_bytes = serialize_ref.proof_bytes(exp)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+    assert nc.circuit_digest == circuit["circuit_digest"]
+    data = nc.prove_bytes(wires, pis)
+    assert len(data) == len(exp_bytes)
+    assert data == exp_bytes
+    nc.close()
+    if which != "full":
+        proof = pg.prove(gpu, pg.CircuitData(gpu, circuit), wires, pis)
+        assert pg.serialization.proof_to_bytes(proof) == exp_bytes
+
+
 @pytest.mark.parametrize("qdf,two_groups", [(5, False), (6, False), (4, True)])
 def test_quotient_degree_factor_that_is_not_a_power_of_two(gpu, qdf, two_groups):
     """The trimmed-and-copied chunk path (prover.rs:153-166) of both provers — the Python mirror and the
@@ -245,6 +277,64 @@ def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu, degree_bits, pr
     assert len(data) == proof_bytes
     vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
     assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
+    nc.close()
+
+
+@pytest.mark.parametrize("compile_gates", [True, False])
+def test_all_25_ed25519_gates_with_honest_rows_proof_bytes(gpu, compile_gates):
+    """configs[3]'s gate table doing real work: the 25 gates of the ed25519 circuit with their real parameters, every kind
+    instantiated by honestly generated rows (tests/ed25519_rows.py), 234 wires, copy constraints — 2^8 rows so that the
+    CPU restatement of prove() can be run beside it: gl_prove's bytes equal the oracle's, compiled and interpreted gates."""
+    import plonky2_gpu_amd as pg
+    from oracle import accel, serialize_ref
+    import ed25519_rows as er
+
+    fp = dict(rate_bits=3, cap_height=2, reduction_arity_bits=[3, 2], proof_of_work_bits=4, num_query_rounds=6)
+    with accel.c_backend():
+        circuit, wires, pis = er.make_all_gates_circuit(8, seed=4, templates=3, fri_params=fp)
+        oc, ow = er.as_oracle_circuit(circuit, wires, prove_ref)
+        exp = prove_ref.prove(oc, ow, pis)
+        assert prove_ref.verify(oc, exp)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+    assert nc.circuit_digest == oc["circuit_digest"]
+    assert nc.prove_bytes(wires, pis) == serialize_ref.proof_bytes(exp)
+    nc.close()
+
+
+def test_full_size_proof_with_all_25_gate_kinds_in_use_is_accepted_by_the_oracle_verifier(gpu):
+    """BASELINE.json configs[3] at its full shape (2^18 rows, 234 wires / 80 routed, 88 preprocessed polynomials, rate 8,
+    cap height 4, arities [4,4,4,4], 28 queries, 16 PoW bits) with EVERY one of the 25 gate kinds constraining rows
+    (10 485 rows each, honestly generated, tied by copy constraints): proven by gl_prove, accepted by the oracle's
+    verifier, which re-derives every challenge and evaluates all 25 gates' constraints at zeta over F_p^2 on its own."""
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd.challenger import hash_no_pad
+    from oracle import accel
+    import ed25519_rows as er
+
+    with accel.c_backend():
+        circuit, wires, pis = er.make_all_gates_circuit(18, seed=1, templates=4, pih_of=lambda x: hash_no_pad(gpu, x))
+    assert circuit["fri_params"]["reduction_arity_bits"] == [4, 4, 4, 4]
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))
+    data = nc.prove_bytes(d_wires, pis)
+    assert len(data) == 204544
+    vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
+    with accel.c_backend():
+        assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
+    # the same circuit with one limb of one U32RangeCheckGate{8} row off by one: the quotient stops being a polynomial
+    bad = wires.copy()
+    row = next(r for r in range(1 << 18) if (r + 2) % 25 == 21)
+    bad[10, row] = (int(bad[10, row]) + 1) % prove_ref.P
+    from plonky2_gpu_amd._lib import Plonky2HipError
+    try:
+        data_bad = nc.prove_bytes(pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(bad)), pis)
+    except Plonky2HipError:
+        data_bad = None  # "Quotient has failed" is also a legitimate way to notice
+    if data_bad is not None:
+        with accel.c_backend(), pytest.raises((AssertionError, ValueError)):
+            prove_ref.verify(vc, pg.serialization.proof_from_bytes(data_bad, circuit))
     nc.close()
 
 

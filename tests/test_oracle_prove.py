@@ -136,3 +136,50 @@ def test_other_numbers_of_challenges(num_challenges):
     assert len(proof["openings"]["plonk_zs"]) == num_challenges
     assert len(proof["openings"]["quotient_polys"]) == 8 * num_challenges
     assert prove_ref.verify(circuit, proof)
+
+
+@pytest.mark.parametrize("which", ["mini", "mini2", "full"])
+def test_c_backend_gives_the_same_proof(which):
+    """oracle/accel.py serves Poseidon / Merkle / NTT from the pinned C restatement so that prove_ref reaches 2^10..2^12
+    rows in the GPU parity tests. Same circuits, with and without it: the circuit digest, the proof and the verifier's
+    verdict must not change."""
+    from oracle import accel
+    from plonk_instance import make_full_circuit
+
+    def build():
+        if which == "full":
+            return make_full_circuit(4, seed=7)
+        return make_circuit(5 if which == "mini" else 4, seed=31, two_groups=which == "mini2", arity_bits=(2, 1))
+
+    circuit, wires, pis = build()
+    pure = prove_ref.prove(circuit, wires, pis)
+    with accel.c_backend():
+        c2, w2, p2 = build()
+        fast = prove_ref.prove(circuit, wires, pis)
+        assert prove_ref.verify(circuit, fast)
+    assert c2["circuit_digest"] == circuit["circuit_digest"] and c2["constants_sigmas"]["digests"] == circuit["constants_sigmas"]["digests"]
+    assert w2 == wires and p2 == pis
+    assert fast == pure
+    from oracle import pyref
+    assert pyref.poseidon.__module__ == "oracle.pyref"  # the backend is gone when the block ends
+
+
+def test_all_25_ed25519_gates_with_honest_rows_prove_then_verify():
+    """tests/ed25519_rows.py: the ed25519 gate table with its real parameters, every gate kind instantiated by the witness
+    generators of oracle/gates_ref.py, copy constraints between equal cells. The oracle proves it and its verifier
+    accepts; a single corrupted limb of a U32 gate row is caught."""
+    from oracle import accel
+    import ed25519_rows as er
+
+    fp = dict(rate_bits=3, cap_height=1, reduction_arity_bits=[2, 1], proof_of_work_bits=2, num_query_rounds=2)
+    with accel.c_backend():
+        circuit, wires, pis = er.make_all_gates_circuit(6, seed=3, templates=2, fri_params=fp)
+        oc, ow = er.as_oracle_circuit(circuit, wires, prove_ref)
+        proof = prove_ref.prove(oc, ow, pis)
+        assert prove_ref.verify(oc, proof)
+        assert sorted(set((r + 2) % 25 for r in range(64))) == list(range(25))  # every gate kind has rows
+        bad = [list(c) for c in ow]
+        row = next(r for r in range(64) if (r + 2) % 25 == 18)  # a U32ArithmeticGate{6} row
+        bad[40][row] = (bad[40][row] + 1) % prove_ref.P
+        with pytest.raises(AssertionError):
+            prove_ref.verify(oc, prove_ref.prove(oc, bad, pis))
