@@ -83,8 +83,9 @@ def fri_openings(openings):
             + openings["quotient_polys"], openings["plonk_zs_next"]]
 
 
-def prove(circuit, wires, public_inputs):
-    """plonk/prover.rs:40-233 from the full witness (wire columns) on."""
+def prove(circuit, wires, public_inputs, trace=None):
+    """plonk/prover.rs:40-233 from the full witness (wire columns) on. `trace` (a dict) receives the intermediate objects
+    the reference can dump (prover.rs:829-877): commitments, Z / partial-product values, challenges, quotient polynomials."""
     fp = circuit["fri_params"]
     rate_bits, cap_height = fp["rate_bits"], fp["cap_height"]
     db, n = circuit["degree_bits"], 1 << circuit["degree_bits"]
@@ -131,6 +132,9 @@ def prove(circuit, wires, public_inputs):
     for batch in fri_openings(openings):
         ch.observe_extension_elements(batch)
     opening_proof = fri_ref.prove_openings(fri_instance(circuit, zeta), [cs, wires_c, zs_c, quot_c], ch, fp)
+    if trace is not None:
+        trace.update(wires_commitment=wires_c, zs_partial_products=zs_pp, zs_partial_products_commitment=zs_c, betas=betas, gammas=gammas,
+                     alphas=alphas, quotient_polys=quotient_polys, public_inputs_hash=pih)
     return dict(wires_cap=wires_c["cap"], plonk_zs_partial_products_cap=zs_c["cap"], quotient_polys_cap=quot_c["cap"],
                 openings=openings, opening_proof=opening_proof, public_inputs=list(public_inputs))
 
