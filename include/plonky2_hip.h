@@ -291,6 +291,13 @@ GlError gl_merkle_tree_from_leaves(const uint64_t *d_rows, uint32_t leaf_len, ui
 GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
                      void *ctx);
 
+/* The pack step of a commitment whose columns are sharded over `world` GPUs (one process per GPU; plonky2_gpu_amd/dist.py):
+ * d_out[(q*n_cols + c)*leaves_per_rank + i] = d_lde[c*col_stride + q*leaves_per_rank + i] — for every rank q, the leaf
+ * range it will hash of every one of this rank's n_cols LDE columns, contiguous per destination rank, in ONE launch
+ * (d_out: world * n_cols * leaves_per_rank elements). The slices go out as they are with one send per peer. */
+GlError gl_pack_leaf_ranges(const uint64_t *d_lde, uint64_t col_stride, uint32_t n_cols, uint64_t leaves_per_rank, uint32_t world,
+                            uint64_t *d_out, void *ctx);
+
 /* PolynomialBatch::from_coeffs (plonky2/src/fri/oracle.rs:911-977) without the host-side struct:
  *   d_coeffs   [poly_num][2^log_n]            in
  *   d_lde      [(poly_num+salt_size)][n_ext]  out, column-major, bit-reversed (n_ext = 2^(log_n+rate_bits));

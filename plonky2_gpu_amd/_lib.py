@@ -116,6 +116,7 @@ SIGNATURES = {
     "gl_ctx_create": (_vp, [_i]),
     "gl_ctx_destroy": (None, [_vp]),
     "gl_ctx_synchronize": (GlError, [_vp]),
+    "gl_pack_leaf_ranges": (GlError, [_vp, _u64, _u32, _u64, _u32, _vp, _vp]),
     "gl_malloc": (GlError, [ctypes.POINTER(_vp), _u64]),
     "gl_ctx_malloc": (GlError, [ctypes.POINTER(_vp), _u64, _vp]),
     "gl_free": (GlError, [_vp]),

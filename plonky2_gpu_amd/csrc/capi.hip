@@ -335,6 +335,19 @@ __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, ui
     out[i] = (op >= 8 && op <= 12) ? r : gl::canon(r);  // canonical-domain ops must already be canonical
 }
 
+// out[(q * n_cols + c) * L + i] = lde[c * col_stride + q * L + i]: every column's leaf range of every rank, grouped by
+// rank — what a column-sharded commit sends (dist.py); 16 B per lane, L is a multiple of 2.
+__global__ __launch_bounds__(256) void pack_leaf_ranges_kernel(const uint64_t *__restrict__ lde, uint64_t col_stride, uint32_t n_cols,
+                                                               uint64_t L, uint32_t world, uint64_t *__restrict__ out) {
+    const uint64_t pairs = L / 2, total = (uint64_t)world * n_cols * pairs;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = (g % pairs) * 2, rest = g / pairs;
+        const uint32_t c = (uint32_t)(rest % n_cols), q = (uint32_t)(rest / n_cols);
+        const uint4 v = *reinterpret_cast<const uint4 *>(lde + (uint64_t)c * col_stride + (uint64_t)q * L + i);
+        *reinterpret_cast<uint4 *>(out + ((uint64_t)q * n_cols + c) * L + i) = v;
+    }
+}
+
 GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
                                 uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                                 uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, Streams *s,
@@ -813,6 +826,21 @@ GlError gl_transpose(const uint64_t *d_cols, uint64_t *d_rows, uint32_t n_cols, 
     DeviceCall device_call(ctx);
     if (!ctx || !d_cols || !d_rows) return fail(GL_E_INVALID, "null pointer");
     HIP_TRY(transpose_to_leaf_major(d_cols, d_rows, n_cols, n_rows, col_stride, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_pack_leaf_ranges(const uint64_t *d_lde, uint64_t col_stride, uint32_t n_cols, uint64_t leaves_per_rank, uint32_t world,
+                            uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx || !d_lde || !d_out) return fail(GL_E_INVALID, "null pointer");
+    if (world == 0 || n_cols == 0 || leaves_per_rank == 0) return ok();
+    if ((leaves_per_rank & 1) || (col_stride & 1) || (((uintptr_t)d_lde | (uintptr_t)d_out) & 15))
+        return fail(GL_E_INVALID, "leaf ranges and strides must be even, buffers 16-byte aligned");
+    if (col_stride < (uint64_t)world * leaves_per_rank) return fail(GL_E_INVALID, "col_stride smaller than world * leaves_per_rank");
+    const uint64_t total = (uint64_t)world * n_cols * (leaves_per_rank / 2);
+    const unsigned grid = (unsigned)(total / 256 + 1 > 16384 ? 16384 : total / 256 + 1);
+    hipLaunchKernelGGL(pack_leaf_ranges_kernel, dim3(grid), dim3(256), 0, S(ctx)->stream, d_lde, col_stride, n_cols, leaves_per_rank, world, d_out);
+    HIP_TRY(hipGetLastError());
     return ok();
 }
 

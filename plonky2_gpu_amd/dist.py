@@ -44,7 +44,10 @@ class ProverGroup:
             saved = os.dup(1)
             try:
                 os.dup2(2, 1)
-                td.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)
+                kw = {}
+                if self.backend == "nccl":  # bind the communicator to this rank's GPU instead of letting torch guess it from the rank
+                    kw["device_id"] = torch.device("cuda", self.device_index)
+                td.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world, **kw)
                 td.barrier()
             finally:
                 os.dup2(saved, 1)
@@ -88,6 +91,18 @@ class ProverGroup:
             self.td = None
 
 
+class _DevicePointer:
+    """A raw device pointer as an object torch.as_tensor understands (CUDA array interface v2): lets torch.distributed
+    send from and receive into the library's own buffers without a copy."""
+
+    def __init__(self, ptr, n_elems):
+        self.__cuda_array_interface__ = {"shape": (int(n_elems),), "typestr": "<i8", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def device_tensor(torch, ptr, n_elems, device_index):
+    return torch.as_tensor(_DevicePointer(ptr, n_elems), device=torch.device("cuda", device_index))
+
+
 class ShardedCommit:
     """One rank's part of a commitment whose columns are spread over the ranks (second row):
     `d_coeffs` / `d_lde` hold this rank's columns [my_cols][n] / [my_cols][n_ext]; `d_leaves` is the column-major
@@ -124,44 +139,41 @@ def sharded_commit_from_values(group, ctx, d_values, col_lo, col_hi, total_cols,
     d_lde = DeviceBuffer(ctx, mine * n_ext)
     _lib.call("gl_coset_lde_batch", d_values.ptr, d_lde.ptr, mine, log_n, rate_bits, 7, n, n_ext, ctx.ptr)
     d_leaves = DeviceBuffer(ctx, total_cols * L)
+    # ONE launch groups, for every rank, the leaf range it hashes of every one of my columns (gl_pack_leaf_ranges); the
+    # slice for rank q is then contiguous: [mine][L] at packed + q * mine * L.
+    d_packed = DeviceBuffer(ctx, W * mine * L)
+    _lib.call("gl_pack_leaf_ranges", d_lde.ptr, n_ext, mine, L, W, d_packed.ptr, ctx.ptr)
     # my own columns of my own leaf range stay on the device
-    for c in range(mine):
-        _lib.call("gl_memcpy_d2d", d_leaves.at((col_lo + c) * L), d_lde.at(c * n_ext + r * L), 8 * L, ctx.ptr)
+    _lib.call("gl_memcpy_d2d", d_leaves.at(col_lo * L), d_packed.at(r * mine * L), 8 * mine * L, ctx.ptr)
     if W > 1:
         td, torch = group.td, group.torch
         on_device = group.backend == "nccl"
-        dev = group._dev()
-        send, recv, ops = {}, {}, []
+        ops, keep = [], []
+        ctx.synchronize()
         for q in range(W):
             if q == r:
                 continue
-            send[q] = torch.empty(mine * L, dtype=torch.int64, device=dev)
-            recv[q] = torch.empty((bounds[q][1] - bounds[q][0]) * L, dtype=torch.int64, device=dev)
-            for c in range(mine):  # [mine][L]: the slice of every one of my columns that rank q hashes
-                src = d_lde.at(c * n_ext + q * L)
-                if on_device:
-                    _lib.call("gl_memcpy_d2d", send[q].data_ptr() + 8 * c * L, src, 8 * L, ctx.ptr)
-                else:
-                    _lib.call("gl_memcpy_d2h", send[q].data_ptr() + 8 * c * L, src, 8 * L, ctx.ptr)
-        ctx.synchronize()
-        for q in range(W):
-            if q != r:
-                ops.append(td.P2POp(td.isend, send[q], q))
-                ops.append(td.P2POp(td.irecv, recv[q], q))
+            cnt_q = (bounds[q][1] - bounds[q][0]) * L
+            if on_device:
+                # zero copy: RCCL sends from the packed buffer and receives straight into the leaf block of rank q's columns
+                send = device_tensor(torch, d_packed.at(q * mine * L), mine * L, group.device_index)
+                recv = device_tensor(torch, d_leaves.at(bounds[q][0] * L), cnt_q, group.device_index)
+            else:  # gloo: staged through host memory, one copy per peer
+                send = torch.empty(mine * L, dtype=torch.int64)
+                recv = torch.empty(cnt_q, dtype=torch.int64)
+                _lib.call("gl_memcpy_d2h", send.data_ptr(), d_packed.at(q * mine * L), 8 * mine * L, ctx.ptr)
+            keep.append((q, send, recv, cnt_q))
+            ops.append(td.P2POp(td.isend, send, q))
+            ops.append(td.P2POp(td.irecv, recv, q))
         for req in td.batch_isend_irecv(ops):
             req.wait()
         if on_device:
             torch.cuda.synchronize()
-        for q in range(W):
-            if q == r:
-                continue
-            cnt = (bounds[q][1] - bounds[q][0]) * L
-            dst = d_leaves.at(bounds[q][0] * L)
-            if on_device:
-                _lib.call("gl_memcpy_d2d", dst, recv[q].data_ptr(), 8 * cnt, ctx.ptr)
-            else:
-                _lib.call("gl_memcpy_h2d", dst, recv[q].data_ptr(), 8 * cnt, ctx.ptr)
+        else:
+            for q, _, recv, cnt_q in keep:
+                _lib.call("gl_memcpy_h2d", d_leaves.at(bounds[q][0] * L), recv.data_ptr(), 8 * cnt_q, ctx.ptr)
         ctx.synchronize()
+    d_packed.free()
     local_cap_height = cap_height - (W.bit_length() - 1)
     n_dig = 2 * (L - (1 << local_cap_height))
     d_digests = DeviceBuffer(ctx, 4 * max(n_dig, 1))

@@ -34,3 +34,14 @@ def test_sharded_commit_argument_errors(gpu):
         sharded_commit_from_values(g, gpu, d, 1, 5, 5, 4, 3, 2)  # not the slice shard_range assigns
     sc = sharded_commit_from_values(g, gpu, d, 0, 4, 4, 4, 3, 2)  # world 1: the plain commit
     assert sc.leaf_lo == 0 and sc.leaves_per_rank == 128 and sc.cap.shape == (4, 4)
+
+
+def test_rccl_route_with_one_rank(gpu):
+    """backend "nccl" (= RCCL) on the one GPU there is: process group, collectives on device tensors, zero-copy tensors over
+    the library's buffers, the sharded commit under that group (tests/dist_nccl_self.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_nccl_self.py")], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "nccl single-rank ok" in p.stdout
