@@ -26,6 +26,7 @@
 //    (fft.rs:92-101) folded into the last pass's store addresses.
 #include "ntt.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -63,6 +64,7 @@ struct PassParams {
     uint32_t tw_hi;      // inter-pass twiddle root = w_{2^tw_hi}
     uint32_t cs_hi_len;  // entries per coset in cs_hi
     uint32_t rate_bits;  // F_COSET: blockIdx.z = coset r, written to block bitrev(r)
+    uint64_t *stamps;    // diagnostic builds only (-DPLONKY2_NTT_STAMPS): per-phase cycle totals, see tools/ntt_stamps.py
     uint32_t row_shift;  // inverse natural-order row pass: rotate the row tile by one so that the
                          // flipped 64-byte output segments are aligned (t_limit is a power of two)
 };
@@ -423,6 +425,20 @@ constexpr int WIDE_MIN_LOGR = 7;           // wide (16-wave) tiles are instantia
 constexpr int WBUF = EW + EW / 16 + 2;    // padded wave buffer; the skew of 2 words spreads the eight buffers over
                                           // the banks for the cooperative (cross-buffer) accesses
 
+#ifdef PLONKY2_NTT_STAMPS
+// In-kernel stamps (diagnostic build, never the product): every wave adds the shader-clock cycles it spent in each phase of
+// its tile loop; lane 0 adds the totals to p.stamps[phase] at the end. Stamping costs a wait for outstanding LDS / scalar
+// memory operations per stamp, so the phases are slightly serialised compared with the product kernel.
+#define STAMP(k)                                          \
+    do {                                                  \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[k] += now_ - stamp_last;                \
+        stamp_last = now_;                                \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // Workgroup barrier that waits for this wave's LDS traffic only. __syncthreads() also drains vmcnt (hipcc puts
 // s_waitcnt vmcnt(0) in front of it), which would stall on the NEXT tile's global loads that are meant to stay in
 // flight across the whole transform of the current one.
@@ -432,7 +448,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // workgroup per CU): the wide tile doubles the segments of the cooperative accesses to 128 bytes — whole cache lines —
 // which the memory system moves ~25 % faster than 64-byte halves (tools/ubench_mem.hip, profiles/r02_ubench_mem.txt).
 template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW>
-__global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pass_wave_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t total) {
+__global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pass_wave_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t total, const uint32_t xcd_map) {
     static_assert(LOGR <= LOGEW, "a wave tile holds whole R-point columns");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int R = 1 << LOGR;
@@ -542,8 +558,23 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
     // next tile's radix rounds to drain.
     u64x2 pre[8];
     uint64_t chain[2] = {1, 1};
-    uint32_t id = blockIdx.x;
+    // Which tiles a workgroup walks. Workgroups are dealt to the eight XCDs round-robin (workgroup w runs on XCD w mod 8) and
+    // every XCD has its own L2, so with xcd_map the workgroups of ONE XCD take CONSECUTIVE tiles at every step: the k-th
+    // tile of workgroup w is ((k*8 + w%8) * (G/8)) + w/8. Consecutive tiles of a column are the adjacent 64/128-byte
+    // pieces of the same rows, so an XCD's L2 and the DRAM pages behind it see whole runs of a row at about the same time
+    // instead of one piece in eight. Without it: w, w+G, w+2G, ...
     const uint32_t G = gridDim.x;
+    const uint32_t per_xcd = G >> 3;
+    auto tile_at = [&](uint32_t k) -> uint32_t {
+        const uint64_t t = xcd_map ? ((uint64_t)k * 8 + (blockIdx.x & 7)) * per_xcd + (blockIdx.x >> 3) : (uint64_t)k * G + blockIdx.x;
+        return t < total ? (uint32_t)t : 0xFFFFFFFFu;
+    };
+    uint32_t step = 0;
+    uint32_t id = tile_at(0);
+#ifdef PLONKY2_NTT_STAMPS
+    uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     auto chain_of = [&](uint32_t tile) {
         if constexpr (TWIDDLE) {
             uint32_t b, a, z;
@@ -558,11 +589,12 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
     if (id < total) {
         land(id, pre);
         chain_of(id);
-        if (id + G < total) issue_loads(id + G, pre);
+        if (tile_at(1) < total) issue_loads(tile_at(1), pre);
     }
+    STAMP(0);  // prologue: twiddle table, first tile's loads and landing
 
-    for (; id < total; id += G) {
-        const uint32_t nid = id + G;
+    for (; id < total; id = tile_at(++step)) {
+        const uint32_t nid = tile_at(step + 1);
         uint32_t b, a, z;
         decode(id, b, a, z);
         // Per-thread slot and address arithmetic is the same for every tile; left to itself the compiler hoists all of it
@@ -573,6 +605,7 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
 
         // ---- R-point DIFs of this wave's TW columns, no workgroup barrier ------------------------
         tile_transform<LOGEW, WT, LOGR, TWIDDLE>(data, tw, p, lane_i, b * WAVES + wave, z, TWIDDLE ? chain : nullptr);
+        STAMP(1);  // radix rounds
 
         // ---- results: LDS -> registers ----------------------------------------------------------------
         u64x2 res[8];
@@ -599,16 +632,20 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 res[it].y = data[phys(((m + 1) << logtw) + tl, logtw)];
             }
         }
+        STAMP(2);  // barrier (all waves done) + results LDS -> registers
         // the next tile's arrival overwrites buffers that a cooperative load / store lets other waves touch
         if constexpr (!(rows_in && rows_out))
             lds_barrier();
         else
             tile_sync<WT>();
+        STAMP(3);  // barrier (all results read)
 
         // ---- tile k+1 lands ---------------------------------------------------------------------------
         if (nid < total) {
             land(nid, pre);
+            STAMP(4);  // wait for the prefetched loads, registers -> LDS, barrier
             chain_of(nid);
+            STAMP(5);  // twiddle-chain look-ups
         }
 
         // ---- stores of tile k -------------------------------------------------------------------------
@@ -675,9 +712,18 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
             }
         }
+        STAMP(6);  // stores issued
         // ---- loads of tile k+2 ------------------------------------------------------------------------
-        if (nid + G < total && nid + G > nid) issue_loads(nid + G, pre);
+        if (tile_at(step + 2) < total) issue_loads(tile_at(step + 2), pre);
+        STAMP(7);  // loads issued
+#ifdef PLONKY2_NTT_STAMPS
+        stamp_acc[8] += 1;  // tiles
+#endif
     }
+#ifdef PLONKY2_NTT_STAMPS
+    if (p.stamps && lane == 0)
+        for (int k = 0; k < 9; k++) atomicAdd(reinterpret_cast<unsigned long long *>(p.stamps + k), (unsigned long long)stamp_acc[k]);
+#endif
 }
 
 // PLONKY2_NTT_KERNEL=tile selects the workgroup-tile kernel for every size (A/B measurements, tests of both)
@@ -685,6 +731,43 @@ static bool use_wave_kernel() {
     static const bool v = [] {
         const char *e = getenv("PLONKY2_NTT_KERNEL");
         return !(e && e[0] == 't');
+    }();
+    return v;
+}
+
+#ifdef PLONKY2_NTT_STAMPS
+// three groups of 16 counters (column pass, transposed-store row pass, in-place row pass) in device memory; the file named by
+// PLONKY2_NTT_STAMPS_OUT receives them when the process exits
+static uint64_t *g_stamps = nullptr;
+static void ntt_stamps_dump() {
+    const char *path = getenv("PLONKY2_NTT_STAMPS_OUT");
+    if (!g_stamps || !path) return;
+    uint64_t h[48];
+    if (hipMemcpy(h, g_stamps, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    for (int g = 0; g < 3; g++) {
+        fprintf(f, "{\"pass\": \"%s\"", g == 0 ? "column" : g == 1 ? "row_transposed_store" : "row_in_place");
+        for (int k = 0; k < 9; k++) fprintf(f, ", \"c%d\": %llu", k, (unsigned long long)h[16 * g + k]);
+        fprintf(f, "}\n");
+    }
+    fclose(f);
+}
+static uint64_t *ntt_stamp_buffer(int group) {
+    if (!g_stamps) {
+        if (hipMalloc(&g_stamps, 48 * sizeof(uint64_t)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_stamps, 0, 48 * sizeof(uint64_t));
+        atexit(ntt_stamps_dump);
+    }
+    return g_stamps + 16 * group;
+}
+#endif
+
+// PLONKY2_NTT_XCD=0: workgroups walk tiles w, w+G, ... instead of the XCD-aware order (A/B measurements)
+static bool xcd_map_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PLONKY2_NTT_XCD");
+        return !(e && e[0] == '0');
     }();
     return v;
 }
@@ -718,9 +801,14 @@ hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t 
     if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t resident = persistent_workgroups() >> (LOGW - 3);  // the LDS holds two 8-wave or one 16-wave workgroup per CU
     const uint32_t wgs = (uint32_t)(total < resident ? total : resident);
+#ifdef PLONKY2_NTT_STAMPS
+    PassParams p = p_in;
+    p.stamps = ntt_stamp_buffer(TWIDDLE ? 0 : (ROWS_OUT ? 2 : 1));
+#else
     const PassParams &p = p_in;
+#endif
     hipLaunchKernelGGL((ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW>), dim3(wgs), dim3(64 << LOGW), lds_bytes, stream, p,
-                       (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)total);
+                       (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)total, (uint32_t)(xcd_map_enabled() && wgs % 8 == 0 ? 1 : 0));
     return hipGetLastError();
 }
 
