@@ -56,6 +56,8 @@ struct DeviceState {
     std::recursive_mutex call_mu;
     hipStream_t last_stream = nullptr;
     hipEvent_t order_event = nullptr;
+    hipStream_t hash_stream = nullptr;     // pipelined commit: leaf hashing trails the LDE on this lower-priority stream
+    std::vector<hipEvent_t> chunk_events;  //   one event per column chunk + one for "tree done"
     uint64_t *ref_staging = nullptr;       // its column-major staging copy of the three leaf-major inputs
     uint64_t ref_staging_elems = 0;
 };
@@ -348,6 +350,42 @@ __global__ __launch_bounds__(256) void pack_leaf_ranges_kernel(const uint64_t *_
     }
 }
 
+// Pipelined commit (large commitments): the columns are extended chunk by chunk on the caller's stream while a second,
+// lower-priority stream absorbs the finished chunks into the leaves' sponges (hash_leaves_chunk). The LDE passes are
+// latency-bound and leave half of the vector ALU idle; the hashing is ALU-bound: running them side by
+// side hides most of the LDE. PLONKY2_COMMIT_PIPELINE=0 turns it off (A/B measurements).
+bool commit_pipeline_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PLONKY2_COMMIT_PIPELINE");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+hipError_t get_hash_stream(hipStream_t *hs, std::vector<hipEvent_t> **events, size_t need) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState &st = g_dev[dev & 63];
+    if (!st.hash_stream) {
+        int lo = 0, hi = 0;  // numerically lower = higher priority; the hashing takes the LOWEST so that the LDE runs ahead
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e != hipSuccess) return e;
+        e = hipStreamCreateWithPriority(&st.hash_stream, hipStreamNonBlocking, lo);
+        if (e != hipSuccess) return e;
+    }
+    while (st.chunk_events.size() < need) {
+        hipEvent_t ev;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        st.chunk_events.push_back(ev);
+    }
+    *hs = st.hash_stream;
+    *events = &st.chunk_events;
+    return hipSuccess;
+}
+
 GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,
                                 uint32_t cap_height, uint32_t salt_size, uint64_t shift, uint64_t *d_lde,
                                 uint64_t *d_leaves, uint64_t *d_digests, uint64_t *d_cap, Streams *s,
@@ -361,8 +399,49 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     CosetLease ct;
     HIP_TRY(get_tables(&tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
-    HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
     (void)sync_stream2_before_leaves;
+    const uint32_t leaf_len = (uint32_t)(poly_num + salt_size);
+    constexpr uint64_t CHUNK = 16;  // columns per pipeline step: two rate blocks
+    if (commit_pipeline_enabled() && poly_num >= 3 * CHUNK && n_ext >= (1ull << 16)) {
+        const size_t n_chunks = (size_t)((poly_num + CHUNK - 1) / CHUNK);
+        hipStream_t hs;
+        std::vector<hipEvent_t> *evs;
+        HIP_TRY(get_hash_stream(&hs, &evs, n_chunks + 2));
+        // the hash stream starts behind whatever the caller has queued (the buffers may still be in use by earlier work)
+        HIP_TRY(hipEventRecord((*evs)[n_chunks], s->stream));
+        HIP_TRY(hipStreamWaitEvent(hs, (*evs)[n_chunks], 0));
+        // A launch that starts in the middle of the leaf (c0 != 0) carries only the capacity, so its first block must be a
+        // full one: if the last chunk (with the salt columns and a trailing partial block) would be shorter than a rate
+        // block, the chunk before it is not absorbed on its own but together with the last.
+        const uint64_t last_c0 = (n_chunks - 1) * CHUNK;
+        const bool merge_last_two = (leaf_len & 7) && leaf_len - last_c0 < 8;
+        uint64_t absorbed = 0;
+        for (size_t c = 0; c < n_chunks; c++) {
+            const bool last = c + 1 == n_chunks;
+            const uint64_t c0 = c * CHUNK, c1 = last ? poly_num : c0 + CHUNK;
+            HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs + c0 * n, d_lde + c0 * n_ext, c1 - c0, n, n_ext, s->stream));
+            HIP_TRY(hipEventRecord((*evs)[c], s->stream));
+            HIP_TRY(hipStreamWaitEvent(hs, (*evs)[c], 0));
+            if (!last && merge_last_two && c + 2 == n_chunks) continue;
+            const uint64_t upto = last ? leaf_len : c1;  // the last launch also takes the salt columns (already in d_lde)
+            HIP_TRY(hash_leaves_chunk(d_lde, (uint32_t)absorbed, (uint32_t)upto, leaf_len, n_ext, n_ext, cap_height, d_digests, d_cap, hs));
+            absorbed = upto;
+        }
+        hipEvent_t ev_lde2 = nullptr, ev_tr2 = nullptr;
+        if (d_leaves) {
+            HIP_TRY(get_events(&ev_lde2, &ev_tr2));
+            HIP_TRY(hipEventRecord(ev_lde2, s->stream));
+            HIP_TRY(hipStreamWaitEvent(s->stream2, ev_lde2, 0));
+            HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, leaf_len, n_ext, n_ext, s->stream2));
+            HIP_TRY(hipEventRecord(ev_tr2, s->stream2));
+        }
+        HIP_TRY(merkle_tree_layers(d_digests, d_cap, n_ext, cap_height, hs));
+        HIP_TRY(hipEventRecord((*evs)[n_chunks + 1], hs));
+        HIP_TRY(hipStreamWaitEvent(s->stream, (*evs)[n_chunks + 1], 0));  // the caller's stream continues after the tree
+        if (d_leaves) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr2, 0));
+        return ok();
+    }
+    HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
     hipEvent_t ev_lde = nullptr, ev_tr = nullptr;
     if (d_leaves) {
         // The leaf-major copy is pure HBM traffic and the Poseidon hashing pure integer ALU work:

@@ -83,6 +83,56 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
     }
 }
 
+// The same sponge cut at column boundaries, so that hashing can start before the last columns exist (a commit's LDE
+// produces them chunk by chunk): this launch absorbs columns [c0, c1) of every leaf, c0 a multiple of 8. In overwrite mode
+// a full block replaces all eight rate words (hashing.rs:89-98), so what survives from one permutation to the next full
+// block is the CAPACITY, four words — exactly the size of the leaf's digest slot, which carries it between launches
+// (raw u64 representatives; the last launch overwrites it with the canonical digest). leaf_len > 4 (shorter leaves are
+// not hashed at all, config.rs:57-63).
+__global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *__restrict__ cols, uint32_t c0, uint32_t c1,
+                                                                uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                                                                uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
+                                                                uint32_t log_sub_leaves) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint64_t *slot;
+    if (log_sub_leaves == 0) {
+        slot = cap + 4 * i;
+    } else {
+        uint64_t sub = i >> log_sub_leaves, idx = i & ((1ull << log_sub_leaves) - 1);
+        uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+        slot = digests + 4 * (sub * sub_digests + digest_slot(idx, 0));
+    }
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    if (c0 != 0) {
+        const u64x2 a = reinterpret_cast<const u64x2 *>(slot)[0], b = reinterpret_cast<const u64x2 *>(slot)[1];
+        s[8] = a.x, s[9] = a.y, s[10] = b.x, s[11] = b.y;
+    }
+    uint32_t j = c0;
+    for (; j + 8 <= c1; j += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+        poseidon::permute(s);
+    }
+    if (c1 == leaf_len) {
+        if (j < leaf_len) {
+            // short last block overwrites only its own lanes (hashing.rs:89-92): the other rate words are the previous
+            // permutation's, which this launch has just computed (c1 - c0 >= 8) or, for a chunk shorter than a block, cannot
+            // have — the host never makes such a chunk (see merkle_tree_from_columns_chunked)
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (j + k < leaf_len) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+            poseidon::permute(s);
+        }
+        store_hash(slot, s);
+    } else {
+        reinterpret_cast<u64x2 *>(slot)[0] = u64x2{s[8], s[9]};
+        reinterpret_cast<u64x2 *>(slot)[1] = u64x2{s[10], s[11]};
+    }
+}
+
 // Same, for leaf-major input rows[i*leaf_len + j] (used by gl_merkle_tree_from_leaves).
 __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restrict__ rows, uint32_t leaf_len,
                                                         uint64_t n_leaves, uint64_t *__restrict__ digests,
@@ -323,6 +373,23 @@ hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uin
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return tree_layers(digests, cap, n_leaves, log_sub, stream);
+}
+
+hipError_t hash_leaves_chunk(const uint64_t *cols, uint32_t c0, uint32_t c1, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
+                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream) {
+    int lg = log2_exact(n_leaves);
+    if (lg < 0 || (int)cap_height > lg || leaf_len <= 4 || (c0 & 7) || c0 >= c1 || c1 > leaf_len) return hipErrorInvalidValue;
+    if (c1 != leaf_len && ((c1 - c0) & 7)) return hipErrorInvalidValue;       // inner chunks are whole rate blocks
+    if (c1 == leaf_len && (leaf_len & 7) && c1 - c0 < 8 && c0 != 0) return hipErrorInvalidValue;  // see the kernel
+    hipLaunchKernelGGL(hash_leaves_chunk_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, cols, c0, c1, leaf_len, n_leaves,
+                       col_stride, digests, cap, (uint32_t)(lg - cap_height));
+    return hipGetLastError();
+}
+
+hipError_t merkle_tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t cap_height, hipStream_t stream) {
+    int lg = log2_exact(n_leaves);
+    if (lg < 0 || (int)cap_height > lg) return hipErrorInvalidValue;
+    return tree_layers(digests, cap, n_leaves, (uint32_t)(lg - cap_height), stream);
 }
 
 hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,
