@@ -72,11 +72,11 @@ def cpu_baseline(log_n):
     # about 10 s of timed work have accumulated (bounded: at most 16 calls)
     one = o.fft_bench(n, 1, 4)
     per_thread = 2 * 4 / one
-    # all threads, then half and a quarter of them (2^20-point columns are 8 MiB each: on a big host the all-thread run is
+    # all threads, then a half, a quarter and an eighth of them (2^20-point columns are 8 MiB each: on a big host the all-thread run is
     # bound by the memory system, and fewer threads can deliver more); two columns per thread per call, the thread count
     # with the best rate is run again until about 10 s of timed work have accumulated
     cols, rates = 2, {}
-    for t in sorted({threads, max(1, threads // 2), max(1, threads // 4)}, reverse=True):
+    for t in sorted({threads, max(1, threads // 2), max(1, threads // 4), max(1, threads // 8)}, reverse=True):
         rates[t] = 2 * t * cols / o.fft_bench(n, t, cols, seed=0x706C6F6E6B7932 + t)
     best = max(rates, key=rates.get)
     timed, calls = 0.0, 0

@@ -482,6 +482,42 @@ __device__ __forceinline__ void dot_term(DotAcc &d, uint64_t a, uint64_t b) {
         : "vcc");
 }
 
+// Carry-free dot products for x times COMPILE-TIME constants (Poseidon's partial rounds). x is split once into limbs of
+// 21 / 21 / 22 bits, x = x0 + x1*2^21 + x2*2^42, and every constant c comes with c*2^21 and c*2^42 (mod p) from a table:
+//     x*c = x0*c + x1*(c 2^21) + x2*(c 2^42)   (mod p).
+// With the three constants split into 32-bit halves every partial product is below 2^54, so a dot product of up to ~500 terms
+// is two plain 64-bit sums (low halves, high halves): six v_mad_u64_u32 per term and NO carry instruction (dot_term needs
+// four multiply-adds plus four carry counters), two accumulator registers pairs instead of 4.5, and the reduction at the end
+// is fold96 (7 instructions) instead of dot_finish (20). The vector ALU of the permutation kernel is issue-bound at four
+// cycles per instruction whatever the instruction (rocprofv3: SQ_INSTS_VALU x 4 = kernel cycles), so instructions saved are
+// time saved.
+struct Limbs3 {
+    uint32_t x0, x1, x2;
+};
+__device__ __forceinline__ Limbs3 split21(uint64_t x) {
+    Limbs3 r;
+    r.x0 = (uint32_t)x & 0x1FFFFFu;
+    r.x1 = (uint32_t)(x >> 21) & 0x1FFFFFu;
+    r.x2 = (uint32_t)(x >> 42);
+    return r;
+}
+struct DotAcc2 {
+    uint64_t lo = 0, hi = 0;  // value = lo + hi * 2^32
+};
+__device__ __forceinline__ void dot_term3(DotAcc2 &d, const Limbs3 &x, uint64_t c0, uint64_t c1, uint64_t c2) {
+    d.lo += (uint64_t)x.x0 * (uint32_t)c0;
+    d.hi += (uint64_t)x.x0 * (uint32_t)(c0 >> 32);
+    d.lo += (uint64_t)x.x1 * (uint32_t)c1;
+    d.hi += (uint64_t)x.x1 * (uint32_t)(c1 >> 32);
+    d.lo += (uint64_t)x.x2 * (uint32_t)c2;
+    d.hi += (uint64_t)x.x2 * (uint32_t)(c2 >> 32);
+}
+// a term with a small constant (< 2^32) needs no limbs: x * c = xl*c + (xh*c) * 2^32, both products below 2^64 / terms
+__device__ __forceinline__ void dot_term_small(DotAcc2 &d, uint64_t x, uint32_t c) {
+    d.lo += (uint64_t)(uint32_t)x * c;
+    d.hi += (uint64_t)(uint32_t)(x >> 32) * c;
+}
+
 // value = (A0 + k0*2^64) + (A1 + k1*2^64)*2^32 + (A2 + k2*2^64)*2^64   (mod p): the portable statement of
 // what dot_finish (carry-flag version, below) computes.
 __device__ __forceinline__ uint64_t dot_finish_generic(const DotAcc &d) {

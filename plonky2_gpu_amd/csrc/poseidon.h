@@ -11,6 +11,7 @@
 
 #define POSEIDON_CONST __device__ const
 #include "poseidon_constants.h"
+#include "poseidon_limb_constants.h"
 
 namespace poseidon {
 
@@ -68,48 +69,65 @@ using gl::dot_term;
 //     d_r = c*u_r + sum_i s_i(block start)*w_hat[r][i] + sum_{q in block, q < r} CROSS[r][q]*u_q,
 //     CROSS[r][q] = sum_i w_hat[r][i]*v[q][i]      (tools/gen_poseidon_constants.py)
 // and the s_i are brought up to date once per block, s_i += sum_q v[q][i]*u_q — all of it lazy dot
-// products (8 VALU per term, one reduction per sum) instead of 22-instruction macs: 638 terms and
-// 44 reductions for the 22 rounds instead of 264 terms, 242 macs and 22 reductions.
+// products instead of 22-instruction macs: 638 terms and 44 reductions for the 22 rounds instead of 264 terms, 242 macs
+// and 22 reductions — and, since round 2, carry-free ones: the multiplicand is split once into 21/21/22-bit limbs and every
+// constant comes with its 2^21 and 2^42 multiples, six multiply-adds per term and a seven-instruction reduction per sum
+// (gl::dot_term3 / fold96; before: four multiply-adds + four carry counters per term and twenty instructions per sum).
 __device__ __forceinline__ void partial_rounds(uint64_t (&s)[W]) {
-    // mds_partial_layer_init (poseidon.rs:339-365): out[c] = sum_r s[r] * M[r-1][c-1]
+    using gl::DotAcc2;
+    using gl::Limbs3;
+    using gl::dot_term3;
+    // mds_partial_layer_init (poseidon.rs:339-365): out[c] = sum_r s[r] * M[r-1][c-1]; constants in consumption order
     {
-        uint64_t out[W];
-        out[0] = s[0];
+        Limbs3 sl[W];
+#pragma unroll
+        for (int r = 1; r < W; r++) sl[r] = gl::split21(s[r]);
 #pragma unroll
         for (int c = 1; c < W; c++) {
-            DotAcc acc;
+            DotAcc2 acc;
 #pragma unroll
-            for (int r = 1; r < W; r++) dot_term(acc, s[r], POSEIDON_FAST_PARTIAL_ROUND_INITIAL_MATRIX[(r - 1) * 11 + (c - 1)]);
-            out[c] = dot_finish(acc);
+            for (int r = 1; r < W; r++) {
+                const int t = (c - 1) * 11 + (r - 1);
+                dot_term3(acc, sl[r], POSEIDON_INIT_STREAM_C0[t], POSEIDON_INIT_STREAM_C21[t], POSEIDON_INIT_STREAM_C42[t]);
+            }
+            s[c] = gl::fold96(acc.lo, acc.hi);
         }
-#pragma unroll
-        for (int i = 0; i < W; i++) s[i] = out[i];
     }
     constexpr int B = 11;
 #pragma unroll 1
-    for (int base = 0; base < N_PARTIAL; base += B) {
-        uint64_t u[B];
+    for (int blk = 0; blk < N_PARTIAL / B; blk++) {
+        // this block's constants: [round k: 11 W_HATS, k CROSS] x 11, then VS [i][q] (tools/gen_poseidon_limb_tables.py)
+        const uint64_t *__restrict__ c0 = POSEIDON_PARTIAL_STREAM_C0 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
+        const uint64_t *__restrict__ c21 = POSEIDON_PARTIAL_STREAM_C21 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
+        const uint64_t *__restrict__ c42 = POSEIDON_PARTIAL_STREAM_C42 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
+        Limbs3 sl[W], ul[B];
+#pragma unroll
+        for (int i = 1; i < W; i++) sl[i] = gl::split21(s[i]);  // block-start values, used by all eleven rounds of the block
         uint64_t x = s[0];
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const int r = base + k;
-            u[k] = gl::add_canonical(gl::pow7(x), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[r]);
-            DotAcc acc;
-            dot_term(acc, u[k], POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]);
+            const uint64_t u = gl::add_canonical(gl::pow7(x), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[blk * B + k]);
+            ul[k] = gl::split21(u);
+            DotAcc2 acc;
+            gl::dot_term_small(acc, u, (uint32_t)(POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]));
+            const int off = k * 11 + k * (k - 1) / 2;
 #pragma unroll
-            for (int i = 1; i < W; i++) dot_term(acc, s[i], POSEIDON_FAST_PARTIAL_ROUND_W_HATS[r * 11 + (i - 1)]);
+            for (int i = 1; i < W; i++) dot_term3(acc, sl[i], c0[off + i - 1], c21[off + i - 1], c42[off + i - 1]);
 #pragma unroll
-            for (int q = 0; q < k; q++) dot_term(acc, u[q], POSEIDON_FAST_PARTIAL_ROUND_CROSS[r * N_PARTIAL + base + q]);
-            x = dot_finish(acc);
+            for (int q = 0; q < k; q++) dot_term3(acc, ul[q], c0[off + 11 + q], c21[off + 11 + q], c42[off + 11 + q]);
+            x = gl::fold96(acc.lo, acc.hi);
         }
         s[0] = x;
 #pragma unroll
         for (int i = 1; i < W; i++) {
-            DotAcc acc;
-            acc.a0 = s[i];  // the block-start value, weight 2^0
+            DotAcc2 acc;
+            acc.lo = (uint32_t)s[i], acc.hi = s[i] >> 32;  // the block-start value, weight 2^0
 #pragma unroll
-            for (int q = 0; q < B; q++) dot_term(acc, u[q], POSEIDON_FAST_PARTIAL_ROUND_VS[(base + q) * 11 + (i - 1)]);
-            s[i] = dot_finish(acc);
+            for (int q = 0; q < B; q++) {
+                const int t = 176 + (i - 1) * 11 + q;
+                dot_term3(acc, ul[q], c0[t], c21[t], c42[t]);
+            }
+            s[i] = gl::fold96(acc.lo, acc.hi);
         }
     }
 }

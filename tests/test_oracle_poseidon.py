@@ -100,3 +100,37 @@ def test_commit_from_values_matches_independent_model(oracle):
     assert oracle.canon(got["leaves"]).tolist() == leaves
     assert oracle.canon(got["digests"]).tolist() == dig
     assert oracle.canon(got["cap"]).tolist() == cap
+
+
+def test_device_limb_tables_are_what_the_generator_writes_and_what_they_claim():
+    """csrc/poseidon_limb_constants.h (c, c*2^21, c*2^42 mod p in the order the device consumes them) is generated data: it
+    must equal the generator's output, and every triple must satisfy x*c = x0*c + x1*c21 + x2*c42 for a 21/21/22-bit split."""
+    import os
+    import random
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_poseidon_limb_tables.py"), "--check"]).returncode == 0
+    text = open(os.path.join(root, "plonky2_gpu_amd", "csrc", "poseidon_limb_constants.h")).read()
+    P = 0xFFFFFFFF00000001
+
+    def arr(name):
+        m = re.search(r"uint64_t %s\[(\d+)\][^=]*= \{(.*?)\};" % name, text, re.S)
+        v = [int(t[:-3], 16) for t in re.findall(r"0x[0-9a-fA-F]+ULL", m.group(2))]
+        assert len(v) == int(m.group(1))
+        return v
+
+    rng = random.Random(3)
+    for stream, n in (("POSEIDON_INIT_STREAM", 121), ("POSEIDON_PARTIAL_STREAM", 594)):
+        c0, c21, c42 = arr(stream + "_C0"), arr(stream + "_C21"), arr(stream + "_C42")
+        assert len(c0) == n
+        for k in range(n):
+            assert c21[k] == c0[k] * (1 << 21) % P and c42[k] == c0[k] * (1 << 42) % P
+            x = rng.randrange(1 << 64)
+            x0, x1, x2 = x & 0x1FFFFF, (x >> 21) & 0x1FFFFF, x >> 42
+            lo = x0 * (c0[k] & 0xFFFFFFFF) + x1 * (c21[k] & 0xFFFFFFFF) + x2 * (c42[k] & 0xFFFFFFFF)
+            hi = x0 * (c0[k] >> 32) + x1 * (c21[k] >> 32) + x2 * (c42[k] >> 32)
+            assert lo < 1 << 56 and hi < 1 << 56  # 23 terms stay far below 2^63 (gl::fold96's domain)
+            assert (lo + (hi << 32)) % P == x * c0[k] % P
