@@ -604,7 +604,9 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
         asm volatile("" : "+v"(tid_i), "+v"(lane_i));
 
         // ---- R-point DIFs of this wave's TW columns, no workgroup barrier ------------------------
+#ifndef PLONKY2_NTT_SKELETON  // diagnostic builds only: the pass without its arithmetic (memory and LDS traffic alone)
         tile_transform<LOGEW, WT, LOGR, TWIDDLE>(data, tw, p, lane_i, b * WAVES + wave, z, TWIDDLE ? chain : nullptr);
+#endif
         STAMP(1);  // radix rounds
 
         // ---- results: LDS -> registers ----------------------------------------------------------------

@@ -1,0 +1,24 @@
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from plonky2_gpu_amd import _lib
+if os.environ.get("PLONKY2_LIB"):
+    _lib.LIB_PATH = os.environ["PLONKY2_LIB"]
+import plonky2_gpu_amd as pg
+ctx = pg.Context(0)
+log_n, batch = 20, 64
+n = 1 << log_n
+rng = np.random.default_rng(1)
+host = rng.integers(0, 0xFFFFFFFF00000001, size=(batch, n), dtype=np.uint64)
+buf = pg.DeviceBuffer.from_host(ctx, host)
+def t(order):
+    ms = []
+    for r in range(10):
+        e0, e1 = pg.Event(), pg.Event()
+        e0.record(ctx)
+        _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 0, order, ctx.ptr)
+        e1.record(ctx)
+        ctx.synchronize()
+        if r: ms.append(e1.elapsed_ms_since(e0))
+    return float(np.median(ms))
+print(json.dumps({"tag": os.environ.get("TAG"), "wg_per_cu": os.environ.get("PLONKY2_NTT_WG_PER_CU"), "natural_ms": t(0), "bitrev_ms": t(1)}), flush=True)
