@@ -447,13 +447,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // LOGW = log2 of the wavefronts per workgroup: 3 (tile of 8192 elements, two workgroups per CU) or 4 (16384 elements, one
 // workgroup per CU): the wide tile doubles the segments of the cooperative accesses to 128 bytes — whole cache lines —
 // which the memory system moves ~25 % faster than 64-byte halves (tools/ubench_mem.hip, profiles/r02_ubench_mem.txt).
-template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW>
+//
+// SPLIT (column passes of 2R = 2048 points, LOGR = 10, sixteen waves): a column is twice a wave tile. The first DIF stage —
+// a[j] = x[j] + x[j+R], b[j] = (x[j] - x[j+R]) * w_2R^j — is taken while the segments are spread over the wave buffers (the
+// thread that loaded row j also loaded row j+R), and the two R-point transforms that remain, of a (even frequencies) and b (odd
+// frequencies), are wave tiles like any other: wave 2t holds a of column t, wave 2t+1 holds b. Two passes instead of three
+// for 2^21 and 2^22 points.
+template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW, bool SPLIT = false>
 __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pass_wave_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t total, const uint32_t xcd_map) {
     static_assert(LOGR <= LOGEW, "a wave tile holds whole R-point columns");
+    static_assert(!SPLIT || (LOGR == LOGEW && !ROWS_IN && !ROWS_OUT), "split columns: column passes of 2 * 1024 points");
     extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
     constexpr int R = 1 << LOGR;
     constexpr int NT = 64 << LOGW, WAVES = 1 << LOGW, LOGE = LOGEW + LOGW;  // this kernel's workgroup geometry
-    constexpr uint32_t logt = LOGE - LOGR, T = 1u << logt;        // columns of the workgroup tile
+    constexpr uint32_t logt = LOGE - LOGR - (SPLIT ? 1 : 0), T = 1u << logt;        // columns of the workgroup tile
     constexpr uint32_t logtw = LOGEW - LOGR, TW = 1u << logtw;    // columns of a wave tile
     static_assert(T >= 2, "16-byte accesses");
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -461,7 +468,14 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
     uint64_t *tw = lds + WAVES * WBUF;
     // slot of element (row m, column t) of the workgroup tile
     auto slot = [&](uint32_t m, uint32_t t) -> uint32_t {
+        if constexpr (SPLIT) return ((t << 1) + (m >> LOGR)) * WBUF + phys(m & (R - 1), 0);
         return (t >> logtw) * WBUF + phys((m << logtw) + (t & (TW - 1)), logtw);
+    };
+    // slot of OUTPUT row m: frequency m of a split column is element m >> 1 of the half m & 1 when the tile is in natural order
+    auto slot_out = [&](uint32_t m, uint32_t t) -> uint32_t {
+        if constexpr (SPLIT)
+            if (p.flags & F_NATURAL) return ((t << 1) + (m & 1)) * WBUF + phys(m >> 1, 0);
+        return slot(m, t);
     };
     constexpr bool rows_in = ROWS_IN, rows_out = ROWS_OUT;  // F_LOAD_ROWS / F_STORE_ROWS, fixed at compile time
     const bool coset = p.flags & F_COSET, inverse = p.flags & F_INVERSE, do_scale = p.scale != 1;
@@ -515,7 +529,29 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
         uint32_t z = id / (gx * gy);
         uint32_t tid_i = tid, lane_i = lane;
         asm volatile("" : "+v"(tid_i), "+v"(lane_i));
-        if constexpr (!rows_in) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                uint32_t c = tid_i + it * NT;
+                uint32_t t = (c & (T / 2 - 1)) * 2, m = c >> (logt - 1);  // m < R; pre[it + 4] is row m + R of the same columns
+                u64x2 x = pre[it], y = pre[it + 4];
+                if (coset) {
+                    uint64_t ex = (uint64_t)m * p.in_m, ey = (uint64_t)(m + R) * p.in_m;
+                    uint64_t sx = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(ex >> 10)], p.cs_lo[z * 1024 + (uint32_t)(ex & 1023)]);
+                    uint64_t sy = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(ey >> 10)], p.cs_lo[z * 1024 + (uint32_t)(ey & 1023)]);
+                    x.x = gl::mul(x.x, sx);
+                    x.y = gl::mul(x.y, sx);
+                    y.x = gl::mul(y.x, sy);
+                    y.y = gl::mul(y.y, sy);
+                }
+                const uint64_t wv = p.twh[m << (12 - (LOGR + 1))];  // w_2R^m
+                lds[slot(m, t)] = gl::add(x.x, y.x);
+                lds[slot(m, t + 1)] = gl::add(x.y, y.y);
+                lds[slot(m + R, t)] = gl::mul(gl::sub(x.x, y.x), wv);
+                lds[slot(m + R, t + 1)] = gl::mul(gl::sub(x.y, y.y), wv);
+            }
+            lds_barrier();
+        } else if constexpr (!rows_in) {
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 uint32_t c = tid_i + it * NT;
@@ -581,7 +617,19 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
             decode(tile, b, a, z);
             uint32_t lane_i = lane;
             asm volatile("" : "+v"(lane_i));
-            twiddle_chain<logtw, LOGR>(p, lane_i, b * WAVES + wave, z, chain[0], chain[1]);
+            if constexpr (SPLIT) {
+                // output frequency of column L: k1 = 2 * k_inner + h = bitrev4(i) * (2R/16) + (2 * kr + h)
+                const uint64_t L = (uint64_t)b * T + (wave >> 1);
+                const uint32_t kr = 2 * brev_rt(lane_i, LOGR - 4) + (wave & 1);
+                uint64_t c = wpow(p, L * kr);
+                if (p.flags & F_COSET)
+                    c = gl::mul(c, gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[z * 1024 + (uint32_t)(L & 1023)]));
+                if (p.chain_scale != 1) c = gl::mul(c, p.chain_scale);
+                chain[0] = c;
+                chain[1] = wpow(p, L << (LOGR - 3));
+            } else {
+                twiddle_chain<logtw, LOGR>(p, lane_i, b * WAVES + wave, z, chain[0], chain[1]);
+            }
         }
     };
     if (id < total) issue_loads(id, pre);
@@ -620,8 +668,8 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 if constexpr (TW >= 2) {
                     res[it] = *reinterpret_cast<const u64x2 *>(&lds[slot(m, t)]);
                 } else {
-                    res[it].x = lds[slot(m, t)];
-                    res[it].y = lds[slot(m, t + 1)];
+                    res[it].x = lds[slot_out(m, t)];
+                    res[it].y = lds[slot_out(m, t + 1)];
                 }
             }
         } else {
@@ -789,12 +837,12 @@ static uint32_t persistent_workgroups() {
     return v;
 }
 
-template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW = 3>
+template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW = 3, bool SPLIT = false>
 hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t stream) {
     size_t lds_bytes = (size_t)((WBUF << LOGW) + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -809,7 +857,7 @@ hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t 
 #else
     const PassParams &p = p_in;
 #endif
-    hipLaunchKernelGGL((ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW>), dim3(wgs), dim3(64 << LOGW), lds_bytes, stream, p,
+    hipLaunchKernelGGL((ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW, SPLIT>), dim3(wgs), dim3(64 << LOGW), lds_bytes, stream, p,
                        (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)total, (uint32_t)(xcd_map_enabled() && wgs % 8 == 0 ? 1 : 0));
     return hipGetLastError();
 }
@@ -834,6 +882,13 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
         if (ri && ro) return launch_pass_wave_mode<LOGR, false, true, true>(p, grid, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// column pass of 2048 points (ntt_pass_wave_kernel, SPLIT): the planner asks for it with logr = 11 and F_WIDE
+template <bool TWIDDLE>
+hipError_t launch_pass_wave_split(const PassParams &p, dim3 grid, hipStream_t stream) {
+    if (!(p.flags & F_WIDE) || (p.flags & (F_LOAD_ROWS | F_STORE_ROWS))) return hipErrorInvalidValue;
+    return launch_pass_wave_mode<LOGEW, TWIDDLE, false, false, 4, true>(p, grid, stream);
 }
 
 template <int LOGR, bool TWIDDLE>
@@ -867,6 +922,8 @@ hipError_t dispatch_pass(int logr, const PassParams &p, dim3 grid, hipStream_t s
             default:
                 break;
         }
+        if constexpr (TWIDDLE)
+            if (logr == LOGEW + 1) return launch_pass_wave_split<true>(p, grid, stream);
         if constexpr (!TWIDDLE) {
             switch (logr) {
                 case 1: return launch_pass_wave<1, false>(p, grid, stream);
@@ -920,7 +977,7 @@ static bool wide_ok(uint32_t logr, uint64_t t_limit) {
         const char *e = getenv("PLONKY2_NTT_WIDE");
         return !(e && e[0] == '0');
     }();
-    return enabled && use_wave_kernel() && logr >= (uint32_t)WIDE_MIN_LOGR && logr <= (uint32_t)LOGEW &&
+    return enabled && use_wave_kernel() && logr >= (uint32_t)WIDE_MIN_LOGR && logr <= (uint32_t)LOGEW + 1 &&  // LOGEW + 1: split columns
            (t_limit & ((1ull << (LOGE + 1 - logr)) - 1)) == 0;
 }
 
@@ -964,8 +1021,9 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         return dispatch_pass<false>(log_n, p, grid, stream);
     }
 
-    if (log_n <= 20) {
-        // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass)
+    if (log_n <= 20 || (log_n == 21 && wide_ok(11, 1024))) {
+        // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass); 2^21 = 2048 x 1024 with the
+        // column pass on split columns
         const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
         // measured at 2^20 on one device: wide tiles make the column pass 6 % faster and the transposed-store row pass 4 % slower
@@ -1266,7 +1324,7 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
         }
         return hipSuccess;
     }
-    if (log_n > 20) {
+    if (log_n > 21 || (log_n == 21 && !wide_ok(11, 1024))) {
         // three-pass sizes; needs the coset blocks of all polynomials contiguous (dst_stride = n << rate_bits)
         if (dst_stride != n_cosets * n) return hipErrorInvalidValue;
         const uint32_t la = (log_n + 2) / 3, lb = (log_n - la + 1) / 2, lc = log_n - la - lb;

@@ -193,6 +193,27 @@ def test_more_distinct_cosets_than_the_table_cache_holds(gpu, oracle):
     assert (got[0] == oracle.canon(oracle.coset_lde(c, 2))[bitrev_perm(12)]).all()
 
 
+@pytest.mark.parametrize(
+    "env",
+    [
+        {"PLONKY2_NTT_KERNEL": "tile"},  # workgroup-tile kernel everywhere, three passes from 2^21
+        {"PLONKY2_NTT_WIDE": "0"},  # 8192-element tiles only: no 128-byte column pass, no split columns (2^21 in three passes)
+        {"PLONKY2_NTT_XCD": "0", "PLONKY2_NTT_WG_PER_CU": "1"},  # plain tile order, one workgroup per CU
+    ],
+    ids=["tile-kernel", "narrow-tiles", "plain-order"],
+)
+def test_alternative_kernel_selections(gpu, env):
+    """The library picks its pass kernels once per process from the environment (A/B knobs of DESIGN section 3.1); every
+    selection must give the oracle's results. Runs tests/ntt_variant_child.py under each."""
+    import os
+    import subprocess
+    import sys
+
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ntt_variant_child.py")
+    r = subprocess.run([sys.executable, child], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_ntt_argument_errors(gpu):
     import plonky2_gpu_amd as pg
     from plonky2_gpu_amd import _lib
