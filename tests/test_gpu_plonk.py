@@ -156,6 +156,37 @@ def test_opening_evaluations_in_the_quadratic_extension(gpu, oracle, n_polys, lo
             assert tuple(int(v) for v in got[q, i]) == plonk_ref.eval_ext2([int(c) for c in coeffs[i]], z), (q, i)
 
 
+def test_quadratic_extension_reference_constants_on_the_device(gpu):
+    """The device's F_{p^2} arithmetic against the reference's constants (field/src/goldilocks_extensions.rs:24-27,
+    field/src/field_testing.rs:154-166): evaluating X^k at the extension's power-of-two generator g = (0, 15659105665374529263)
+    gives g^k — g^2 is the base field's power-of-two generator 1753635133440165772, g^(2^15) has order 2^18 (its 2^18-th power
+    through another evaluation is one) — and at the multiplicative generator the evaluation of X^(2^16) equals the oracle's
+    power."""
+    import plonky2_gpu_amd as pg
+    from oracle import fri_ref
+
+    gen = (18081566051660590251, 16121475356294670766)
+    g = (0, 15659105665374529263)
+    log_n = 17
+    coeffs = np.zeros((4, 1 << log_n), dtype=np.uint64)
+    coeffs[0, 2] = 1  # X^2
+    coeffs[1, 1 << 15] = 1  # X^(2^15)
+    coeffs[2, 1 << 16] = 1  # X^(2^16)
+    coeffs[3, :3] = (5, 0, 3)  # 5 + 3 X^2
+    batch = pg.PolynomialBatch.from_coeffs(gpu, coeffs, 1, False, 0, leaf_major=False)
+    got = batch.eval_polynomials_ext2([g, gen])
+    val = lambda q, i: tuple(int(v) for v in got[q, i])
+    assert val(0, 0) == (1753635133440165772, 0)
+    h = val(0, 1)
+    assert h == fri_ref.ext_pow(g, 1 << 15) and fri_ref.ext_pow(h, 1 << 18) == (1, 0) and fri_ref.ext_pow(h, 1 << 17) != (1, 0)
+    assert val(1, 2) == fri_ref.ext_pow(gen, 1 << 16)
+    assert val(0, 3) == ((5 + 3 * 1753635133440165772) % P, 0)
+    # the device value fed back: evaluating X^(2^16) at h = g^(2^15) is g^(2^31), whose fourth power is one
+    again = batch.eval_polynomials_ext2([h])
+    g31 = tuple(int(v) for v in again[0, 2])
+    assert g31 == fri_ref.ext_pow(g, 1 << 31) and fri_ref.ext_pow(g31, 4) == (1, 0) and fri_ref.ext_pow(g31, 2) != (1, 0)
+
+
 @pytest.mark.parametrize("two_groups,degree_bits", [(False, 4), (True, 4), (True, 7)])
 def test_quotient_with_table_driven_gates(gpu, two_groups, degree_bits):
     """compute_quotient_polys for a circuit described by gate programs (Noop / Constant / PublicInput /

@@ -86,6 +86,32 @@ def test_ext2_evaluation_against_power_sums():
         assert plonk_ref.eval_ext2(coeffs, zb) == (poly_eval(coeffs, zb[0]), 0)
 
 
+def test_quadratic_extension_reference_constants():
+    """The reference's own known answers for F_p[X]/(X^2 - 7) (field/src/goldilocks_extensions.rs:19-27 with the checks of
+    field/src/field_testing.rs:154-166, test_power_of_two_gen): the multiplicative generator raised to (p^2 - 1) / 2^33 is the
+    power-of-two generator, whose square is the base field's power-of-two generator (goldilocks_field.rs:89), and
+    DTH_ROOT = W^((p-1)/2). They pin the extension multiplication every opening, FRI fold and gate evaluation of the oracle
+    uses (plonk_ref.ext2_mul; gates_ref.Ext is checked against it)."""
+    from oracle import fri_ref, gates_ref
+
+    W, dth_root = 7, 18446744069414584320
+    gen = (18081566051660590251, 16121475356294670766)
+    pow2_gen = (0, 15659105665374529263)
+    base_pow2_gen = 1753635133440165772
+    assert plonk_ref.W == W and gates_ref.W == W
+    assert pow(W, (P - 1) // 2, P) == dth_root == P - 1
+    assert (P * P) >> 33 == (P * P - 1) >> 33  # order() >> TWO_ADICITY as the reference writes it
+    assert fri_ref.ext_pow(gen, (P * P) >> 33) == pow2_gen
+    assert fri_ref.ext_pow(pow2_gen, 2) == (base_pow2_gen, 0)
+    assert fri_ref.ext_pow(pow2_gen, 1 << 33) == (1, 0) and fri_ref.ext_pow(pow2_gen, 1 << 32) != (1, 0)
+    assert fri_ref.ext_mul(gen, fri_ref.ext_inv(gen)) == (1, 0)
+    # Frobenius: x^p = (a, DTH_ROOT * b)  (field_testing.rs:135-144)
+    assert fri_ref.ext_pow(gen, P) == (gen[0], dth_root * gen[1] % P)
+    # the second extension class the oracle carries agrees
+    assert gates_ref.Ext.mul(gen, pow2_gen) == fri_ref.ext_mul(gen, pow2_gen)
+    assert gates_ref.Ext.mul(pow2_gen, pow2_gen) == (base_pow2_gen, 0)
+
+
 @pytest.mark.parametrize("two_groups", [False, True])
 def test_mini_circuit_with_gates_satisfies_the_verifier_identity(two_groups):
     """Gate constraints (filters from selector polynomials) + permutation argument on a tiny real
