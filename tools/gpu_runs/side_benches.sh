@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r02aux
+O=gpurun_out/side
 mkdir -p $O
 timeout 600 python3 tools/sweep.py > $O/sweep.jsonl 2> $O/sweep.err
 timeout 300 python3 tools/bench_prove.py 18 234 5 1 1 > $O/prove.json 2> $O/prove.err

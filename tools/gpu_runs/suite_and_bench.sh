@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r02full
+O=gpurun_out/suite
 mkdir -p $O
 timeout 1500 python3 -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1
 echo "tests rc=$?" >> $O/gpu_suite.log

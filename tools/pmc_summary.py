@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 passes of tools/scratch/pmc.sh (one directory per counter set, each a run of
+"""Summarise the rocprofv3 passes of tools/gpu_runs/pmc_passes.sh (one directory per counter set, each a run of
 `bench.py --no-prove --no-cpu` or of tools/bench_poseidon.py) into profiles/<tag>_pmc_summary.json.
 
 Usage: python tools/pmc_summary.py <gpurun_out/r02pmc> <tag>
