@@ -1,6 +1,8 @@
 """Differential campaign one level below fuzz_prove.py: randomly shaped NTTs, coset LDEs and
 PolynomialBatch commits on the device against the C oracle (oracle/gl_oracle.c).
-    python tests/fuzz_commit.py [cases=60] [seed=1]
+    python tests/fuzz_commit.py [cases=60] [seed=1] [large]
+`large`: 2^13..2^22 rows (every two-pass decomposition, wide and narrow tiles, ragged tiles, the split columns of 2^21, three passes at 2^22),
+1..5 polynomials, rate 0..1.
 Shapes: 1..48 polynomials (crossing the 8-element sponge block and the <=4 `not hashed` rule), 2^0..2^13
 rows, rate 0..3 bits, every legal cap height, values that are NOT canonical (>= p) in a tenth of the
 cases, from_values and from_coeffs, with and without the leaf-major copy; forward / inverse NTT with
@@ -28,20 +30,31 @@ def rand_values(nprng, shape, non_canonical):
 
 def bitrev_perm(n):
     bits = n.bit_length() - 1
-    return np.array([int(f"{i:0{bits}b}"[::-1], 2) if bits else 0 for i in range(n)], dtype=np.int64)
+    idx = np.arange(n, dtype=np.int64)
+    out = np.zeros(n, dtype=np.int64)
+    for b in range(bits):
+        out |= ((idx >> b) & 1) << (bits - 1 - b)
+    return out
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     rng, nprng = random.Random(seed), np.random.default_rng(seed)
     ctx = pg.Context(0)
     t0 = time.time()
     for k in range(cases):
-        log_n = rng.choice([0, 1, 2, 3, 5, 7, 9, 10, 11, 12, 13])
-        n_polys = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 31, 48])
-        rate_bits = rng.choice([0, 1, 2, 3])
-        cap_height = rng.randrange(0, log_n + rate_bits + 1)
+        if large:
+            log_n = rng.choice([13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+            n_polys = rng.choice([1, 2, 3, 5])
+            rate_bits = rng.choice([0, 1]) if log_n < 21 else 0  # the LDE of 2^21 and 2^22 rows is in test_gpu_ntt.py
+            cap_height = rng.randrange(0, 6)
+        else:
+            log_n = rng.choice([0, 1, 2, 3, 5, 7, 9, 10, 11, 12, 13])
+            n_polys = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 31, 48])
+            rate_bits = rng.choice([0, 1, 2, 3])
+            cap_height = rng.randrange(0, log_n + rate_bits + 1)
         non_canonical = rng.random() < 0.1
         from_values = rng.random() < 0.5
         leaf_major = rng.random() < 0.5
@@ -69,7 +82,7 @@ def main():
         # ---- NTT on the same data: forward natural, forward bit-reversed, inverse round trip
         x = vals.copy()
         nat = pg.fft_with_options(ctx, x)
-        want = o.canon(o.fft_batch(x.copy()))
+        want = o.canon(o.fft_batch(x.copy(), threads=4))
         ok = ok and (nat == want).all()
         buf = pg.DeviceBuffer.from_host(ctx, x)
         n = 1 << log_n

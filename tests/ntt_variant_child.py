@@ -22,7 +22,7 @@ def bitrev_perm(bits):
 
 def main():
     gpu = pg.Context(0)
-    for log_n in (9, 13, 16, 20, 21):
+    for log_n in (9, 13, 16, 20, 21, 22):
         x = oracle.random_field((3, 1 << log_n), seed=9100 + log_n)
         exp = oracle.canon(oracle.fft_batch(x, threads=2))
         f = pg.fft_with_options(gpu, x)
@@ -30,7 +30,7 @@ def main():
         assert (pg.ifft_with_options(gpu, f) == x).all(), ("inverse", log_n)
         b = pg.fft_with_options(gpu, x[1], bit_reversed=True)
         assert (b == exp[1][bitrev_perm(log_n)]).all(), ("bit-reversed", log_n)
-    for log_n, rate_bits in ((14, 3), (20, 1), (21, 1)):
+    for log_n, rate_bits in ((14, 3), (20, 1), (21, 1), (22, 0)):
         c = oracle.random_field((2, 1 << log_n), seed=9200 + log_n)
         got = pg.coset_lde_bit_reversed(gpu, c, rate_bits)
         perm = bitrev_perm(log_n + rate_bits)

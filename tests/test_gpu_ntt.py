@@ -144,10 +144,11 @@ def test_ntt_three_pass_sizes(gpu, oracle, log_n):
     assert (b == exp[1][bitrev_perm(log_n)]).all()
 
 
-def test_coset_lde_three_pass(gpu, oracle):
+@pytest.mark.parametrize("log_n,rate_bits", [(21, 1), (22, 1), (23, 0)])
+def test_coset_lde_three_pass(gpu, oracle, log_n, rate_bits):
+    """Coset LDE of the large sizes: 2^21 in two passes (split 2048-point columns), 2^22 and 2^23 in three."""
     import plonky2_gpu_amd as pg
 
-    log_n, rate_bits = 21, 1
     c = oracle.random_field((2, 1 << log_n), seed=6000)
     got = pg.coset_lde_bit_reversed(gpu, c, rate_bits)
     perm = bitrev_perm(log_n + rate_bits)

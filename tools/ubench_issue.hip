@@ -10,7 +10,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR, CND32, ADD32, SUB32, ADDE64, MAD1 };
+enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR, CND32, ADD32, SUB32, ADDE64, MAD1, DOT4, MAD24, PERM, ADD3, LSHLADD32, ALIGNBIT, BFE, PLSWAP32, MADI64, MADU16 };
 
 template <int KIND>
 __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
@@ -26,6 +26,16 @@ __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
     if constexpr (KIND == ADD32) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(c) : "v"(x));                     // no carry-out
     if constexpr (KIND == SUB32) asm volatile("v_sub_u32_e32 %0, %0, %1" : "+v"(c) : "v"(x));
     if constexpr (KIND == ADDE64) asm volatile("v_add_co_u32_e64 %0, vcc, %0, %1" : "+v"(c) : "v"(x) : "vcc");    // VOP3 encoding of the carry add
+    if constexpr (KIND == DOT4) asm volatile("v_dot4_u32_u8 %0, %1, %1, %0" : "+v"(c) : "v"(x));                  // 4 x (u8 * u8) + u32
+    if constexpr (KIND == MAD24) asm volatile("v_mad_u32_u24 %0, %1, %1, %0" : "+v"(c) : "v"(x));                 // 24 x 24 + 32
+    if constexpr (KIND == PERM) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(c) : "v"(x));                     // byte shuffle
+    if constexpr (KIND == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(c) : "v"(x));
+    if constexpr (KIND == LSHLADD32) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(c) : "v"(x));
+    if constexpr (KIND == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(c) : "v"(x));
+    if constexpr (KIND == BFE) asm volatile("v_bfe_u32 %0, %0, 3, 21" : "+v"(c));
+    if constexpr (KIND == PLSWAP32) { uint32_t t = x; asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(t)); }
+    if constexpr (KIND == MADI64) asm volatile("v_mad_i64_i32 %0, vcc, %1, %1, %0" : "+v"(w) : "v"(x) : "vcc");
+    if constexpr (KIND == MADU16) asm volatile("v_mad_u32_u16 %0, %1, %1, %0" : "+v"(c) : "v"(x));
     if constexpr (KIND == MAD1) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w) : "v"(x) : "vcc");       // multiply-add used as a 64-bit add
 }
 
@@ -88,6 +98,16 @@ int main() {
     run<0, 16, SUB32>("v_sub_u32 (no carry-out) only");
     run<0, 16, ADDE64>("v_add_co_u32_e64 (VOP3) only");
     run<0, 16, MAD1>("v_mad_u64_u32 x*1 + acc only");
+    run<0, 16, DOT4>("v_dot4_u32_u8 only");
+    run<0, 16, MAD24>("v_mad_u32_u24 only");
+    run<0, 16, MADU16>("v_mad_u32_u16 only");
+    run<0, 16, PERM>("v_perm_b32 only");
+    run<0, 16, ADD3>("v_add3_u32 only");
+    run<0, 16, LSHLADD32>("v_lshl_add_u32 only");
+    run<0, 16, ALIGNBIT>("v_alignbit_b32 only");
+    run<0, 16, BFE>("v_bfe_u32 only");
+    run<0, 16, PLSWAP32>("v_permlane32_swap_b32 only");
+    run<0, 16, MADI64>("v_mad_i64_i32 only");
     printf("-- the field multiplication's shape: 5 multiply-adds and 11-14 carry-chain instructions\n");
     run<5, 14, ADDC>("old gl::mul shape (5 + 14)");
     run<5, 11, ADDC>("new gl::mul shape (5 + 11)");
