@@ -107,6 +107,49 @@ def test_commit_from_values_matches_oracle(gpu, oracle, n_polys, log_n, rate_bit
     assert (b2.merkle_tree.cap == batch.merkle_tree.cap).all()
 
 
+@pytest.mark.parametrize(
+    "n_polys,log_n,rate_bits,h,leaf_major,salted",
+    [
+        (48, 13, 3, 4, True, False),  # exactly three chunks, whole rate blocks
+        (50, 13, 3, 4, False, False),  # last chunk of 2 columns: merged with the one before it
+        (55, 14, 2, 0, True, False),  # 7 columns left over, cap height 0
+        (57, 13, 3, 2, False, False),  # 9 left over: its own launch, ragged last block
+        (135, 13, 3, 4, True, False),  # the benchmark's leaf length
+        (64, 15, 1, 4, False, False),
+        (50, 13, 3, 4, True, True),  # salt columns ride on the last launch
+        (60, 13, 3, 3, False, True),  # 60 + 4 = whole rate blocks only with the salt
+    ],
+)
+def test_commit_through_the_pipelined_path(gpu, oracle, n_polys, log_n, rate_bits, h, leaf_major, salted):
+    """From 48 columns and 2^16 leaves on, the commit runs the LDE in chunks of 16 columns on the caller's stream while a second
+    stream absorbs each finished chunk into the leaves' sponges (capi.hip commit_from_coeffs_impl; the capacity words wait in the
+    digest slot between launches). Same answers as the one-shot path's oracle: coefficients, LDE, digests, cap, leaf-major copy,
+    for chunk counts and leftovers of every kind, with and without salt columns."""
+    import plonky2_gpu_amd as pg
+
+    n_ext = 1 << (log_n + rate_bits)
+    assert n_polys >= 48 and n_ext >= 1 << 16  # the conditions of the pipelined branch
+    vals = oracle.random_field((n_polys, 1 << log_n), seed=n_polys * 77 + log_n)
+    salt = oracle.random_field((4, n_ext), seed=n_polys + 1) if salted else None
+    batch = pg.PolynomialBatch.from_values(gpu, vals, rate_bits, salted, h, salt=salt, leaf_major=leaf_major)
+    exp = oracle.commit_from_values(vals, rate_bits, h, threads=8)
+    leaves = oracle.canon(exp["leaves"])
+    if salted:
+        leaves = np.concatenate([leaves, salt.T], axis=1)
+        dig, cap = oracle.merkle_tree(leaves, h, threads=8)
+    else:
+        dig, cap = exp["digests"], exp["cap"]
+    assert (batch.polynomials == oracle.canon(exp["coeffs"])).all()
+    assert (batch.merkle_tree.cap == oracle.canon(cap)).all()
+    assert (batch.merkle_tree.digests == oracle.canon(dig).reshape(-1, 4)).all()
+    assert (batch.lde_column_major()[:n_polys] == leaves[:, :n_polys].T).all()
+    if leaf_major:
+        assert (batch.merkle_tree.d_leaves.download().reshape(n_ext, -1) == leaves).all()
+    # from_coeffs takes the same branch
+    b2 = pg.PolynomialBatch.from_coeffs(gpu, batch.polynomials, rate_bits, salted, h, salt=salt, leaf_major=False)
+    assert (b2.merkle_tree.cap == batch.merkle_tree.cap).all() and (b2.merkle_tree.digests == batch.merkle_tree.digests).all()
+
+
 def test_commit_with_blinding_salt(gpu, oracle):
     """blinding appends SALT_SIZE columns to every leaf (oracle.rs:985-1002); with caller-provided
     salt the tree equals the oracle's tree over [LDE | salt]."""
