@@ -103,7 +103,7 @@ def _unplanar(a):
     return [(int(x), int(y)) for x, y in zip(a[0], a[1])]
 
 
-@pytest.mark.parametrize("log_n,m", [(0, 1), (3, 1), (4, 5), (9, 3), (12, 37), (15, 2)])
+@pytest.mark.parametrize("log_n,m", [(0, 1), (3, 1), (4, 5), (9, 3), (12, 37), (15, 2), (18, 3)])
 def test_reduce_polys_base(gpu, log_n, m):
     import random
 
@@ -122,7 +122,7 @@ def test_reduce_polys_base(gpu, log_n, m):
     assert _unplanar(d_out.download()) == fri_ref.reduce_polys_base(polys, alpha)
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 5, 8, 9, 13, 16])
+@pytest.mark.parametrize("log_n", [1, 2, 5, 8, 9, 13, 16, 18, 20])  # 2^18: the ed25519 proof; 2^20: config #3's degree
 def test_divide_by_linear_accumulate(gpu, log_n):
     import random
 
@@ -143,7 +143,7 @@ def test_divide_by_linear_accumulate(gpu, log_n):
     assert _unplanar(d_final.download()) == exp
 
 
-@pytest.mark.parametrize("log_len,ab", [(1, 1), (4, 2), (6, 3), (10, 4), (14, 1), (14, 4)])
+@pytest.mark.parametrize("log_len,ab", [(1, 1), (4, 2), (6, 3), (10, 4), (14, 1), (14, 4), (18, 4), (19, 2)])
 def test_fold_and_interleave(gpu, log_len, ab):
     import random
 
