@@ -117,6 +117,36 @@ def test_proof_bytes_equal_the_oracle_at_2e10_to_2e12_rows(gpu, which, degree_bi
         assert pg.serialization.proof_to_bytes(proof) == exp_bytes
 
 
+def test_proof_bytes_at_2e13_rows_equal_the_fixture(gpu):
+    """2^13 rows of the 13-gate circuit (135 wires): the first size at which the commitments inside gl_prove take the pipelined
+    branch (48+ columns, 2^16 leaves) and the LDE has 2^16 points per column. The oracle prover needs minutes for it, so its
+    proof is a fixture (tests/golden/prove_full_2e13.bin, written by tests/golden/gen_prove_golden.py); circuit and witness are
+    rebuilt here from the same seed and must give the same circuit digest and the same proof, byte for byte."""
+    import hashlib
+    import json
+    import os
+
+    import plonky2_gpu_amd as pg
+    from oracle import accel
+    from plonk_instance import make_full_circuit
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "prove_full_2e13.json")))
+    want = open(os.path.join(gold, "prove_full_2e13.bin"), "rb").read()
+    assert hashlib.sha256(want).hexdigest() == meta["sha256"] and len(want) == meta["bytes"]
+    with accel.c_backend():
+        circuit, wires, pis = make_full_circuit(meta["degree_bits"], seed=meta["seed"], arity_bits=tuple(meta["arity_bits"]),
+                                                cap_height=meta["cap_height"], num_queries=meta["num_queries"])
+    assert [int(v) for v in circuit["circuit_digest"]] == meta["circuit_digest"]
+    for compile_gates in (True, False):
+        nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+        assert [int(v) for v in nc.circuit_digest] == meta["circuit_digest"]
+        data = nc.prove_bytes(wires, pis)
+        nc.close()
+        assert len(data) == len(want)
+        assert data == want, compile_gates
+
+
 @pytest.mark.parametrize("qdf,two_groups", [(5, False), (6, False), (4, True)])
 def test_quotient_degree_factor_that_is_not_a_power_of_two(gpu, qdf, two_groups):
     """The trimmed-and-copied chunk path (prover.rs:153-166) of both provers — the Python mirror and the
