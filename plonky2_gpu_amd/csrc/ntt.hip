@@ -748,7 +748,17 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 for (int it = 0; it < 8; it++) {
                     uint32_t c = lane_i + it * WT;
                     uint32_t tl = c & (TW - 1), t = wave * TW + tl, m = (c >> logtw) * 2;
-                    *reinterpret_cast<u64x2 *>(p.dst + out_base + (uint64_t)t * p.out_t + m) = finish(res[it]);
+                    {
+                        // whole rows written once and not read again by this kernel: nontemporal stores (bit-reversed
+                        // 2^20 transform 0.70 ms against 0.73 with plain stores, profiles/r02_ntt_nontemporal_experiment.jsonl;
+                        // nontemporal LOADS of the rows cost 2-3 %)
+                        typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
+                        const u64x2 fv = finish(res[it]);
+                        v2u64 t2;
+                        t2.x = fv.x;
+                        t2.y = fv.y;
+                        __builtin_nontemporal_store(t2, reinterpret_cast<v2u64 *>(p.dst + out_base + (uint64_t)t * p.out_t + m));
+                    }
                 }
             } else {
 #pragma unroll
