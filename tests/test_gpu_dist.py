@@ -45,3 +45,33 @@ def test_rccl_route_with_one_rank(gpu):
                        timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "nccl single-rank ok" in p.stdout
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_with_two_ranks_prints_one_line_for_the_whole_job(gpu, launcher):
+    """bench.py exactly as the scaling run starts it — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — and as `python bench.py --gpus N` (which
+    starts its N ranks itself before anything touches the GPU). Two ranks share this box's one device (rank synchronisation then
+    goes over gloo; with a device per rank it is RCCL): rank 0 prints ONE JSON line, n_gpus = 2, the value is the job's aggregate,
+    the commit leg runs on rank 0, the prove leg on every rank, the CPU baseline only at N = 1."""
+    import json
+
+    bench = os.path.join(ROOT, "bench.py")
+    tail = [bench, "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29500 + os.getpid() % 400)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["metric"] and d["unit"] and d["value"] > 0 and d["config"]["ranks"] == 2
+    assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
+    assert d["extra"]["commit_ms"] > 0 and d["extra"]["prove"]["proofs_per_s_all_gpus"] > 0
