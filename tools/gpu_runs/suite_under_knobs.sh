@@ -1,0 +1,8 @@
+#!/bin/bash
+# the whole GPU suite once more under the alternative kernel selections (DESIGN / INTEGRATION section 10)
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/suite_knobs; mkdir -p $O
+run() { tag=$1; shift; env "$@" timeout 1500 python3 -m pytest tests -x -q -m gpu > $O/$tag.log 2>&1; echo "$tag rc=$? $(tail -n 1 $O/$tag.log)"; }
+run tile PLONKY2_NTT_KERNEL=tile
+run narrow_nopipe PLONKY2_NTT_WIDE=0 PLONKY2_COMMIT_PIPELINE=0
+run plain_wg1 PLONKY2_NTT_XCD=0 PLONKY2_NTT_WG_PER_CU=1
