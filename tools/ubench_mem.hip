@@ -105,8 +105,8 @@ static double time_ms(F &&f, int reps = 7) {
 int main() {
     const uint64_t LOGN = 20, N = 1ull << LOGN, COLS = 64, TOTAL = COLS * N;
     uint64_t *a, *b, *mid;
-    CK(hipMalloc(&a, TOTAL * 8));
-    CK(hipMalloc(&b, TOTAL * 8));
+    CK(hipMalloc(&a, (TOTAL + COLS * 1024 * 512) * 8));  // room for padded row strides
+    CK(hipMalloc(&b, (TOTAL + COLS * 1024 * 512) * 8));
     CK(hipMalloc(&mid, 16 * N * 8));
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -129,6 +129,8 @@ int main() {
     auto contig = [&](uint64_t E) { return Pat{N, E, 0, 31}; };
     // column pass of an R x (N/R) matrix: tile = R rows x T columns, T = E/R; segment = T elements at stride N/R
     auto colpat = [&](uint64_t E, uint64_t R) { uint64_t T = E / R; uint32_t lw = 0; while ((2ull << lw) < T) lw++; return Pat{N, T, N / R, T >= 2 ? lw : 0}; };
+    // the same with the rows of the R x (N/R) matrix pad elements apart (is the 8 KiB stride itself a problem for the channels?)
+    auto colpad = [&](uint64_t E, uint64_t R, uint64_t pad) { Pat q = colpat(E, R); q.col_stride = N + R * pad; q.seg_stride = N / R + pad; return q; };
     struct Case { const char *name; int nt, iter; uint64_t E; Pat in, out; };
     std::vector<Case> cases = {
         {"tile 64KiB/512thr: contiguous -> contiguous (row pass, in place)", 512, 8, 8192, contig(8192), contig(8192)},
@@ -142,6 +144,12 @@ int main() {
         {"tile 128KiB/1024thr: 128B segs stride 8KiB -> same (column pass R=1024, T=16)", 1024, 8, 16384, colpat(16384, 1024), colpat(16384, 1024)},
         {"tile 128KiB/1024thr: contiguous -> 128B segs stride 8KiB (row pass natural, T=16)", 1024, 8, 16384, contig(16384), colpat(16384, 1024)},
         {"tile 128KiB/512thr x16: 128B segs stride 8KiB -> same", 512, 16, 16384, colpat(16384, 1024), colpat(16384, 1024)},
+        {"tile 128KiB/1024thr: 128B segs stride 8KiB+128B -> same", 1024, 8, 16384, colpad(16384, 1024, 16), colpad(16384, 1024, 16)},
+        {"tile 128KiB/1024thr: 128B segs stride 8KiB+256B -> same", 1024, 8, 16384, colpad(16384, 1024, 32), colpad(16384, 1024, 32)},
+        {"tile 128KiB/1024thr: 128B segs stride 8KiB+1152B -> same", 1024, 8, 16384, colpad(16384, 1024, 144), colpad(16384, 1024, 144)},
+        {"tile 64KiB/512thr: 64B segs stride 8KiB+64B -> same", 512, 8, 8192, colpad(8192, 1024, 8), colpad(8192, 1024, 8)},
+        {"tile 64KiB/512thr: 64B segs stride 8KiB+192B -> same", 512, 8, 8192, colpad(8192, 1024, 24), colpad(8192, 1024, 24)},
+        {"tile 64KiB/512thr: contiguous -> 64B segs stride 8KiB+192B", 512, 8, 8192, contig(8192), colpad(8192, 1024, 24)},
         {"tile 32KiB/256thr: contiguous -> contiguous", 256, 8, 4096, contig(4096), contig(4096)},
         {"tile 32KiB/256thr: 64B segs stride 16KiB -> same (column pass R=512, T=8)", 256, 8, 4096, colpat(4096, 512), colpat(4096, 512)},
     };
