@@ -300,6 +300,112 @@ __global__ __launch_bounds__(256) void transpose_back_kernel(const uint64_t *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same two transposes on strips: a workgroup moves 64 rows x a chunk of up to 96 columns (all of them when the matrix
+// has no more). In the leaf-major matrix such a strip is contiguous when it spans all columns, and runs of chunk * 8 bytes per
+// row otherwise, so that side is read or written as a FLAT range, 16 bytes per lane when whole; the column-major side is 512
+// contiguous bytes of one column per wavefront instruction. The 64 x 64 tiles above leave 7 lanes in 64 busy on the third
+// column tile of a 135-column matrix and never use 16-byte accesses (3.2 TB/s); the strips are kept for every shape.
+// ---------------------------------------------------------------------------------------------
+constexpr int STRIP_ROWS = 64;
+constexpr int STRIP_MAX_COLS = 96;  // 64 rows x (pitch <= 97) x 8 bytes = 49 KB of LDS at most: three workgroups per CU (126 columns: two, and slower)
+
+struct StripGeom {
+    uint32_t n_cols, chunk, n_chunks, pitch;  // chunk columns per strip (the last strip may be shorter), LDS row pitch (odd)
+    uint32_t magic, magic_last;               // floor(2^32 / count) + 1 for a full and for the last strip: f / count = (f * magic) >> 32
+};
+
+__device__ __forceinline__ void strip_range(const StripGeom &g, uint32_t &c_begin, uint32_t &c_count, uint32_t &magic) {
+    c_begin = blockIdx.y * g.chunk;
+    const bool last = g.n_cols - c_begin < g.chunk;
+    c_count = last ? g.n_cols - c_begin : g.chunk;
+    magic = last ? g.magic_last : g.magic;
+}
+
+__global__ __launch_bounds__(256) void transpose_strip_kernel(const uint64_t *__restrict__ cols, uint64_t *__restrict__ rows, uint64_t n_rows,
+                                                              uint64_t col_stride, const StripGeom g) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t strip[];
+    const uint64_t r0 = (uint64_t)blockIdx.x * STRIP_ROWS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t c_begin, c_count, magic;
+    strip_range(g, c_begin, c_count, magic);
+    const bool row_ok = r0 + lane < n_rows;
+    // columns -> LDS: one column per wavefront instruction, four in flight per wave
+    for (uint32_t c = wave; c < c_count; c += 16) {
+        uint64_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t cc = c + 4 * k;
+            v[k] = (cc < c_count && row_ok) ? cols[(uint64_t)(c_begin + cc) * col_stride + r0 + lane] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t cc = c + 4 * k;
+            if (cc < c_count) strip[lane * g.pitch + cc] = v[k];
+        }
+    }
+    __syncthreads();
+    // LDS -> rows, flat over the strip
+    const uint32_t total = STRIP_ROWS * c_count;
+    const bool whole = c_count == g.n_cols && r0 + STRIP_ROWS <= n_rows && !(c_count & 1);
+    if (whole) {
+        u64x2 *out = reinterpret_cast<u64x2 *>(rows + r0 * g.n_cols);
+        for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
+            const uint32_t f = 2 * q, r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;  // c even, c + 1 < c_count
+            u64x2 t;
+            t.x = strip[r * g.pitch + c];
+            t.y = strip[r * g.pitch + c + 1];
+            out[q] = t;
+        }
+    } else {
+        for (uint32_t f = threadIdx.x; f < total; f += 256) {
+            const uint32_t r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            if (r0 + r < n_rows) rows[(r0 + r) * g.n_cols + c_begin + c] = strip[r * g.pitch + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_strip_back_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols, uint64_t n_rows,
+                                                                   uint64_t col_stride, const StripGeom g) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t strip[];
+    const uint64_t r0 = (uint64_t)blockIdx.x * STRIP_ROWS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t c_begin, c_count, magic;
+    strip_range(g, c_begin, c_count, magic);
+    const uint32_t total = STRIP_ROWS * c_count;
+    const bool whole = c_count == g.n_cols && r0 + STRIP_ROWS <= n_rows && !(c_count & 1);
+    if (whole) {
+        const u64x2 *in = reinterpret_cast<const u64x2 *>(rows + r0 * g.n_cols);
+        for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
+            const uint32_t f = 2 * q, r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            const u64x2 t = in[q];
+            strip[r * g.pitch + c] = t.x;
+            strip[r * g.pitch + c + 1] = t.y;
+        }
+    } else {
+        for (uint32_t f = threadIdx.x; f < total; f += 256) {
+            const uint32_t r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            if (r0 + r < n_rows) strip[r * g.pitch + c] = rows[(r0 + r) * g.n_cols + c_begin + c];
+        }
+    }
+    __syncthreads();
+    if (r0 + lane < n_rows)
+        for (uint32_t c = wave; c < c_count; c += 4) cols[(uint64_t)(c_begin + c) * col_stride + r0 + lane] = strip[lane * g.pitch + c];
+}
+
+static StripGeom strip_geom(uint32_t n_cols) {
+    StripGeom g;
+    g.n_cols = n_cols;
+    g.n_chunks = (n_cols + STRIP_MAX_COLS - 1) / STRIP_MAX_COLS;
+    g.chunk = (n_cols + g.n_chunks - 1) / g.n_chunks;
+    g.n_chunks = (n_cols + g.chunk - 1) / g.chunk;
+    g.pitch = g.chunk | 1;
+    const uint32_t last = n_cols - (g.n_chunks - 1) * g.chunk;
+    g.magic = (uint32_t)(0x100000000ull / g.chunk) + 1;  // exact for f * count < 2^32; f < 64 * 129
+    g.magic_last = (uint32_t)(0x100000000ull / last) + 1;
+    return g;
+}
+
 unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 // per-device tables of the cooperative permutation, built on first use
@@ -431,9 +537,24 @@ hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64
     return hipGetLastError();
 }
 
+// PLONKY2_TRANSPOSE=tile keeps the 64 x 64 tiles (A/B measurements)
+static bool strips_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("PLONKY2_TRANSPOSE");
+        return !(e && e[0] == 't');
+    }();
+    return v;
+}
+
 hipError_t transpose_to_column_major(const uint64_t *rows, uint64_t *cols, uint32_t n_cols, uint64_t n_rows, uint64_t col_stride,
                                      hipStream_t stream) {
     if (n_cols == 0 || n_rows == 0) return hipSuccess;
+    if (strips_enabled()) {
+        const StripGeom g = strip_geom(n_cols);
+        hipLaunchKernelGGL(transpose_strip_back_kernel, dim3(grid_for(n_rows, STRIP_ROWS), g.n_chunks), dim3(256), (size_t)STRIP_ROWS * g.pitch * 8, stream, rows,
+                           cols, n_rows, col_stride, g);
+        return hipGetLastError();
+    }
     dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
     hipLaunchKernelGGL(transpose_back_kernel, grid, dim3(256), 0, stream, rows, cols, n_cols, n_rows, col_stride);
     return hipGetLastError();
@@ -442,6 +563,12 @@ hipError_t transpose_to_column_major(const uint64_t *rows, uint64_t *cols, uint3
 hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
                                    uint64_t col_stride, hipStream_t stream) {
     if (n_cols == 0 || n_rows == 0) return hipSuccess;
+    if (strips_enabled()) {
+        const StripGeom g = strip_geom(n_cols);
+        hipLaunchKernelGGL(transpose_strip_kernel, dim3(grid_for(n_rows, STRIP_ROWS), g.n_chunks), dim3(256), (size_t)STRIP_ROWS * g.pitch * 8, stream, cols, rows,
+                           n_rows, col_stride, g);
+        return hipGetLastError();
+    }
     dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, cols, rows, n_cols, n_rows, col_stride);
     return hipGetLastError();

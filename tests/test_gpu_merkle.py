@@ -309,3 +309,32 @@ def test_commit_at_the_full_benchmark_size(gpu, oracle):
     assert (b.merkle_tree.cap == cap).all()
     for slot in [0, 1, 2 * (n_ext - 16) - 1] + [int(s) for s in rng.integers(0, 2 * (n_ext - 16), size=200)]:
         assert (a.merkle_tree.d_digests.download(4 * slot, 4) == b.merkle_tree.d_digests.download(4 * slot, 4)).all(), slot
+
+
+@pytest.mark.parametrize("n_cols,n_rows", [(1, 64), (7, 1000), (64, 4096), (96, 640), (97, 641), (135, 8192), (234, 2048), (300, 129), (20, 1 << 16)])
+@pytest.mark.parametrize("kernel", ["strip", "tile"])
+def test_leaf_major_copy_and_back(gpu, n_cols, n_rows, kernel):
+    """gl_transpose (column-major -> leaf-major; plonky2/src/util/mod.rs:23-53 `transpose`) for whole and ragged strips, one and several
+    column chunks, odd and even widths — equal to numpy — with the strip kernels and with the 64 x 64 tiles (PLONKY2_TRANSPOSE=tile, in a
+    child process: the choice is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import plonky2_gpu_amd as pg
+from plonky2_gpu_amd import _lib
+ctx = pg.Context(0)
+n_cols, n_rows = {n_cols}, {n_rows}
+stride = n_rows + 24
+host = np.random.default_rng(n_cols * 7 + n_rows).integers(0, pg.P, size=(n_cols, stride), dtype=np.uint64)
+d_c = pg.DeviceBuffer.from_host(ctx, host); d_r = pg.DeviceBuffer(ctx, n_cols * n_rows + 8)
+_lib.call("gl_transpose", d_c.ptr, d_r.ptr, n_cols, n_rows, stride, ctx.ptr); ctx.synchronize()
+assert (d_r.download(0, n_rows * n_cols).reshape(n_rows, n_cols) == host[:, :n_rows].T).all()
+print("ok")
+"""
+    env = dict(os.environ, PLONKY2_TRANSPOSE=kernel)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1000:] + r.stderr[-2000:]
