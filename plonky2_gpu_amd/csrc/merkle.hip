@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256) void transpose_back_kernel(const uint64_t *__r
 // contiguous bytes of one column per wavefront instruction. The 64 x 64 tiles above leave 7 lanes in 64 busy on the third
 // column tile of a 135-column matrix and never use 16-byte accesses (3.2 TB/s); the strips are kept for every shape.
 // ---------------------------------------------------------------------------------------------
-constexpr int STRIP_ROWS = 64;
-constexpr int STRIP_MAX_COLS = 96;  // 64 rows x (pitch <= 97) x 8 bytes = 49 KB of LDS at most: three workgroups per CU (126 columns: two, and slower)
+constexpr int STRIP_MAX_COLS = 96;    // 64-row strips: 64 x (pitch <= 97) x 8 bytes = 49 KB of LDS at most, three workgroups per CU
+constexpr int STRIP_MAX_COLS32 = 192;  // 32-row strips for wider matrices: whole rows up to 192 columns in the same 49 KB
 
 struct StripGeom {
     uint32_t n_cols, chunk, n_chunks, pitch;  // chunk columns per strip (the last strip may be shorter), LDS row pitch (odd)
@@ -322,39 +322,43 @@ __device__ __forceinline__ void strip_range(const StripGeom &g, uint32_t &c_begi
     magic = last ? g.magic_last : g.magic;
 }
 
+// ROWS = 64: a wavefront instruction moves 64 rows of one column; ROWS = 32: 32 rows of two adjacent columns
+template <int ROWS>
 __global__ __launch_bounds__(256) void transpose_strip_kernel(const uint64_t *__restrict__ cols, uint64_t *__restrict__ rows, uint64_t n_rows,
                                                               uint64_t col_stride, const StripGeom g) {
     extern __shared__ __attribute__((aligned(16))) uint64_t strip[];
-    const uint64_t r0 = (uint64_t)blockIdx.x * STRIP_ROWS;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t CPW = 64 / ROWS;  // columns per wavefront instruction
+    const uint64_t r0 = (uint64_t)blockIdx.x * ROWS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & (ROWS - 1), lc = lane / ROWS;
     uint32_t c_begin, c_count, magic;
     strip_range(g, c_begin, c_count, magic);
-    const bool row_ok = r0 + lane < n_rows;
-    // columns -> LDS: one column per wavefront instruction, four in flight per wave
-    for (uint32_t c = wave; c < c_count; c += 16) {
+    const bool row_ok = r0 + lr < n_rows;
+    for (uint32_t c = wave * CPW + lc; c < c_count; c += 16 * CPW) {
         uint64_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t cc = c + 4 * k;
-            v[k] = (cc < c_count && row_ok) ? cols[(uint64_t)(c_begin + cc) * col_stride + r0 + lane] : 0;
+            const uint32_t cc = c + 4 * CPW * k;
+            v[k] = (cc < c_count && row_ok) ? cols[(uint64_t)(c_begin + cc) * col_stride + r0 + lr] : 0;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t cc = c + 4 * k;
-            if (cc < c_count) strip[lane * g.pitch + cc] = v[k];
+            const uint32_t cc = c + 4 * CPW * k;
+            if (cc < c_count) strip[lr * g.pitch + cc] = v[k];
         }
     }
     __syncthreads();
-    // LDS -> rows, flat over the strip
-    const uint32_t total = STRIP_ROWS * c_count;
-    const bool whole = c_count == g.n_cols && r0 + STRIP_ROWS <= n_rows && !(c_count & 1);
-    if (whole) {
+    // LDS -> rows, flat over the strip. A strip that spans all columns and whole rows is one contiguous, 16-byte aligned range
+    // (ROWS is even and r0 a multiple of it), whatever the parity of the column count: the two elements of a piece may sit
+    // in different rows.
+    const uint32_t total = ROWS * c_count;
+    if (c_count == g.n_cols && r0 + ROWS <= n_rows) {
         u64x2 *out = reinterpret_cast<u64x2 *>(rows + r0 * g.n_cols);
         for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
-            const uint32_t f = 2 * q, r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;  // c even, c + 1 < c_count
+            const uint32_t f = 2 * q, ra = (uint32_t)(((uint64_t)f * magic) >> 32), ca = f - ra * c_count;
+            const uint32_t rb = ca + 1 == c_count ? ra + 1 : ra, cb = ca + 1 == c_count ? 0 : ca + 1;
             u64x2 t;
-            t.x = strip[r * g.pitch + c];
-            t.y = strip[r * g.pitch + c + 1];
+            t.x = strip[ra * g.pitch + ca];
+            t.y = strip[rb * g.pitch + cb];
             out[q] = t;
         }
     } else {
@@ -365,22 +369,24 @@ __global__ __launch_bounds__(256) void transpose_strip_kernel(const uint64_t *__
     }
 }
 
+template <int ROWS>
 __global__ __launch_bounds__(256) void transpose_strip_back_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols, uint64_t n_rows,
                                                                    uint64_t col_stride, const StripGeom g) {
     extern __shared__ __attribute__((aligned(16))) uint64_t strip[];
-    const uint64_t r0 = (uint64_t)blockIdx.x * STRIP_ROWS;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t CPW = 64 / ROWS;
+    const uint64_t r0 = (uint64_t)blockIdx.x * ROWS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & (ROWS - 1), lc = lane / ROWS;
     uint32_t c_begin, c_count, magic;
     strip_range(g, c_begin, c_count, magic);
-    const uint32_t total = STRIP_ROWS * c_count;
-    const bool whole = c_count == g.n_cols && r0 + STRIP_ROWS <= n_rows && !(c_count & 1);
-    if (whole) {
+    const uint32_t total = ROWS * c_count;
+    if (c_count == g.n_cols && r0 + ROWS <= n_rows) {
         const u64x2 *in = reinterpret_cast<const u64x2 *>(rows + r0 * g.n_cols);
         for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
-            const uint32_t f = 2 * q, r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            const uint32_t f = 2 * q, ra = (uint32_t)(((uint64_t)f * magic) >> 32), ca = f - ra * c_count;
+            const uint32_t rb = ca + 1 == c_count ? ra + 1 : ra, cb = ca + 1 == c_count ? 0 : ca + 1;
             const u64x2 t = in[q];
-            strip[r * g.pitch + c] = t.x;
-            strip[r * g.pitch + c + 1] = t.y;
+            strip[ra * g.pitch + ca] = t.x;
+            strip[rb * g.pitch + cb] = t.y;
         }
     } else {
         for (uint32_t f = threadIdx.x; f < total; f += 256) {
@@ -389,19 +395,23 @@ __global__ __launch_bounds__(256) void transpose_strip_back_kernel(const uint64_
         }
     }
     __syncthreads();
-    if (r0 + lane < n_rows)
-        for (uint32_t c = wave; c < c_count; c += 4) cols[(uint64_t)(c_begin + c) * col_stride + r0 + lane] = strip[lane * g.pitch + c];
+    if (r0 + lr < n_rows)
+        for (uint32_t c = wave * CPW + lc; c < c_count; c += 4 * CPW) cols[(uint64_t)(c_begin + c) * col_stride + r0 + lr] = strip[lr * g.pitch + c];
 }
 
+// 64-row strips up to 96 columns, 32-row strips beyond
+static bool strip_rows32(uint32_t n_cols) { return n_cols > (uint32_t)STRIP_MAX_COLS; }
+
 static StripGeom strip_geom(uint32_t n_cols) {
+    const uint32_t max_cols = strip_rows32(n_cols) ? STRIP_MAX_COLS32 : STRIP_MAX_COLS;
     StripGeom g;
     g.n_cols = n_cols;
-    g.n_chunks = (n_cols + STRIP_MAX_COLS - 1) / STRIP_MAX_COLS;
+    g.n_chunks = (n_cols + max_cols - 1) / max_cols;
     g.chunk = (n_cols + g.n_chunks - 1) / g.n_chunks;
     g.n_chunks = (n_cols + g.chunk - 1) / g.chunk;
     g.pitch = g.chunk | 1;
     const uint32_t last = n_cols - (g.n_chunks - 1) * g.chunk;
-    g.magic = (uint32_t)(0x100000000ull / g.chunk) + 1;  // exact for f * count < 2^32; f < 64 * 129
+    g.magic = (uint32_t)(0x100000000ull / g.chunk) + 1;  // exact for f * count < 2^32; f < 64 * 193
     g.magic_last = (uint32_t)(0x100000000ull / last) + 1;
     return g;
 }
@@ -551,8 +561,12 @@ hipError_t transpose_to_column_major(const uint64_t *rows, uint64_t *cols, uint3
     if (n_cols == 0 || n_rows == 0) return hipSuccess;
     if (strips_enabled()) {
         const StripGeom g = strip_geom(n_cols);
-        hipLaunchKernelGGL(transpose_strip_back_kernel, dim3(grid_for(n_rows, STRIP_ROWS), g.n_chunks), dim3(256), (size_t)STRIP_ROWS * g.pitch * 8, stream, rows,
-                           cols, n_rows, col_stride, g);
+        if (strip_rows32(n_cols))
+            hipLaunchKernelGGL(transpose_strip_back_kernel<32>, dim3(grid_for(n_rows, 32), g.n_chunks), dim3(256), (size_t)32 * g.pitch * 8, stream, rows, cols,
+                               n_rows, col_stride, g);
+        else
+            hipLaunchKernelGGL(transpose_strip_back_kernel<64>, dim3(grid_for(n_rows, 64), g.n_chunks), dim3(256), (size_t)64 * g.pitch * 8, stream, rows, cols,
+                               n_rows, col_stride, g);
         return hipGetLastError();
     }
     dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
@@ -565,8 +579,12 @@ hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_
     if (n_cols == 0 || n_rows == 0) return hipSuccess;
     if (strips_enabled()) {
         const StripGeom g = strip_geom(n_cols);
-        hipLaunchKernelGGL(transpose_strip_kernel, dim3(grid_for(n_rows, STRIP_ROWS), g.n_chunks), dim3(256), (size_t)STRIP_ROWS * g.pitch * 8, stream, cols, rows,
-                           n_rows, col_stride, g);
+        if (strip_rows32(n_cols))
+            hipLaunchKernelGGL(transpose_strip_kernel<32>, dim3(grid_for(n_rows, 32), g.n_chunks), dim3(256), (size_t)32 * g.pitch * 8, stream, cols, rows, n_rows,
+                               col_stride, g);
+        else
+            hipLaunchKernelGGL(transpose_strip_kernel<64>, dim3(grid_for(n_rows, 64), g.n_chunks), dim3(256), (size_t)64 * g.pitch * 8, stream, cols, rows, n_rows,
+                               col_stride, g);
         return hipGetLastError();
     }
     dim3 grid(grid_for(n_rows, TP), grid_for(n_cols, TP));
