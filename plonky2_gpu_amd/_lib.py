@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplonky2_hip.so")
+# PLONKY2_HIP_LIBRARY=<path>: load another build of the library (diagnostic builds, A/B measurements); no fallback either way
+LIB_PATH = os.environ.get("PLONKY2_HIP_LIBRARY") or os.path.join(_HERE, "libplonky2_hip.so")
 
 
 class GlError(ctypes.Structure):

@@ -6,7 +6,7 @@ timeout 900 python3 -m pytest tests/test_gpu_ntt.py tests/test_golden.py -x -q -
 echo "tests rc=$?" >> $O/tests.log; tail -n 4 $O/tests.log
 V=$GRAFT_REPO_ROOT/gpurun_in/ntt_variants
 for rep in 1 2 3; do
-TAG=base PLONKY2_LIB=$V/BASE/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
+TAG=base PLONKY2_HIP_LIBRARY=$V/BASE/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
 TAG=new python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
 done
 cat $O/ab.jsonl

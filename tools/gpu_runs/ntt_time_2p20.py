@@ -1,9 +1,7 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
-from plonky2_gpu_amd import _lib
-if os.environ.get("PLONKY2_LIB"):
-    _lib.LIB_PATH = os.environ["PLONKY2_LIB"]
+from plonky2_gpu_amd import _lib  # PLONKY2_HIP_LIBRARY=<path> selects another build
 import plonky2_gpu_amd as pg
 ctx = pg.Context(0)
 log_n, batch = 20, 64

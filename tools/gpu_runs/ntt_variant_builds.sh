@@ -19,8 +19,8 @@ fi
 O=gpurun_out/ntt_variants; mkdir -p $O; rm -f $O/ab.jsonl
 for rep in 1 2; do
     TAG=product python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
-    TAG=skeleton PLONKY2_LIB=$V/SKELETON/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
-    TAG=skeleton PLONKY2_NTT_WG_PER_CU=1 PLONKY2_LIB=$V/SKELETON/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
+    TAG=skeleton PLONKY2_HIP_LIBRARY=$V/SKELETON/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
+    TAG=skeleton PLONKY2_NTT_WG_PER_CU=1 PLONKY2_HIP_LIBRARY=$V/SKELETON/libplonky2_hip.so python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
     TAG=product PLONKY2_NTT_WG_PER_CU=1 python3 tools/gpu_runs/ntt_time_2p20.py >> $O/ab.jsonl 2>&1
 done
 cat $O/ab.jsonl
