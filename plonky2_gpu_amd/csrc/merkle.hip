@@ -315,6 +315,12 @@ struct StripGeom {
     uint32_t magic, magic_last;               // floor(2^32 / count) + 1 for a full and for the last strip: f / count = (f * magic) >> 32
 };
 
+// f / count for f < 64 * 193. count == 1 has no 32-bit reciprocal (2^32 / 1 does not fit; the truncated magic would be 1 and
+// every quotient 0): the quotient is f itself.
+__device__ __forceinline__ uint32_t strip_div(uint32_t f, uint32_t count, uint32_t magic) {
+    return count == 1 ? f : (uint32_t)(((uint64_t)f * magic) >> 32);
+}
+
 __device__ __forceinline__ void strip_range(const StripGeom &g, uint32_t &c_begin, uint32_t &c_count, uint32_t &magic) {
     c_begin = blockIdx.y * g.chunk;
     const bool last = g.n_cols - c_begin < g.chunk;
@@ -351,10 +357,10 @@ __global__ __launch_bounds__(256) void transpose_strip_kernel(const uint64_t *__
     // (ROWS is even and r0 a multiple of it), whatever the parity of the column count: the two elements of a piece may sit
     // in different rows.
     const uint32_t total = ROWS * c_count;
-    if (c_count == g.n_cols && r0 + ROWS <= n_rows) {
+    if (c_count == g.n_cols && r0 + ROWS <= n_rows && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {  // an 8-byte aligned matrix takes the scalar path
         u64x2 *out = reinterpret_cast<u64x2 *>(rows + r0 * g.n_cols);
         for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
-            const uint32_t f = 2 * q, ra = (uint32_t)(((uint64_t)f * magic) >> 32), ca = f - ra * c_count;
+            const uint32_t f = 2 * q, ra = strip_div(f, c_count, magic), ca = f - ra * c_count;
             const uint32_t rb = ca + 1 == c_count ? ra + 1 : ra, cb = ca + 1 == c_count ? 0 : ca + 1;
             u64x2 t;
             t.x = strip[ra * g.pitch + ca];
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256) void transpose_strip_kernel(const uint64_t *__
         }
     } else {
         for (uint32_t f = threadIdx.x; f < total; f += 256) {
-            const uint32_t r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            const uint32_t r = strip_div(f, c_count, magic), c = f - r * c_count;
             if (r0 + r < n_rows) rows[(r0 + r) * g.n_cols + c_begin + c] = strip[r * g.pitch + c];
         }
     }
@@ -379,10 +385,10 @@ __global__ __launch_bounds__(256) void transpose_strip_back_kernel(const uint64_
     uint32_t c_begin, c_count, magic;
     strip_range(g, c_begin, c_count, magic);
     const uint32_t total = ROWS * c_count;
-    if (c_count == g.n_cols && r0 + ROWS <= n_rows) {
+    if (c_count == g.n_cols && r0 + ROWS <= n_rows && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {  // an 8-byte aligned matrix takes the scalar path
         const u64x2 *in = reinterpret_cast<const u64x2 *>(rows + r0 * g.n_cols);
         for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
-            const uint32_t f = 2 * q, ra = (uint32_t)(((uint64_t)f * magic) >> 32), ca = f - ra * c_count;
+            const uint32_t f = 2 * q, ra = strip_div(f, c_count, magic), ca = f - ra * c_count;
             const uint32_t rb = ca + 1 == c_count ? ra + 1 : ra, cb = ca + 1 == c_count ? 0 : ca + 1;
             const u64x2 t = in[q];
             strip[ra * g.pitch + ca] = t.x;
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void transpose_strip_back_kernel(const uint64_
         }
     } else {
         for (uint32_t f = threadIdx.x; f < total; f += 256) {
-            const uint32_t r = (uint32_t)(((uint64_t)f * magic) >> 32), c = f - r * c_count;
+            const uint32_t r = strip_div(f, c_count, magic), c = f - r * c_count;
             if (r0 + r < n_rows) strip[r * g.pitch + c] = rows[(r0 + r) * g.n_cols + c_begin + c];
         }
     }

@@ -32,8 +32,11 @@
 #include <type_traits>
 
 #include "gl_field.h"
+#include "ntt_kernels.h"
 
 namespace plonky2_hip {
+
+using namespace nttk;
 
 namespace {
 
@@ -42,110 +45,6 @@ constexpr int LOGE = 13;           // tile = 8192 elements
 constexpr int E = 1 << LOGE;
 constexpr int LDS_DATA = E + E / 16;  // padded tile
 
-enum : uint32_t { F_LOAD_ROWS = 1, F_STORE_ROWS = 2, F_NATURAL = 4, F_INVERSE = 8, F_COSET = 16,
-                  F_WIDE = 32,
-                  F_RAW_OUT = 64 };  // the pass feeds another pass: its output need not be canonical (any u64 representative is a legal input)  // F_WIDE: the planner laid the pass out for tiles of 2^(LOGE+1) elements (ntt_pass_wave_kernel, LOGW = 4)
-
-struct PassParams {
-    const uint64_t *src;
-    uint64_t *dst;
-    const uint64_t *twl;  // w_{2^24}^e, e < 4096
-    const uint64_t *twh;  // w_{2^12}^e, e < 4096
-    const uint64_t *cs_hi;  // coset scale tables (F_COSET): s_r^(e<<10), per coset r
-    const uint64_t *cs_lo;  // s_r^e, e < 1024
-    uint64_t in_sa, in_sb, in_sz, in_t, in_m;
-    uint64_t out_sa, out_sb, out_sz, out_t, out_m;
-    uint64_t scale;      // multiplied into every output (1 = none)
-    uint64_t chain_scale;  // folded into the inter-pass twiddle chain start (1 = none): n^-1 of the inverse
-    uint32_t logt;       // log2 T
-    uint32_t t_limit;    // valid range of b*T + t
-    uint32_t flags;
-    uint32_t log_n;      // polynomial length (index flip for the inverse)
-    uint32_t tw_hi;      // inter-pass twiddle root = w_{2^tw_hi}
-    uint32_t cs_hi_len;  // entries per coset in cs_hi
-    uint32_t rate_bits;  // F_COSET: blockIdx.z = coset r, written to block bitrev(r)
-    uint64_t *stamps;    // diagnostic builds only (-DPLONKY2_NTT_STAMPS): per-phase cycle totals, see tools/ntt_stamps.py
-    uint32_t row_shift;  // inverse natural-order row pass: rotate the row tile by one so that the
-                         // flipped 64-byte output segments are aligned (t_limit is a power of two)
-};
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-constexpr int brev_c(int x, int bits) {
-    int r = 0;
-    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
-    return r;
-}
-
-__device__ __forceinline__ uint32_t brev_rt(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
-
-__device__ __forceinline__ uint32_t phys(uint32_t idx, uint32_t logt) { return idx + ((idx >> (4 + logt)) << logt); }
-
-// w_{2^hi}^x through the two-level table of w_{2^24}
-__device__ __forceinline__ uint64_t wpow(const PassParams &p, uint64_t x) {
-    uint32_t e = (uint32_t)(x << (24 - p.tw_hi)) & 0xFFFFFFu;
-    uint64_t h = p.twh[e >> 12];
-    uint32_t lo = e & 4095u;
-    return lo ? gl::mul(h, p.twl[lo]) : h;
-}
-
-// Inter-pass twiddle of the thread that holds, after the pass's last radix-16 round, the outputs
-// k1 = bitrev4(i)*(R/16) + kr of column L: w^(L*k1) = c * step^bitrev4(i) with c = w^(L*kr) (times the coset power
-// s_r^L and the inverse's 1/n where they apply) and step = w^(L*R/16). Four table look-ups in global memory.
-template <int LOGT, int LOGR>
-__device__ __forceinline__ void twiddle_chain(const PassParams &p, uint32_t tid, uint32_t b, uint32_t z, uint64_t &c, uint64_t &step) {
-    constexpr uint32_t TMASK = (1u << LOGT) - 1;
-    uint32_t l = tid & TMASK, rest = tid >> LOGT;
-    uint64_t L = (uint64_t)b * (1u << LOGT) + l;
-    uint32_t kr = brev_rt(rest, LOGR - 4);
-    c = wpow(p, L * kr);
-    if (p.flags & F_COSET) {
-        // fold s_r^L (coset shift power of the low index) into the chain start
-        uint64_t sl = gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(L >> 10)], p.cs_lo[z * 1024 + (uint32_t)(L & 1023)]);
-        c = gl::mul(c, sl);
-    }
-    if (p.chain_scale != 1) c = gl::mul(c, p.chain_scale);
-    step = wpow(p, L << (LOGR - 4));
-}
-
-// In-register radix-2^D DIF butterfly on v[BASE .. BASE+2^D): output slot i holds frequency
-// bitrev_D(i). Stage twiddles w_{2^(s+1)}^j = 2^(39*j*(32>>s)) are multiply-free.
-template <int D, int BASE>
-__device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
-    static_for<0, D>([&](auto S_) {
-        constexpr int s = D - 1 - decltype(S_)::value;
-        constexpr int half = 1 << s;
-        constexpr int NB = (1 << D) / 2;
-        if constexpr (NB >= 2) {
-            // butterflies in pairs through the interleaved carry-chain primitive (gl::bfly2)
-            static_for<0, NB / 2>([&](auto B_) {
-                constexpr int b0 = 2 * decltype(B_)::value, b1 = b0 + 1;
-                constexpr int i00 = BASE + (b0 / half) * 2 * half + (b0 % half), i01 = i00 + half;
-                constexpr int i10 = BASE + (b1 / half) * 2 * half + (b1 % half), i11 = i10 + half;
-                constexpr int K0 = (39 * (b0 % half) * (32 >> s)) % 192, K1 = (39 * (b1 % half) * (32 >> s)) % 192;
-                // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by
-                // swapping the operands of the subtraction instead of negating the product.
-                uint64_t s0, d0, s1, d1;
-                gl::bfly2<(K0 >= 96), (K1 >= 96)>(v[i00], v[i01], v[i10], v[i11], s0, d0, s1, d1);
-                v[i00] = s0;
-                v[i10] = s1;
-                v[i01] = gl::mul_pow2<(K0 >= 96 ? K0 - 96 : K0)>(d0);
-                v[i11] = gl::mul_pow2<(K1 >= 96 ? K1 - 96 : K1)>(d1);
-            });
-        } else {
-            uint64_t a = v[BASE], c = v[BASE + 1];
-            v[BASE] = gl::add(a, c);
-            v[BASE + 1] = gl::sub(a, c);
-        }
-    });
-}
-
 // One radix round over the digit occupying bits [SH, SH+D) of the LDS row index m.
 // LOGT = LOGE - LOGR is a compile-time constant, and the padded LDS address of element i of a
 // group is (group base) + i * (compile-time stride): bits [SH, SH+D) of m are zero in the base, so
@@ -153,20 +52,6 @@ __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
 // of the round uses one base VGPR and an immediate offset.
 // The tile the round works on has 2^LOGE_ elements and NT_ = 2^LOGE_ / 16 threads: the whole workgroup's tile
 // (NT_ = NT = 512) or one wavefront's private tile (NT_ = 64), see ntt_pass_wave_kernel.
-template <int NT_>
-__device__ __forceinline__ void tile_sync() {
-    if constexpr (NT_ == 64) {
-        // One wavefront owns the tile. The LDS executes a wavefront's operations in program order, so a later
-        // ds_read of another lane's slot sees the earlier ds_write without any wait; what is needed is only that the
-        // compiler keeps the program order of the accesses (it must: the indices may alias) and does not schedule
-        // across this point.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    } else {
-        __syncthreads();
-    }
-}
-
 template <int LOGE_, int NT_, int LOGR, int D, int SH, bool TWIDDLE>
 __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, const PassParams &p, uint32_t tid,
                                             uint32_t b, uint32_t z, const uint64_t *chain = nullptr) {
@@ -439,10 +324,6 @@ constexpr int WBUF = EW + EW / 16 + 2;    // padded wave buffer; the skew of 2 w
 #define STAMP(k) do { } while (0)
 #endif
 
-// Workgroup barrier that waits for this wave's LDS traffic only. __syncthreads() also drains vmcnt (hipcc puts
-// s_waitcnt vmcnt(0) in front of it), which would stall on the NEXT tile's global loads that are meant to stay in
-// flight across the whole transform of the current one.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LOGW = log2 of the wavefronts per workgroup: 3 (tile of 8192 elements, two workgroups per CU) or 4 (16384 elements, one
 // workgroup per CU): the wide tile doubles the segments of the cooperative accesses to 128 bytes — whole cache lines —
@@ -823,6 +704,15 @@ static uint64_t *ntt_stamp_buffer(int group) {
 }
 #endif
 
+// PLONKY2_NTT_DIRECT=0: the wave-tile kernels also where a direct pass exists (A/B measurements)
+static bool direct_mode() {
+    static const bool v = [] {
+        const char *e = getenv("PLONKY2_NTT_DIRECT");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 // PLONKY2_NTT_XCD=0: workgroups walk tiles w, w+G, ... instead of the XCD-aware order (A/B measurements)
 static bool xcd_map_enabled() {
     static const bool v = [] {
@@ -879,6 +769,9 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
     const bool ri = p.flags & F_LOAD_ROWS, ro = p.flags & F_STORE_ROWS;
     if constexpr (LOGR >= WIDE_MIN_LOGR) {
         if (p.flags & F_WIDE) {
+            if constexpr (TWIDDLE && LOGR >= 8 && LOGR <= 10)
+                if (!ri && !ro && direct_mode() && !(p.flags & F_COSET) && (p.flags & F_RAW_OUT) && p.scale == 1 && p.in_t == 1 && p.out_t == 1)
+                    return nttk::launch_col_direct(LOGR - 8, p, grid, stream);
             if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false, 4>(p, grid, stream);
             if constexpr (!TWIDDLE)
                 if (ri && !ro) return launch_pass_wave_mode<LOGR, false, true, false, 4>(p, grid, stream);

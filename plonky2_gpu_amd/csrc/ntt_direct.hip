@@ -1,0 +1,303 @@
+// ntt_direct.hip — the "direct" NTT passes for gfx950 (interface: ntt_kernels.h).
+//
+// ntt_pass_wave_kernel moves every element through LDS four or five times per pass (staging exchange of the load, one
+// exchange per radix round, gather exchange of the store) and synchronises its workgroup three times per tile. The passes
+// here load a tile straight into the registers of the first radix round and store it straight from the registers of the
+// last one; LDS is used only to change which index bits sit in registers:
+//
+//   column pass (R = 256 G rows, G = 1 / 2 / 4; tile = R rows x C = 64 / G adjacent columns, sixteen waves):
+//     row m = (R/16) i + 16 g + w      i = register, g = lane / C, w = wave;  column c = lane % C  (8 bytes per lane, C lanes per
+//     row segment: 128 bytes at R = 1024). Rounds: radix 16 over i (registers as loaded) -> twiddle w_R^(kA (16 g + w)) ->
+//     exchange inside the wave (g <-> kA mod G) -> radix G over g -> twiddle w_16G^(kB w), wave-uniform -> exchange ACROSS
+//     the waves (the one workgroup barrier pair of the tile) -> radix 16 over w -> inter-pass twiddle chain -> stores
+//     from registers. Output frequency k1 = kA + 16 kB + 16 G kC.
+//
+// Two LDS round trips and two barriers per tile instead of four or five and three, no per-element address arithmetic
+// (every LDS address is a per-lane base plus an immediate, every global address a per-lane offset plus a scalar base),
+// and a workgroup keeps ONE column tile b for its whole life (it walks the polynomials and cosets of that tile), so the
+// inter-pass twiddle chain of a lane is loop-invariant.
+//
+// Pipeline of a wave: the loads of tile k+1 are issued when the first rounds of tile k are done (the registers are free) and
+// land while tile k is exchanged and finished; the sixteen (twiddle multiply, store) steps that end tile k are spread through
+// the first rounds of tile k+1, so a wave issues a store every few dozen vector instructions instead of sixteen in a row,
+// and no two of the workgroup's barrier-aligned waves queue at the memory pipeline with a burst. At the loop back-edge the
+// tile's loads are the youngest vector-memory operations, which is what the compiler's counted vmcnt waits need to be exact.
+
+#include "ntt_kernels.h"
+
+namespace plonky2_hip {
+namespace nttk {
+
+namespace {
+
+__device__ __forceinline__ uint64_t lds_ld(const unsigned char *lds, uint32_t off) { return *reinterpret_cast<const uint64_t *>(lds + off); }
+__device__ __forceinline__ void lds_st(unsigned char *lds, uint32_t off, uint64_t v) { *reinterpret_cast<uint64_t *>(lds + off) = v; }
+__device__ __forceinline__ uint64_t g_ld(const uint64_t *base, uint32_t byte_off) { return *reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(base) + byte_off); }
+__device__ __forceinline__ void g_st(uint64_t *base, uint32_t byte_off, uint64_t v) { *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(base) + byte_off) = v; }
+
+template <int LOGG>
+struct ColGeom {
+    static constexpr int G = 1 << LOGG, LOGC = 6 - LOGG, C = 1 << LOGC, LOGR = 8 + LOGG, R = 1 << LOGR;
+    static constexpr uint32_t ROWB = C * 8;                            // bytes of one (kAB, w) row of the exchange image
+    static constexpr uint32_t SA = 16 * ROWB + (G >= 4 ? ROWB : 0);    // kAB stride: one pad row makes rows kAB, kAB+1 differ by 128 mod 256 bytes
+    static constexpr uint32_t XBYTES = 16 * G * SA;
+    static constexpr uint32_t TWBYTES = 16 * G * 16 * 8;               // per wave: w_R^(kA (16 g + w)), [g][kA]
+    static constexpr uint32_t LDS_BYTES = XBYTES + TWBYTES;
+};
+
+template <int LOGG, bool NATURAL>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_direct_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t gz, const uint32_t per_b) {
+    using GEO = ColGeom<LOGG>;
+    constexpr int G = GEO::G, LOGC = GEO::LOGC, C = GEO::C, LOGR = GEO::LOGR;
+    constexpr uint32_t ROWB = GEO::ROWB, SA = GEO::SA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char *X = ldsb;
+    unsigned char *TW = ldsb + GEO::XBYTES;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t g = lane >> LOGC, c = lane & (C - 1);
+
+    // ---- which tiles this workgroup walks -------------------------------------------------------------------------
+    const uint32_t W = gridDim.x;
+    const uint32_t u = (W & 7) == 0 ? (blockIdx.x & 7) * (W >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // workgroups of one XCD take adjacent column tiles
+    const uint32_t P = gy * gz;
+    uint32_t b0, bstep, p0, pstep;
+    if (per_b) {
+        b0 = u % gx, bstep = gx, p0 = u / gx, pstep = per_b;
+    } else {
+        b0 = u, bstep = W, p0 = 0, pstep = 1;
+    }
+    const uint32_t np_local = p0 < P ? (P - p0 + pstep - 1) / pstep : 0;
+    const uint32_t nb_local = b0 < gx ? (gx - b0 + bstep - 1) / bstep : 0;
+    const uint32_t n_tiles = np_local * nb_local;
+    if (n_tiles == 0) return;
+
+    // ---- tables ------------------------------------------------------------------------------------------------------
+    for (uint32_t e = tid; e < 16u * G * 16u; e += 1024) {
+        const uint32_t w_ = e / (16 * G), g_ = (e / 16) % G, ka = e % 16;
+        reinterpret_cast<uint64_t *>(TW)[e] = p.twh[(ka * (16 * g_ + w_)) << (12 - LOGR)];
+    }
+    uint64_t t2[G > 1 ? G : 1];  // w_16G^(kB w), wave-uniform
+    static_for<1, G>([&](auto K_) {
+        constexpr int kb = decltype(K_)::value;
+        t2[kb] = p.twh[(kb * wave) << (12 - 4 - LOGG)];
+    });
+
+    // ---- per-lane constants ------------------------------------------------------------------------------------------
+    // Everything below is a function of (lane, wave) and the same for every tile. What the first rounds use stays in registers;
+    // what is used once per tile (global offsets, the address of the exchange read) is recomputed from an opaque copy of the
+    // lane index where it is needed, so that it is not kept live through the register-hungry part of the loop.
+    const uint32_t tw_base = (wave * G + g) * 128;
+    const uint32_t lane_x = wave * ROWB + c * 8;               // this wave's slots of the exchange image: [row][wave][c]
+    const uint32_t pw_base = 16 * g * SA + lane_x;             // private exchange, written as row 16 g + kA
+    const uint32_t pr_base = g * SA + lane_x;                  // ... read back as row 16 g'' + (g + G j); also where round 2 leaves kAB = g + G j + 16 kB
+    constexpr bool natural = NATURAL;
+    auto opaque_lane = [&]() {
+        uint32_t l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    // the output block a lane finishes: rows kAB + 16 G kC, kAB = G wave + g
+    auto kab_of = [&](uint32_t l) { return G * wave + (l >> LOGC); };
+    auto xr_base_of = [&](uint32_t l) { return kab_of(l) * SA + (l & (C - 1)) * 8; };   // + w'' * ROWB
+    auto ld_off_of = [&](uint32_t l) { return (uint32_t)(((l & (C - 1)) + (uint64_t)(16 * (l >> LOGC) + wave) * p.in_m) * 8); };
+    // row of frequency k1 = kAB + 16 G kC in the output: k1 itself, or its bit reversal when the transform runs in place
+    auto st_off_of = [&](uint32_t l) {
+        const uint32_t kab = kab_of(l);
+        const uint32_t out_row_lane = natural ? kab : (brev_rt(kab & 15, 4) << (LOGR - 4)) | (brev_rt(kab >> 4, LOGG) << 4);
+        return (uint32_t)(((l & (C - 1)) + (uint64_t)out_row_lane * p.out_m) * 8);
+    };
+
+    auto tile_of = [&](uint32_t t, uint32_t &b, uint32_t &a, uint32_t &z) {
+        const uint32_t bi = t / np_local, pi = t - bi * np_local;
+        b = b0 + bi * bstep;
+        const uint32_t pp = p0 + pi * pstep;
+        a = pp % gy;
+        z = pp / gy;
+    };
+
+    uint64_t A[16];   // tile in flight / first rounds
+    const uint32_t ld_step = (uint32_t)(((uint64_t)p.in_m << (LOGR - 4)) * 8);   // register i holds row (R/16) i + ...
+    auto issue_loads = [&](uint32_t t) {
+        uint32_t b, a, z;
+        tile_of(t, b, a, z);
+        const uint64_t *base = p.src + (a * p.in_sa + b * p.in_sb + z * p.in_sz);
+        uint32_t off = ld_off_of(opaque_lane());  // tile-invariant, like the sixteen offsets derived from it: left to itself the compiler keeps them all in registers
+        static_for<0, 16>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            A[i] = g_ld(base, off);
+            if constexpr (i < 15) off += ld_step;
+        });
+    };
+
+    uint64_t B[16];   // tile being finished: sixteen w for one (kAB, c)
+    uint64_t cc0 = 1, cstep = 1;   // inter-pass twiddle chain of this lane: w^(L kAB) (times 1/n, coset power), w^(L 16 G)
+    uint32_t chain_b = 0xFFFFFFFFu;
+    const uint32_t st_row = (uint32_t)(p.out_m * 8);
+
+    // One step of the end of tile `t`: output kC = j gets its inter-pass twiddle and is stored.
+    uint64_t cc = 1;
+    uint64_t *obase = p.dst;
+    uint32_t so = 0;
+    auto tail_begin = [&](uint32_t k) {
+        uint32_t b, a, z;
+        tile_of(k, b, a, z);
+        if (b != chain_b) {
+            chain_b = b;
+            const uint32_t l = opaque_lane();
+            const uint64_t L = (uint64_t)b * C + (l & (C - 1));
+            cc0 = wpow(p, L * kab_of(l));
+            if (p.chain_scale != 1) cc0 = gl::mul(cc0, p.chain_scale);
+            cstep = wpow(p, L << (4 + LOGG));
+            // the look-ups are complete when this block ends: at the join below the compiler would otherwise wait for "possibly
+            // pending" loads with vmcnt(0) in every iteration, which also waits for the prefetched tile
+            asm volatile("" : "+v"(cc0), "+v"(cstep));
+        }
+        obase = p.dst + (a * p.out_sa + b * p.out_sb + z * p.out_sz);
+        cc = cc0;
+        so = st_off_of(opaque_lane());
+    };
+    auto tail_unit = [&](auto J_) {
+        constexpr int j = decltype(J_)::value;   // kC
+        constexpr int s3 = brev_c(j, 4);
+        B[s3] = gl::mul(B[s3], cc);
+        if constexpr (j < 15) cc = gl::mul(cc, cstep);
+        const uint32_t row = natural ? (uint32_t)(j << (4 + LOGG)) : (uint32_t)s3;
+        g_st(obase, so + row * st_row, B[s3]);   // unconditional: a branch here would make the compiler forget how many stores are pending
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tail_units = [&](auto LO_, auto HI_) {
+        static_for<decltype(LO_)::value, decltype(HI_)::value>([&](auto J_) { tail_unit(J_); });
+    };
+
+    // first rounds of the tile whose elements are in A: radix 16 over i, twiddle, exchange inside the wave, radix G over g,
+    // twiddle, and the results into the exchange image; the sixteen tail steps of the previous tile are spread through it
+    auto first_rounds = [&](auto WITH_TAIL_) {
+        constexpr bool with_tail = decltype(WITH_TAIL_)::value;   // false: the prologue, nothing to finish
+#define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
+        TAIL(0, 4);   // four results leave before the butterflies need their temporaries
+        radix_dif_stage<4, 0, 3>(A);
+        TAIL(4, 6);
+        radix_dif_stage<4, 0, 2>(A);
+        TAIL(6, 8);
+        radix_dif_stage<4, 0, 1>(A);
+        TAIL(8, 10);
+        radix_dif_stage<4, 0, 0>(A);
+        TAIL(10, 12);
+        static_for<1, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int ka = brev_c(s, 4);
+            A[s] = gl::mul(A[s], lds_ld(TW, tw_base + ka * 8));
+            if constexpr (s == 5) TAIL(12, 13);
+            if constexpr (s == 10) TAIL(13, 14);
+        });
+        if constexpr (G > 1) {
+            static_for<0, 16>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                constexpr int ka = brev_c(s, 4);
+                lds_st(X, pw_base + ka * SA, A[s]);
+            });
+            tile_sync<64>();
+            static_for<0, 16 / G>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                static_for<0, G>([&](auto GG_) {
+                    constexpr int gg = decltype(GG_)::value;
+                    A[j * G + gg] = lds_ld(X, pr_base + (16 * gg + G * j) * SA);
+                });
+            });
+            tile_sync<64>();
+            static_for<0, 16 / G>([&](auto J_) { radix_dif<LOGG, decltype(J_)::value * G>(A); });
+            TAIL(14, 15);
+            static_for<0, 16 / G>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                static_for<0, G>([&](auto S_) {
+                    constexpr int s2 = decltype(S_)::value;
+                    constexpr int kb = brev_c(s2, LOGG);
+                    uint64_t val = A[j * G + s2];
+                    if constexpr (kb != 0) val = gl::mul(val, t2[kb]);
+                    lds_st(X, pr_base + (G * j + 16 * kb) * SA, val);
+                });
+            });
+            TAIL(15, 16);
+        } else {
+            TAIL(14, 16);
+            static_for<0, 16>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                constexpr int ka = brev_c(s, 4);
+                lds_st(X, pr_base + ka * SA, A[s]);
+            });
+        }
+#undef TAIL
+    };
+
+    // ---- pipeline ---------------------------------------------------------------------------------------------------
+    // Iteration k: the exchange image of tile k is read (two barriers), its radix 16 over w is done, and its tail runs inside the
+    // first rounds of tile k+1.
+    lds_barrier();  // tables
+    issue_loads(0);
+    const uint32_t last = n_tiles - 1;
+    first_rounds(std::false_type{});
+    if (last > 0) issue_loads(1);
+#pragma unroll 1
+    for (uint32_t k = 0; k <= last; k++) {
+        lds_barrier();  // image of tile k complete
+        const uint32_t xr_base = xr_base_of(opaque_lane());
+        static_for<0, 16>([&](auto WR_) {
+            constexpr int wr = decltype(WR_)::value;
+            B[wr] = lds_ld(X, xr_base + wr * ROWB);
+        });
+        lds_barrier();  // everyone has read it: the slots may be rewritten
+        radix_dif<4, 0>(B);
+        tail_begin(k);
+        if (k < last) {
+            first_rounds(std::true_type{});
+            if (k + 1 < last) issue_loads(k + 2);
+        } else {
+            tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+        }
+    }
+}
+
+template <int LOGG, bool NATURAL>
+hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
+    using GEO = ColGeom<LOGG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t pairs = (uint64_t)grid.y * grid.z, total = pairs * grid.x;
+    if (total == 0) return hipSuccess;
+    if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    // one workgroup per CU (the exchange image is 128 KiB + pad); a workgroup keeps one column tile when there are no more
+    // column tiles than CUs, and then the polynomials and cosets are dealt to the cus / grid.x workgroups of that tile
+    uint32_t per_b = 0, wgs;
+    if (grid.x <= (uint32_t)cus) {
+        per_b = (uint32_t)cus / grid.x;
+        if (per_b > pairs) per_b = (uint32_t)pairs;
+        wgs = grid.x * per_b;
+    } else {
+        wgs = (uint32_t)cus;
+    }
+    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL>), dim3(wgs), dim3(1024), GEO::LDS_BYTES, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream) {
+    const bool nat = p.flags & F_NATURAL;
+    switch (logg) {
+        case 0: return nat ? launch_col_direct_t<0, true>(p, grid, stream) : launch_col_direct_t<0, false>(p, grid, stream);
+        case 1: return nat ? launch_col_direct_t<1, true>(p, grid, stream) : launch_col_direct_t<1, false>(p, grid, stream);
+        case 2: return nat ? launch_col_direct_t<2, true>(p, grid, stream) : launch_col_direct_t<2, false>(p, grid, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace nttk
+}  // namespace plonky2_hip

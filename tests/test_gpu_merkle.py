@@ -311,7 +311,7 @@ def test_commit_at_the_full_benchmark_size(gpu, oracle):
         assert (a.merkle_tree.d_digests.download(4 * slot, 4) == b.merkle_tree.d_digests.download(4 * slot, 4)).all(), slot
 
 
-@pytest.mark.parametrize("n_cols,n_rows", [(1, 64), (7, 1000), (64, 4096), (96, 640), (97, 641), (135, 8192), (234, 2048), (300, 129), (20, 1 << 16)])
+@pytest.mark.parametrize("n_cols,n_rows", [(1, 64), (1, 10), (1, 65), (2, 10), (7, 1000), (64, 4096), (96, 640), (97, 641), (135, 8192), (234, 2048), (300, 129), (20, 1 << 16)])
 @pytest.mark.parametrize("kernel", ["strip", "tile"])
 def test_leaf_major_copy_and_back(gpu, n_cols, n_rows, kernel):
     """gl_transpose (column-major -> leaf-major; plonky2/src/util/mod.rs:23-53 `transpose`) for whole and ragged strips, one and several
@@ -330,9 +330,11 @@ ctx = pg.Context(0)
 n_cols, n_rows = {n_cols}, {n_rows}
 stride = n_rows + 24
 host = np.random.default_rng(n_cols * 7 + n_rows).integers(0, pg.P, size=(n_cols, stride), dtype=np.uint64)
-d_c = pg.DeviceBuffer.from_host(ctx, host); d_r = pg.DeviceBuffer(ctx, n_cols * n_rows + 8)
+guard = np.full(n_cols * n_rows + 128, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+d_c = pg.DeviceBuffer.from_host(ctx, host); d_r = pg.DeviceBuffer.from_host(ctx, guard)
 _lib.call("gl_transpose", d_c.ptr, d_r.ptr, n_cols, n_rows, stride, ctx.ptr); ctx.synchronize()
 assert (d_r.download(0, n_rows * n_cols).reshape(n_rows, n_cols) == host[:, :n_rows].T).all()
+assert (d_r.download(n_rows * n_cols, 128) == guard[:128]).all(), "wrote past the end of the leaf-major matrix"
 print("ok")
 """
     env = dict(os.environ, PLONKY2_TRANSPOSE=kernel)
