@@ -18,7 +18,7 @@ struct NttTables {
     uint64_t *scratch = nullptr;
     uint64_t scratch_elems = 0;
 };
-constexpr uint64_t NTT_SCRATCH_ELEMS = 1ull << 24;
+constexpr uint64_t NTT_SCRATCH_ELEMS = 1ull << 26;
 
 // Per-(log_n, rate_bits, shift) coset tables: s_r = shift * w_{n<<rate_bits}^r,
 //   lo[r*1024 + e] = s_r^e (e < 1024), hi[r*hi_len + e] = s_r^(1024 e) (e < hi_len = max(n/1024, 1)).

@@ -773,6 +773,9 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
                 if (!ri && !ro && direct_mode() && !(p.flags & F_COSET) && (p.flags & F_RAW_OUT) && p.scale == 1 && p.in_t == 1 && p.out_t == 1)
                     return nttk::launch_col_direct(LOGR - 8, p, grid, stream);
             if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false, 4>(p, grid, stream);
+            if constexpr (!TWIDDLE && LOGR == 10)
+                if (ri && !ro && direct_mode() && (p.flags & F_NATURAL) && !(p.flags & F_COSET) && p.scale == 1 && p.in_m == 1 && p.out_t == 1)
+                    return nttk::launch_row_natural_direct(p, grid, stream);
             if constexpr (!TWIDDLE)
                 if (ri && !ro) return launch_pass_wave_mode<LOGR, false, true, false, 4>(p, grid, stream);
             return hipErrorInvalidValue;
@@ -930,7 +933,8 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
         // measured at 2^20 on one device: wide tiles make the column pass 6 % faster and the transposed-store row pass 4 % slower
-        const bool wideA = wide_ok(la, N2), wideB = false;
+        // the direct row pass (1024-point rows, natural order) works on tiles of sixteen rows
+        const bool wideA = wide_ok(la, N2), wideB = natural && lb == 10 && direct_mode() && wide_ok(lb, N1);
         const uint32_t logtA = LOGE + wideA - la, TA = 1u << logtA, logtB = LOGE + wideB - lb, TB = 1u << logtB;
         if (inverse && !natural) return hipErrorInvalidValue;  // bit-reversed inverse is not on the path
         if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;

@@ -287,6 +287,207 @@ hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t strea
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row pass with natural-order (transposed) output, rows of R = 1024 points; tile = 16 adjacent rows, one per wave.
+//   position j2 = 64 i + 4 h + q     i = register, (h, q) = lane: 8 bytes per lane, 512 contiguous bytes per load.
+//   radix 16 over i -> twiddle w_R^(kA lane) -> exchange inside the wave (h <-> kA) -> radix 16 over h -> twiddle
+//   w_64^(kB q) -> exchange ACROSS the waves: wave kA, lane (kBhi, row), registers (kBlo, q) -> radix 4 over q ->
+//   stores of X[k1 + N1 k2], k2 = kA + 16 kB + 256 kC: sixteen lanes = sixteen adjacent rows k1 = one 128-byte segment.
+// The exchange image is [kA][kB][q][row] with pads chosen so that every access of both exchanges is conflict-free and the
+// slots a wave writes (its row's column of the image) are also the slots of its private exchange:
+//   kA stride 8736, kB stride 544, q stride 136, row stride 8 bytes.
+// ---------------------------------------------------------------------------------------------
+struct RowGeom {
+    static constexpr uint32_t SQ = 136, SB = 544, SA = 8736;
+    static constexpr uint32_t XBYTES = 16 * SA;
+    static constexpr uint32_t TW1_STRIDE = 136, TW1_BYTES = 64 * TW1_STRIDE;   // [lane][kA]: w_1024^(kA lane)
+    static constexpr uint32_t TW2_STRIDE = 136, TW2_BYTES = 4 * TW2_STRIDE;    // [q][kB]:   w_64^(kB q)
+    static constexpr uint32_t LDS_BYTES = XBYTES + TW1_BYTES + TW2_BYTES;
+};
+
+template <bool INVERSE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_row_natural_direct_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t gz) {
+    using GEO = RowGeom;
+    constexpr uint32_t SQ = GEO::SQ, SB = GEO::SB, SA = GEO::SA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char *X = ldsb;
+    unsigned char *TW1 = ldsb + GEO::XBYTES;
+    unsigned char *TW2 = TW1 + GEO::TW1_BYTES;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const uint32_t W = gridDim.x;
+    const uint32_t u = (W & 7) == 0 ? (blockIdx.x & 7) * (W >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // workgroups of one XCD take adjacent row tiles
+    const uint32_t total = gx * gy * gz;
+    if (u >= total) return;
+    const uint32_t n_tiles = (total - u + W - 1) / W;
+
+    for (uint32_t e = tid; e < 64 * 16; e += 1024) {
+        const uint32_t l = e >> 4, ka = e & 15;
+        *reinterpret_cast<uint64_t *>(TW1 + l * GEO::TW1_STRIDE + ka * 8) = p.twh[(ka * l) << 2];
+    }
+    if (tid < 64) {
+        const uint32_t q = tid >> 4, kb = tid & 15;
+        *reinterpret_cast<uint64_t *>(TW2 + q * GEO::TW2_STRIDE + kb * 8) = p.twh[(kb * q) << 6];
+    }
+
+    // first rounds: lane = (h, q) before the private exchange, (kA', q) after it
+    const uint32_t q = lane & 3, hi4 = lane >> 2;
+    const uint32_t tw1_base = lane * GEO::TW1_STRIDE;
+    const uint32_t tw2_base = q * GEO::TW2_STRIDE;
+    const uint32_t pw_base = hi4 * SB + q * SQ + wave * 8;      // + kA * SA
+    const uint32_t pr_base = hi4 * SA + q * SQ + wave * 8;      // + h * SB; round 2 leaves (kA', kB, q) at + kB * SB
+    auto opaque_lane = [&]() {
+        uint32_t l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+
+    auto tile_of = [&](uint32_t t, uint32_t &b, uint32_t &a, uint32_t &z) {
+        const uint32_t id = u + t * W;
+        b = id % gx;
+        const uint32_t r = id / gx;
+        a = r % gy;
+        z = r / gy;
+    };
+
+    uint64_t A[16];
+    auto issue_loads = [&](uint32_t t) {
+        uint32_t b, a, z;
+        tile_of(t, b, a, z);
+        const uint32_t row = (b * 16 + wave + p.row_shift) & (p.t_limit - 1);   // inverse: the tile is rotated by one row (see ntt.hip)
+        const uint64_t *base = p.src + (a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t);
+        const uint32_t off = opaque_lane() * 8;
+        static_for<0, 16>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            A[i] = g_ld(base, off + i * 512);
+        });
+    };
+
+    uint64_t B[16];   // registers (kBlo, q) of (kA = wave, kBhi, row) = lane
+    uint64_t *obase = p.dst;
+    uint32_t o_lane = 0;   // element index inside the polynomial of this lane's outputs, before the register part
+    const uint32_t n_mask = (1u << p.log_n) - 1;
+    auto tail_begin = [&](uint32_t k) {
+        uint32_t b, a, z;
+        tile_of(k, b, a, z);
+        obase = p.dst + (a * p.out_sa + z * p.out_sz);
+        const uint32_t l = opaque_lane();
+        const uint32_t r = l & 15, kbhi = l >> 4;
+        const uint32_t k1 = (b * 16 + r + p.row_shift) & (p.t_limit - 1);
+        o_lane = k1 + (uint32_t)p.out_m * (wave + 64 * kbhi);
+    };
+    // register slot s of B: kBlo = s >> 2, and after the radix 4 over q slot (s & 3) holds kC = bitrev2(s & 3)
+    auto tail_unit = [&](auto J_) {
+        constexpr int s = decltype(J_)::value;
+        constexpr int kblo = s >> 2, kc = brev_c(s & 3, 2);
+        uint32_t o = o_lane + (uint32_t)p.out_m * (16 * kblo + 256 * kc);
+        if constexpr (INVERSE) o = (0u - o) & n_mask;   // index flip i -> n - i of the inverse transform (fft.rs:92-101)
+        g_st(obase, o * 8, gl::canon(B[s]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tail_units = [&](auto LO_, auto HI_) {
+        static_for<decltype(LO_)::value, decltype(HI_)::value>([&](auto J_) { tail_unit(J_); });
+    };
+
+    auto first_rounds = [&](auto WITH_TAIL_) {
+        constexpr bool with_tail = decltype(WITH_TAIL_)::value;
+#define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
+        TAIL(0, 3);
+        radix_dif_stage<4, 0, 3>(A);
+        TAIL(3, 5);
+        radix_dif_stage<4, 0, 2>(A);
+        TAIL(5, 6);
+        radix_dif_stage<4, 0, 1>(A);
+        TAIL(6, 7);
+        radix_dif_stage<4, 0, 0>(A);
+        TAIL(7, 8);
+        static_for<1, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int ka = brev_c(s, 4);
+            A[s] = gl::mul(A[s], lds_ld(TW1, tw1_base + ka * 8));
+            if constexpr (s == 8) TAIL(8, 9);
+        });
+        static_for<0, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int ka = brev_c(s, 4);
+            lds_st(X, pw_base + ka * SA, A[s]);
+        });
+        tile_sync<64>();
+        static_for<0, 16>([&](auto H_) {
+            constexpr int h = decltype(H_)::value;
+            A[h] = lds_ld(X, pr_base + h * SB);
+        });
+        tile_sync<64>();
+        TAIL(9, 10);
+        radix_dif_stage<4, 0, 3>(A);
+        TAIL(10, 11);
+        radix_dif_stage<4, 0, 2>(A);
+        TAIL(11, 12);
+        radix_dif_stage<4, 0, 1>(A);
+        TAIL(12, 13);
+        radix_dif_stage<4, 0, 0>(A);
+        TAIL(13, 14);
+        static_for<0, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int kb = brev_c(s, 4);
+            uint64_t val = A[s];
+            if constexpr (kb != 0) val = gl::mul(val, lds_ld(TW2, tw2_base + kb * 8));   // q = 0: the factor is 1, multiplied all the same (uniform code)
+            lds_st(X, pr_base + kb * SB, val);
+            if constexpr (s == 7) TAIL(14, 15);
+        });
+        TAIL(15, 16);
+#undef TAIL
+    };
+
+    lds_barrier();  // tables
+    issue_loads(0);
+    const uint32_t last = n_tiles - 1;
+    first_rounds(std::false_type{});
+    if (last > 0) issue_loads(1);
+#pragma unroll 1
+    for (uint32_t k = 0; k <= last; k++) {
+        lds_barrier();  // image of tile k complete
+        {
+            const uint32_t l = opaque_lane();
+            const uint32_t xr_base = wave * SA + (l >> 4) * (4 * SB) + (l & 15) * 8;
+            static_for<0, 16>([&](auto S_) {
+                constexpr int s = decltype(S_)::value;
+                B[s] = lds_ld(X, xr_base + (s >> 2) * SB + (s & 3) * SQ);
+            });
+        }
+        lds_barrier();  // everyone has read it
+        static_for<0, 4>([&](auto J_) { radix_dif<2, decltype(J_)::value * 4>(B); });
+        tail_begin(k);
+        if (k < last) {
+            first_rounds(std::true_type{});
+            if (k + 1 < last) issue_loads(k + 2);
+        } else {
+            tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+        }
+    }
+}
+
+template <bool INVERSE>
+hipError_t launch_row_natural_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_row_natural_direct_kernel<INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowGeom::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+    if (total == 0) return hipSuccess;
+    if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t wgs = (uint32_t)(total < (uint64_t)cus ? total : (uint64_t)cus);
+    hipLaunchKernelGGL((ntt_row_natural_direct_kernel<INVERSE>), dim3(wgs), dim3(1024), RowGeom::LDS_BYTES, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream) {
@@ -297,6 +498,11 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
         case 2: return nat ? launch_col_direct_t<2, true>(p, grid, stream) : launch_col_direct_t<2, false>(p, grid, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+
+hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t stream) {
+    return (p.flags & F_INVERSE) ? launch_row_natural_direct_t<true>(p, grid, stream) : launch_row_natural_direct_t<false>(p, grid, stream);
 }
 
 }  // namespace nttk

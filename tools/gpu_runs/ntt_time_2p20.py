@@ -9,14 +9,15 @@ n = 1 << log_n
 rng = np.random.default_rng(1)
 host = rng.integers(0, 0xFFFFFFFF00000001, size=(batch, n), dtype=np.uint64)
 buf = pg.DeviceBuffer.from_host(ctx, host)
+REPS = int(os.environ.get("REPS", "40"))
 def t(order, inverse=0):
     ms = []
-    for r in range(12):
+    for r in range(REPS + 2):
         e0, e1 = pg.Event(), pg.Event()
         e0.record(ctx)
         _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, inverse, order, ctx.ptr)
         e1.record(ctx)
         ctx.synchronize()
-        if r: ms.append(e1.elapsed_ms_since(e0))
-    return float(np.median(ms))
-print(json.dumps({"tag": os.environ.get("TAG"), "wg_per_cu": os.environ.get("PLONKY2_NTT_WG_PER_CU"), "direct": os.environ.get("PLONKY2_NTT_DIRECT"), "natural_ms": t(0), "inverse_ms": t(0, 1), "bitrev_ms": t(1)}), flush=True)
+        if r > 1: ms.append(e1.elapsed_ms_since(e0))
+    return round(float(np.median(ms)), 4), round(float(min(ms)), 4)
+print(json.dumps({"tag": os.environ.get("TAG"), "wg_per_cu": os.environ.get("PLONKY2_NTT_WG_PER_CU"), "direct": os.environ.get("PLONKY2_NTT_DIRECT"), "chunk": os.environ.get("PLONKY2_NTT_CHUNK_COLS"), "natural_ms": t(0), "inverse_ms": t(0, 1), "bitrev_ms": t(1), "note": "[median, min] over %d launches" % REPS}), flush=True)
