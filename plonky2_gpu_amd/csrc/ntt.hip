@@ -1012,9 +1012,12 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
     // Bit-reversed order runs all three in place; natural order keeps the intermediate in the
     // scratch workspace and lets pass 3 write X[k1 + N1*k2 + N1*N2*k3] (T adjacent k1 per segment).
     {
-        const uint32_t la = (log_n + 2) / 3, lb = (log_n - la + 1) / 2, lc = log_n - la - lb;
+        uint32_t la = (log_n + 2) / 3, lb = (log_n - la + 1) / 2, lc = log_n - la - lb;
+        // the direct column passes take 256-point columns: 2^22 = 256 x 256 x 64 instead of 256 x 128 x 128
+        if (direct_mode() && log_n == 22) la = 8, lb = 8, lc = 6;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb, N3 = 1ull << lc, N23 = N2 * N3;
-        const uint32_t logt1 = LOGE - la, T1 = 1u << logt1, logt2 = LOGE - lb, T2 = 1u << logt2, logt3 = LOGE - lc,
+        const bool wide1 = direct_mode() && wide_ok(la, N23), wide2 = direct_mode() && wide_ok(lb, N3);   // 16384-element tiles: the direct passes' geometry
+        const uint32_t logt1 = LOGE + wide1 - la, T1 = 1u << logt1, logt2 = LOGE + wide2 - lb, T2 = 1u << logt2, logt3 = LOGE - lc,
                        T3 = 1u << logt3;
         if (inverse && !natural) return hipErrorInvalidValue;
         if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
@@ -1040,7 +1043,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.out_sb = T1;
             p.out_t = 1;
             p.out_m = N23;
-            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT;
+            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT | (wide1 ? F_WIDE : 0);
             p.log_n = log_n;
             p.tw_hi = log_n;
             p.chain_scale = n_inv;
@@ -1061,7 +1064,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.out_sz = N23;
             p.out_t = 1;
             p.out_m = N3;
-            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT;
+            p.flags = (natural ? F_NATURAL : 0) | F_RAW_OUT | (wide2 ? F_WIDE : 0);
             p.log_n = log_n;
             p.tw_hi = lb + lc;
             e = dispatch_pass<true>(lb, p, dim3((unsigned)(N3 / T2), (unsigned)cnt, (unsigned)N1), stream);

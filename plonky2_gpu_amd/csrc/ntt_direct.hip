@@ -30,10 +30,63 @@ namespace nttk {
 
 namespace {
 
+// Diagnostic builds (tools/gpu_runs/ntt_direct_variants.sh; never the product, their results are wrong by design):
+//   DIRECT_DIAG_SAME_LOADS   every tile loads tile 0's addresses (served by L2)     -> what the load latency costs
+//   DIRECT_DIAG_SAME_STORES  every tile stores to tile 0's addresses                 -> what the store traffic costs
+//   DIRECT_DIAG_NO_BARRIER   the two workgroup barriers of a tile are dropped        -> what waiting for the slowest wave costs
+//   DIRECT_DIAG_TAIL_FRONT   the sixteen tail steps run before the first rounds      -> what spreading the stores buys
+#ifdef DIRECT_DIAG_NO_BARRIER
+#define DIRECT_TILE_BARRIER() tile_sync<64>()
+#else
+#define DIRECT_TILE_BARRIER() lds_barrier()
+#endif
+#ifdef DIRECT_DIAG_SAME_LOADS
+#define DIRECT_LOAD_TILE(t) 0u
+#else
+#define DIRECT_LOAD_TILE(t) (t)
+#endif
+#ifdef DIRECT_DIAG_SAME_STORES
+#define DIRECT_STORE_TILE(t) 0u
+#else
+#define DIRECT_STORE_TILE(t) (t)
+#endif
+
 __device__ __forceinline__ uint64_t lds_ld(const unsigned char *lds, uint32_t off) { return *reinterpret_cast<const uint64_t *>(lds + off); }
 __device__ __forceinline__ void lds_st(unsigned char *lds, uint32_t off, uint64_t v) { *reinterpret_cast<uint64_t *>(lds + off) = v; }
-__device__ __forceinline__ uint64_t g_ld(const uint64_t *base, uint32_t byte_off) { return *reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(base) + byte_off); }
-__device__ __forceinline__ void g_st(uint64_t *base, uint32_t byte_off, uint64_t v) { *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(base) + byte_off) = v; }
+template <bool NT = false>
+__device__ __forceinline__ uint64_t g_ld(const uint64_t *base, uint32_t byte_off) {
+    const uint64_t *q = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(base) + byte_off);
+    if constexpr (NT) return __builtin_nontemporal_load(q);
+    return *q;
+}
+template <bool NT = false>
+__device__ __forceinline__ void g_st(uint64_t *base, uint32_t byte_off, uint64_t v) {
+    uint64_t *q = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(base) + byte_off);
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, q);
+    else
+        *q = v;
+}
+#ifdef DIRECT_DIAG_NT_LOAD_COL
+constexpr bool NT_LOAD_COL = true;
+#else
+constexpr bool NT_LOAD_COL = false;
+#endif
+#ifdef DIRECT_DIAG_NT_STORE_COL
+constexpr bool NT_STORE_COL = true;
+#else
+constexpr bool NT_STORE_COL = false;
+#endif
+#ifdef DIRECT_DIAG_NT_LOAD_ROW
+constexpr bool NT_LOAD_ROW = true;
+#else
+constexpr bool NT_LOAD_ROW = false;
+#endif
+#ifdef DIRECT_DIAG_NT_STORE_ROW
+constexpr bool NT_STORE_ROW = true;
+#else
+constexpr bool NT_STORE_ROW = false;
+#endif
 
 template <int LOGG>
 struct ColGeom {
@@ -121,12 +174,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const uint32_t ld_step = (uint32_t)(((uint64_t)p.in_m << (LOGR - 4)) * 8);   // register i holds row (R/16) i + ...
     auto issue_loads = [&](uint32_t t) {
         uint32_t b, a, z;
-        tile_of(t, b, a, z);
+        tile_of(DIRECT_LOAD_TILE(t), b, a, z);
         const uint64_t *base = p.src + (a * p.in_sa + b * p.in_sb + z * p.in_sz);
         uint32_t off = ld_off_of(opaque_lane());  // tile-invariant, like the sixteen offsets derived from it: left to itself the compiler keeps them all in registers
         static_for<0, 16>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
-            A[i] = g_ld(base, off);
+            A[i] = g_ld<NT_LOAD_COL>(base, off);
             if constexpr (i < 15) off += ld_step;
         });
     };
@@ -154,6 +207,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // pending" loads with vmcnt(0) in every iteration, which also waits for the prefetched tile
             asm volatile("" : "+v"(cc0), "+v"(cstep));
         }
+#ifdef DIRECT_DIAG_SAME_STORES
+        tile_of(0, b, a, z);
+#endif
         obase = p.dst + (a * p.out_sa + b * p.out_sb + z * p.out_sz);
         cc = cc0;
         so = st_off_of(opaque_lane());
@@ -164,7 +220,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         B[s3] = gl::mul(B[s3], cc);
         if constexpr (j < 15) cc = gl::mul(cc, cstep);
         const uint32_t row = natural ? (uint32_t)(j << (4 + LOGG)) : (uint32_t)s3;
-        g_st(obase, so + row * st_row, B[s3]);   // unconditional: a branch here would make the compiler forget how many stores are pending
+        g_st<NT_STORE_COL>(obase, so + row * st_row, B[s3]);   // unconditional: a branch here would make the compiler forget how many stores are pending
         __builtin_amdgcn_sched_barrier(0);
     };
     auto tail_units = [&](auto LO_, auto HI_) {
@@ -175,7 +231,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // twiddle, and the results into the exchange image; the sixteen tail steps of the previous tile are spread through it
     auto first_rounds = [&](auto WITH_TAIL_) {
         constexpr bool with_tail = decltype(WITH_TAIL_)::value;   // false: the prologue, nothing to finish
+#ifdef DIRECT_DIAG_TAIL_FRONT
+        if constexpr (with_tail) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+#define TAIL(lo, hi) do { } while (0)
+#else
 #define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
+#endif
         TAIL(0, 4);   // four results leave before the butterflies need their temporaries
         radix_dif_stage<4, 0, 3>(A);
         TAIL(4, 6);
@@ -241,13 +302,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (last > 0) issue_loads(1);
 #pragma unroll 1
     for (uint32_t k = 0; k <= last; k++) {
-        lds_barrier();  // image of tile k complete
+        DIRECT_TILE_BARRIER();  // image of tile k complete
         const uint32_t xr_base = xr_base_of(opaque_lane());
         static_for<0, 16>([&](auto WR_) {
             constexpr int wr = decltype(WR_)::value;
             B[wr] = lds_ld(X, xr_base + wr * ROWB);
         });
-        lds_barrier();  // everyone has read it: the slots may be rewritten
+        DIRECT_TILE_BARRIER();  // everyone has read it: the slots may be rewritten
         radix_dif<4, 0>(B);
         tail_begin(k);
         if (k < last) {
@@ -356,13 +417,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     uint64_t A[16];
     auto issue_loads = [&](uint32_t t) {
         uint32_t b, a, z;
-        tile_of(t, b, a, z);
+        tile_of(DIRECT_LOAD_TILE(t), b, a, z);
         const uint32_t row = (b * 16 + wave + p.row_shift) & (p.t_limit - 1);   // inverse: the tile is rotated by one row (see ntt.hip)
         const uint64_t *base = p.src + (a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t);
         const uint32_t off = opaque_lane() * 8;
         static_for<0, 16>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
-            A[i] = g_ld(base, off + i * 512);
+            A[i] = g_ld<NT_LOAD_ROW>(base, off + i * 512);
         });
     };
 
@@ -372,7 +433,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const uint32_t n_mask = (1u << p.log_n) - 1;
     auto tail_begin = [&](uint32_t k) {
         uint32_t b, a, z;
-        tile_of(k, b, a, z);
+        tile_of(DIRECT_STORE_TILE(k), b, a, z);
         obase = p.dst + (a * p.out_sa + z * p.out_sz);
         const uint32_t l = opaque_lane();
         const uint32_t r = l & 15, kbhi = l >> 4;
@@ -385,7 +446,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         constexpr int kblo = s >> 2, kc = brev_c(s & 3, 2);
         uint32_t o = o_lane + (uint32_t)p.out_m * (16 * kblo + 256 * kc);
         if constexpr (INVERSE) o = (0u - o) & n_mask;   // index flip i -> n - i of the inverse transform (fft.rs:92-101)
-        g_st(obase, o * 8, gl::canon(B[s]));
+        g_st<NT_STORE_ROW>(obase, o * 8, gl::canon(B[s]));
         __builtin_amdgcn_sched_barrier(0);
     };
     auto tail_units = [&](auto LO_, auto HI_) {
@@ -394,7 +455,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     auto first_rounds = [&](auto WITH_TAIL_) {
         constexpr bool with_tail = decltype(WITH_TAIL_)::value;
+#ifdef DIRECT_DIAG_TAIL_FRONT
+        if constexpr (with_tail) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+#define TAIL(lo, hi) do { } while (0)
+#else
 #define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
+#endif
         TAIL(0, 3);
         radix_dif_stage<4, 0, 3>(A);
         TAIL(3, 5);
@@ -449,7 +515,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     if (last > 0) issue_loads(1);
 #pragma unroll 1
     for (uint32_t k = 0; k <= last; k++) {
-        lds_barrier();  // image of tile k complete
+        DIRECT_TILE_BARRIER();  // image of tile k complete
         {
             const uint32_t l = opaque_lane();
             const uint32_t xr_base = wave * SA + (l >> 4) * (4 * SB) + (l & 15) * 8;
@@ -458,7 +524,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 B[s] = lds_ld(X, xr_base + (s >> 2) * SB + (s & 3) * SQ);
             });
         }
-        lds_barrier();  // everyone has read it
+        DIRECT_TILE_BARRIER();  // everyone has read it
         static_for<0, 4>([&](auto J_) { radix_dif<2, decltype(J_)::value * 4>(B); });
         tail_begin(k);
         if (k < last) {
