@@ -38,6 +38,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a copy kernel reaches is measured in the run
 LOG_N = 20
 BATCH = 64
+MIN_REGION_S = 0.5  # the timed region lasts at least this long (28 ms windows on devices that differ by 9 %)
+WINDOWS = 5         # further windows of the same size after the timed one: median / min / max are reported beside `value`
 
 
 def parse():
@@ -45,6 +47,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=0, help="forward + inverse pairs per step (0 = as many as make the timed region >= 0.5 s)")
+    ap.add_argument("--windows", type=int, default=WINDOWS, help="repeats of the timed region reported as value_windows")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-commit", action="store_true", help="skip the configs[2] commit measurement")
@@ -61,41 +65,57 @@ def parse():
 def cpu_baseline(log_n):
     """The oracle's fft/ifft (port of fft.rs:73-229) on a bounded sample, clocked inside C around the parallel region
     (oracle/gl_oracle.c glo_fft_bench): the root table is built before the clock starts — the reference builds
-    fft_root_table once per circuit (circuit_builder.rs:849-851) — and every thread transforms columns it allocated and
-    filled itself (first touch on its own NUMA node), one column per task as the reference's rayon split (oracle.rs:720)."""
+    fft_root_table once per circuit (circuit_builder.rs:849-851) — every thread is pinned to a core of its own, transforms
+    columns it allocated and filled itself (first touch on its own NUMA node) and reads its node's copy of the table, one
+    column per task as the reference's rayon split (oracle.rs:720).
+
+    `value` is the rate on ALL the cores this process may use: the host's hardware threads, or — when the container has a
+    CPU quota (cgroup cpu.max; the pool's GPU boxes grant 16 CPUs of the host's 256 hardware threads, and threads beyond
+    the quota only time-slice it: 256 threads were SLOWER than 32 in round 2) — as many threads as the quota grants."""
     from oracle import oracle as o
 
     hw = o.hardware_threads()
-    threads = max(1, min(hw, 256))
+    quota = o.cpu_quota()
+    cores = max(1, min(hw, int(quota))) if quota else hw
     n = 1 << log_n
-    # one thread alone (what a single core delivers), then all threads; repeated calls of two columns per thread until
-    # about 10 s of timed work have accumulated (bounded: at most 16 calls)
+    cols = 2
     one = o.fft_bench(n, 1, 4)
     per_thread = 2 * 4 / one
-    # all threads, then a half, a quarter and an eighth of them (2^20-point columns are 8 MiB each: on a big host the all-thread run is
-    # bound by the memory system, and fewer threads can deliver more); two columns per thread per call, the thread count
-    # with the best rate is run again until about 10 s of timed work have accumulated
-    cols, rates = 2, {}
-    for t in sorted({threads, max(1, threads // 2), max(1, threads // 4), max(1, threads // 8)}, reverse=True):
-        rates[t] = 2 * t * cols / o.fft_bench(n, t, cols, seed=0x706C6F6E6B7932 + t)
-    best = max(rates, key=rates.get)
-    timed, calls = 0.0, 0
-    while timed < 10.0 and calls < 12:
-        timed += o.fft_bench(n, best, cols, seed=0x706C6F6E6B7932 + 1000 + calls)
+    # A quota means a shared host: other tenants keep some cores busy, and the pool's boxes gave 190-380 NTT/s for the same
+    # call within one minute. There the threads are left to the scheduler (pinned ones can land on a busy core); on a host of
+    # one's own they are pinned, one per core, for NUMA-local columns.
+    if quota:
+        os.environ["GLO_FFT_BENCH_NO_PIN"] = "1"
+    # the all-core figure, repeated until about 10 s of timed work have accumulated (bounded: at most 24 calls)
+    timed, calls, per_call = 0.0, 0, []
+    while timed < 10.0 and calls < 24:
+        dt = o.fft_bench(n, cores, cols, seed=0x706C6F6E6B7932 + 1000 + calls)
+        per_call.append(2 * cores * cols / dt)
+        timed += dt
         calls += 1
-    transforms = 2 * best * cols * calls
+    transforms = 2 * cores * cols * calls
+    # for the record: other thread counts, one call each (more threads than the quota grants, fewer than the cores)
+    others = {}
+    for t in sorted({max(1, cores // 2), min(hw, 2 * cores), hw} - {cores}):
+        others[str(t)] = 2 * t * cols / o.fft_bench(n, t, cols, seed=0x706C6F6E6B7932 + t)
+    best = max([transforms / timed] + list(others.values()))
     return {
         "value": transforms / timed,
         "unit": "NTT/s",
-        "cores": best,
+        "cores": cores,
         "kind": "port",
+        "host_hardware_threads": hw,
+        "container_cpu_quota": quota,
         "one_thread_NTT_per_s": per_thread,
-        "NTT_per_s_by_threads": {str(k): v for k, v in rates.items()},
-        "parallel_efficiency": transforms / timed / (per_thread * best),
-        "sample": f"{calls} x ({best} threads x {cols} columns of 2^{log_n}, forward + inverse) = {transforms} transforms in "
-                  f"{timed:.2f} s of in-C wall clock; {best} of {hw} hardware threads gave the best rate of "
-                  f"{ {k: round(v, 1) for k, v in rates.items()} }; C restatement of fft_classic, root table prebuilt, "
-                  f"thread-local columns; one thread alone: {per_thread:.2f} NTT/s",
+        "NTT_per_s_per_call_min_median_max": [min(per_call), sorted(per_call)[len(per_call) // 2], max(per_call)],
+        "threads_pinned": not quota,
+        "NTT_per_s_at_other_thread_counts": others,
+        "best_of_all_thread_counts_NTT_per_s": best,
+        "parallel_efficiency": transforms / timed / (per_thread * cores),
+        "sample": f"{calls} x ({cores} threads x {cols} columns of 2^{log_n}, forward + inverse) = {transforms} transforms in "
+                  f"{timed:.2f} s of in-C wall clock on {cores} threads = every CPU the container may use "
+                  f"({hw} hardware threads on the host, cgroup quota {quota}); C restatement of fft_classic, root table "
+                  f"prebuilt per NUMA node, thread-local columns; one thread alone: {per_thread:.2f} NTT/s",
     }
 
 
@@ -144,46 +164,78 @@ def dft_point(x, log_n, k):
     return int(terms[0])
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
+POSEIDON_RATE = os.path.join(ROOT, "profiles", "r03_poseidon_rate.json")
+# the kernel sources whose counters the summary holds: tools/pmc_summary.py records their sha256 next to the counters
+PMC_SOURCES = ["plonky2_gpu_amd/csrc/ntt.hip", "plonky2_gpu_amd/csrc/ntt_direct.hip", "plonky2_gpu_amd/csrc/ntt_kernels.h",
+               "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/gl_field.h"]
 
 
-def pmc_summary():
-    return json.load(open(PMC_SUMMARY)) if os.path.exists(PMC_SUMMARY) else None
+def source_hashes(root=ROOT):
+    import hashlib
+
+    out = {}
+    for rel in PMC_SOURCES:
+        path = os.path.join(root, rel)
+        out[rel] = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+    return out
+
+
+def pmc_summary(path=None, root=ROOT):
+    """(summary, None) when the committed counter summary was collected on the kernel sources of this tree, (None, reason)
+    otherwise: counters are not measured by bench.py (rocprofv3 cannot run inside it), so a summary that is older than the
+    kernels it describes must not be quoted."""
+    path = path or PMC_SUMMARY
+    if not os.path.exists(path):
+        return None, f"{os.path.relpath(path, root)} is absent"
+    d = json.load(open(path))
+    have, now = d.get("source_sha256"), source_hashes(root)
+    if not have:
+        return None, f"{os.path.relpath(path, root)} records no source hashes"
+    stale = sorted(k for k in now if have.get(k) != now[k])
+    if stale:
+        return None, f"{os.path.relpath(path, root)} was collected on other versions of {', '.join(stale)}: regenerate it (tools/gpu_runs/pmc_passes.sh, tools/pmc_summary.py)"
+    return d, None
 
 
 def pmc_traffic(log_n, batch):
-    """HBM-side bytes per forward batch transform from the committed counter summary (rocprofv3 FETCH_SIZE and WRITE_SIZE
-    in separate passes of this command, FETCH_SIZE x 2 on every kernel as the gfx950 note of MI355X_MICROARCH.md prescribes;
-    the copy kernel of the same passes — a known 512 MiB each way — calibrates it). bench.py cannot read counters while it runs."""
-    d = pmc_summary()
-    if log_n != 20 or not d:
-        return None
-    total = 0.0
+    """(bytes, source note): HBM-side bytes per forward batch transform from the committed counter summary (rocprofv3
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE x 2 as the gfx950 note of MI355X_MICROARCH.md prescribes),
+    per launch pair of `batch` columns; (None, why) when the summary is absent or stale."""
+    d, why = pmc_summary()
+    if not d:
+        return None, why
+    if log_n != 20:
+        return None, "the counter passes were collected at 2^20"
+    total, per_launch_cols = 0.0, None
     for name, e in d["kernels"].items():
-        if name.startswith("ntt_pass_wave_kernel<10,") and name.endswith("grid=262144") and ",true,true," not in name:
+        if name.startswith(("ntt_col_direct_kernel<2,true>", "ntt_row_natural_direct_kernel<false>")):
             total += e["derived"].get("read_bytes (FETCH_SIZE KiB x 1024 x 2)", 0) + e["derived"].get("write_bytes (WRITE_SIZE KiB x 1024)", 0)
-    return total * (batch / 16.0) if total else None  # the launches are per 16-column chunk
+            per_launch_cols = d.get("ntt_columns_per_launch", 64)
+    if not total:
+        return None, "the summary holds no direct-pass kernels"
+    return total * (batch / float(per_launch_cols)), os.path.relpath(PMC_SUMMARY, ROOT)
 
 
 def poseidon_issue_bound():
     """What the counters say bounds the leaf hashing: the permutation kernel issues VALU instructions back to back
     (SQ_INSTS_VALU x 4 cycles = the kernel's cycles x 1024 SIMDs), so permutations/s <= 64 lanes x 1024 SIMDs x clock /
-    (VALU instructions per wavefront-permutation x 4)."""
-    d = pmc_summary()
+    (VALU instructions per wavefront-permutation x 4). (bound, None) or (None, why not)."""
+    d, why = pmc_summary()
     if not d:
-        return None
+        return None, why
     e = d["kernels"].get("permute_batch_kernel grid=4194304")
-    if not e:
-        return None
+    if not e or not os.path.exists(POSEIDON_RATE):
+        return None, "no permutation kernel in the summary"
     insts = e["derived"]["valu_insts_per_wave"]
     cycles = e["derived"]["kernel_cycles"]
-    rate = json.load(open(os.path.join(ROOT, "profiles", "r02_poseidon_rate.json")))
+    rate = json.load(open(POSEIDON_RATE))
     clock = cycles / (rate["ms"] * 1e-3)
     return {"valu_insts_per_wavefront_permutation": insts, "issue_cycles_per_valu_inst": 4,
             "valu_issue_frac_of_kernel_cycles": e["derived"]["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"],
             "clock_GHz_during_kernel": clock / 1e9, "bound_permutations_per_s": 64 * 1024 * clock / (insts * 4.0),
             "standalone_permutations_per_s": rate["permutations_per_s"],
-            "source": "profiles/r02_pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVES, GRBM_GUI_ACTIVE on tools/bench_poseidon.py), profiles/r02_poseidon_rate.json"}
+            "source": f"{os.path.relpath(PMC_SUMMARY, ROOT)} (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVES, GRBM_GUI_ACTIVE on tools/bench_poseidon.py), {os.path.relpath(POSEIDON_RATE, ROOT)}"}, None
 
 
 def launch_ranks(n, argv=None, script=None, extra_env=None):
@@ -256,20 +308,42 @@ def main():
     host = splitmix64_field(batch * n, start=dist.rank << 40).reshape(batch, n)
     buf = pg.DeviceBuffer.from_host(ctx, host)
 
-    def step():
+    def pair():
         _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 0, 0, ctx.ptr)
         _lib.call("gl_ntt_batch", buf.ptr, batch, log_n, n, 1, 0, ctx.ptr)
 
+    # A step is `inner` forward + inverse transforms of the batch. One pair takes about 1.2 ms, and devices of the pool differ
+    # by several per cent on the same binary, so the timed region is kept at >= MIN_REGION_S whatever --steps says: `inner`
+    # is set from a short calibration (the same on every rank: max over ranks) and printed in config.
+    for _ in range(3):
+        pair()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        pair()
+    ctx.synchronize()
+    t_pair = dist.max((time.perf_counter() - t0) / 8)
+    inner = args.inner if args.inner > 0 else max(1, int(np.ceil(1.15 * MIN_REGION_S / (args.steps * t_pair))))  # 15 % margin: the calibration pairs run on a cold clock
+
+    def step():
+        for _ in range(inner):
+            pair()
+
+    def timed_window():
+        ctx.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.synchronize()
+        dist.barrier()
+        return dist.max(time.perf_counter() - t)
+
     for _ in range(args.warmup):
         step()
-    ctx.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    dist.barrier()
-    elapsed = dist.max(time.perf_counter() - t0)
+    elapsed = timed_window()  # THE timed region: exactly --steps steps between barrier + synchronize on both sides
+    # the same region again, WINDOWS times: the spread says how much one window can be trusted
+    window_s = [elapsed] + [timed_window() for _ in range(max(0, args.windows))]
 
     # parity: after an equal number of forward/inverse transforms the batch must equal the input
     back = buf.download().reshape(batch, n)
@@ -277,7 +351,7 @@ def main():
         raise SystemExit("bench: ifft(fft(x)) != x — results invalid")
 
     # forward transform timed with HIP events on the launch stream (roofline numerator: 16 B/elt)
-    reps = max(5, args.steps)
+    reps = max(40, args.steps)
     ev = [pg.Event() for _ in range(2 * reps)]
     fwd_ms = []
     for r in range(reps):
@@ -305,7 +379,7 @@ def main():
     scratch.free()
     copy_gbs = 2 * 8.0 * batch * n / (min(copy_ms) * 1e-3) / 1e9
     mulmods = (n // 2) * log_n * batch  # (N/2) lg N butterflies per transform, one mulmod + add + sub each
-    traffic = pmc_traffic(log_n, batch)
+    traffic, traffic_source = pmc_traffic(log_n, batch)
 
     out = None
     if dist.rank == 0:
@@ -324,10 +398,12 @@ def main():
     extra = {}
     if not args.no_commit and dist.rank == 0:
         extra = bench_commit(pg, _lib, ctx, args.commit_cols, args.commit_log_n)
-        bound = poseidon_issue_bound()
+        bound, why = poseidon_issue_bound()
         if bound:
             bound["commit_permutations_per_s_frac_of_bound"] = extra["poseidon_permutations_per_s"] / bound["bound_permutations_per_s"]
-            extra["poseidon_valu_issue_bound"] = bound
+        extra["poseidon_valu_issue_bound"] = bound
+        if not bound:
+            extra["poseidon_valu_issue_bound_absent_because"] = why
 
     if not args.no_prove:
         pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
@@ -335,7 +411,8 @@ def main():
             extra["prove"] = pr
 
     if dist.rank == 0:
-        ntts = 2 * batch * args.steps * dist.world
+        ntts = 2 * batch * inner * args.steps * dist.world
+        rates = sorted(ntts / w for w in window_s)
         out = {
             "metric": "NTTs/sec at 2^20 Goldilocks",
             "value": ntts / elapsed,
@@ -344,16 +421,21 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_windows": {"count": len(rates), "median": rates[len(rates) // 2], "min": rates[0], "max": rates[-1],
+                              "seconds_per_window": round(float(np.median(window_s)), 3),
+                              "note": "the timed region (`value`) and WINDOWS repeats of it, NTT/s each"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, integer modular)",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: {batch} columns x 2^{log_n} points per GPU, forward + inverse NTT per step "
+                "workload": f"configs[1]: {batch} columns x 2^{log_n} points per GPU, {inner} x (forward + inverse NTT of the batch) per step "
                             f"(natural order in/out, bit-exact vs field/src/fft.rs), inputs resident in HBM",
                 "batch_columns": batch,
                 "log_n": log_n,
+                "pairs_per_step": inner,
+                "transforms_per_step": 2 * batch * inner,
                 "parallelism": f"columns sharded over {dist.world} GPU(s), no collective",
                 "ranks": dist.world,
                 "devices_visible": ndev,
@@ -366,17 +448,18 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, summarised by "
-                                  "tools/pmc_summary.py into profiles/r02_pmc_summary.json (gfx950 x2 correction on every "
-                                  "kernel's FETCH_SIZE, calibrated on the copy kernel of the same passes); null when absent",
-                "kernel": "forward batch NTT = ntt_pass_wave_kernel<10,true,..> (column pass) + ntt_pass_wave_kernel<10,false,..> (row pass)",
-                "binding_roof": "two passes move 2x the algorithmic bytes (traffic); the passes are latency-bound, not "
-                                "bandwidth- or ALU-bound: counters give VALU issue 51 % (column pass) / 62 % (row pass) of "
-                                "the kernel cycles and waves parked at s_waitcnt/barrier 47-54 % of their lifetime; the same "
-                                "instruction stream with its traffic served from L2 runs 30 % faster, with no global memory "
-                                "at all 35 % faster (profiles/r02_ntt_*_experiment.jsonl, DESIGN.md 3.1)",
+                "traffic_source": traffic_source if traffic is not None else None,
+                "traffic_absent_because": None if traffic is not None else traffic_source,
+                "kernel": "forward batch NTT = ntt_col_direct_kernel<2,true> (column pass) + ntt_row_natural_direct_kernel<false> (row pass), "
+                          "one launch pair per 64-column batch",
+                "binding_roof": "two passes move 2x the algorithmic bytes (traffic). The passes are bound by vector-ALU issue: "
+                                "the same instruction stream with loads and stores served from L2 and without its workgroup "
+                                "barriers runs 12 % faster (profiles/r03_ntt_direct_diagnostic_variants.jsonl), counters in "
+                                "profiles/r03_pmc_summary.json, DESIGN.md 3.1",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
+                "ms_min_max": [float(min(fwd_ms)), float(max(fwd_ms))],
+                "ms_launch_pairs_timed": reps,
                 "measured_copy_GBps": copy_gbs,
                 "frac_of_measured_copy": achieved / copy_gbs,
                 "algorithmic_butterflies_per_launch_pair": mulmods,

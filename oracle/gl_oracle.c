@@ -5,8 +5,11 @@
  * one task per column for NTT/LDE (fri/oracle.rs:720, 990-997), one task per cap subtree plus
  * fork-join recursion for the tree (hash/merkle_tree.rs:96-99, 232-243).
  */
+#define _GNU_SOURCE /* sched_setaffinity for the cpu_baseline harness */
 #include "gl_oracle.h"
 
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -311,16 +314,113 @@ void glo_fft_batch(uint64_t *v, size_t n_polys, size_t n, int inverse, int n_thr
  * the parallel region between two barriers, so thread start-up, allocation and the table are outside it.
  * Returns seconds for the 2 * n_threads * cols_per_thread transforms; *checksum defeats dead-code elimination and
  * lets the caller see that ifft(fft(x)) == x held (0 = every column came back unchanged). */
+/* NUMA node of every CPU from /sys/devices/system/node/node<k>/cpulist (no libnuma in this image); -1 = unknown. */
+#define GLO_MAX_CPUS 4096
+#define GLO_MAX_NODES 64
+static int cpu_nodes(int *node_of_cpu) {
+    int n_nodes = 0;
+    for (int c = 0; c < GLO_MAX_CPUS; c++) node_of_cpu[c] = -1;
+    for (int k = 0; k < GLO_MAX_NODES; k++) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", k);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;
+        int lo, hi, got = 0;
+        char sep;
+        while (fscanf(f, "%d", &lo) == 1) {
+            hi = lo;
+            if (fscanf(f, "%c", &sep) == 1 && sep == '-') {
+                if (fscanf(f, "%d", &hi) != 1) break;
+                if (fscanf(f, "%c", &sep) != 1) sep = 0;
+            }
+            for (int c = lo; c <= hi && c < GLO_MAX_CPUS; c++) node_of_cpu[c] = k, got = 1;
+            if (sep != ',') break;
+        }
+        fclose(f);
+        if (got && k + 1 > n_nodes) n_nodes = k + 1;
+    }
+    return n_nodes;
+}
+
 double glo_fft_bench(size_t n, int n_threads, int cols_per_thread, uint64_t seed, uint64_t *checksum) {
     if (n_threads < 1) n_threads = 1;
     if (cols_per_thread < 1) cols_per_thread = 1;
-    root_table_t rt = root_table_new(n);
+    /* The CPUs this process may use, and their NUMA nodes. Thread t is pinned to a core of its own while there are cores
+     * (spread evenly over them, so over both sockets), allocates and fills its columns there (first touch on its own node)
+     * and reads the copy of the root table that the first thread of its node built. What made round 2's harness SLOWER
+     * beyond 32 threads turned out to be none of this: the GPU box's container has a CPU quota
+     * (cgroup cpu.max = 16 CPUs on the pool's boxes) and 256 threads time-slice 16 CPUs' worth of time — bench.py now
+     * reads the quota (oracle.cpu_quota) and runs as many threads as it grants. */
+    cpu_set_t allowed;
+    int cpus[GLO_MAX_CPUS], n_cpus = 0;
+    static int node_of_cpu[GLO_MAX_CPUS];
+    int n_nodes = cpu_nodes(node_of_cpu);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        /* physical cores first (the lowest-numbered hardware thread of every core), their SMT siblings after them: n_threads
+         * <= cores then means one thread per core */
+        for (int pass = 0; pass < 2; pass++)
+            for (int c = 0; c < CPU_SETSIZE && c < GLO_MAX_CPUS; c++) {
+                if (!CPU_ISSET(c, &allowed)) continue;
+                char path[112];
+                int first = c;
+                snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+                FILE *f = fopen(path, "r");
+                if (f) {
+                    if (fscanf(f, "%d", &first) != 1) first = c;
+                    fclose(f);
+                }
+                if ((first == c) == (pass == 0)) cpus[n_cpus++] = c;
+            }
+    }
+    int n_primary = 0;
+    for (int i = 0; i < n_cpus; i++) {
+        /* the list is primaries then siblings: count the primaries (a sibling's id is never the first of its list) */
+        char path[112];
+        int first = cpus[i];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpus[i]);
+        FILE *f = fopen(path, "r");
+        if (f) {
+            if (fscanf(f, "%d", &first) != 1) first = cpus[i];
+            fclose(f);
+        }
+        if (first == cpus[i]) n_primary++;
+    }
+    if (n_nodes < 1) n_nodes = 1;
+    root_table_t tables[GLO_MAX_NODES];
+    int table_ready[GLO_MAX_NODES];
+    for (int k = 0; k < GLO_MAX_NODES; k++) table_ready[k] = 0;
     double t0 = 0, t1 = 0;
     uint64_t bad = 0;
 #pragma omp parallel num_threads(n_threads) reduction(| : bad)
     {
-        int tid = omp_get_thread_num();
-        uint64_t *v = (uint64_t *)malloc((size_t)cols_per_thread * n * sizeof(uint64_t));
+        int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+        int node = 0;
+        if (n_cpus > 0 && !getenv("GLO_FFT_BENCH_NO_PIN")) {
+            /* up to one thread per core: spread over the cores (and so over the sockets); more: fill the siblings in order */
+            int cpu = nt <= n_primary ? cpus[(int)(((long)tid * n_primary) / nt)] : cpus[tid % n_cpus];
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpu, &one);
+            (void)sched_setaffinity(0, sizeof one, &one);
+            if (node_of_cpu[cpu] >= 0) node = node_of_cpu[cpu];
+        }
+#pragma omp barrier
+        /* one root table per NUMA node, built by one of the node's threads (fft_root_table is built once per circuit,
+         * circuit_builder.rs:849-851; a rayon worker reads it through its socket's caches) */
+#pragma omp critical(glo_fft_bench_tables)
+        {
+            if (!table_ready[node]) {
+                tables[node] = root_table_new(n);
+                table_ready[node] = 1;
+            }
+        }
+#pragma omp barrier
+        const root_table_t *rt = &tables[node];
+        /* columns of different threads start 8320 bytes apart modulo the page size: 8 MiB columns that are all page-aligned
+         * fall on the same cache sets */
+        size_t skew = ((size_t)tid % 61) * 8320 / sizeof(uint64_t);
+        uint64_t *v_alloc = (uint64_t *)malloc(((size_t)cols_per_thread * n + skew) * sizeof(uint64_t));
+        uint64_t *v = v_alloc + skew;
         uint64_t *ref = (uint64_t *)malloc(n * sizeof(uint64_t));
         uint64_t x = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(tid + 1);
         for (size_t i = 0; i < (size_t)cols_per_thread * n; i++) { /* SplitMix64, rejected to [0, p) */
@@ -339,17 +439,20 @@ double glo_fft_bench(size_t n, int n_threads, int cols_per_thread, uint64_t seed
 #pragma omp master
         t0 = omp_get_wtime();
         for (int c = 0; c < cols_per_thread; c++) {
-            fft_with_table(v + (size_t)c * n, n, 0, &rt);
-            ifft_with_table(v + (size_t)c * n, n, &rt);
+            fft_with_table(v + (size_t)c * n, n, 0, rt);
+            ifft_with_table(v + (size_t)c * n, n, rt);
         }
 #pragma omp barrier
 #pragma omp master
         t1 = omp_get_wtime();
         for (size_t i = 0; i < n; i++) bad |= glo_canon(v[i]) ^ ref[i];
-        free(v);
+        free(v_alloc);
         free(ref);
+        /* the pool's threads are reused by later parallel regions of this process: give them the whole mask back */
+        if (n_cpus > 0) (void)sched_setaffinity(0, sizeof allowed, &allowed);
     }
-    root_table_free(&rt);
+    for (int k = 0; k < GLO_MAX_NODES; k++)
+        if (table_ready[k]) root_table_free(&tables[k]);
     if (checksum) *checksum = bad;
     return t1 - t0;
 }

@@ -235,6 +235,22 @@ def hardware_threads():
     return lib().glo_hardware_threads()
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use, from the cgroup (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us);
+    None when there is no limit. The GPU boxes of the pool grant 16 of the host's 256 hardware threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def random_field(shape, seed=0x706C6F6E6B7932):
     """Uniform canonical field elements from a seeded generator (numpy PCG64; rejection-free:
     draw 64 bits and fold the 2^32-1 values >= p back by subtraction — bias 2^-32, irrelevant

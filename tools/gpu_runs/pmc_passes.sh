@@ -1,14 +1,16 @@
 #!/bin/bash
-# counters + kernel stats of the final kernels -> gpurun_out/r02pmc (summarised into profiles/ by tools/pmc_summary.py)
+# counters + kernel stats of the final kernels -> gpurun_out/${TAG}pmc, summarised into profiles/${TAG}_pmc_summary.json by
+# tools/pmc_summary.py (which records the sha256 of the kernel sources: bench.py refuses a summary of other sources)
+TAG=${TAG:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02pmc
+O=$R/gpurun_out/${TAG}pmc
 mkdir -p $O
 cd /tmp
-B="python3 $R/bench.py --no-prove --no-cpu --steps 3 --warmup 1"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bench -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 > $O/stats_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ntt -- python3 $R/bench.py --no-prove --no-cpu --no-commit --steps 20 --warmup 3 > $O/stats_ntt.log 2>&1
+B="python3 $R/bench.py --no-prove --no-cpu --steps 3 --warmup 1 --inner 1 --windows 0"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bench -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 --inner 1 --windows 0 > $O/stats_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ntt -- python3 $R/bench.py --no-prove --no-cpu --no-commit --steps 20 --warmup 3 --inner 1 --windows 0 > $O/stats_ntt.log 2>&1
 pmc() { n=$1; shift; timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$n -- $B > $O/pmc_$n.log 2>&1; }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
@@ -23,4 +25,6 @@ pp sq2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_IFETCH SQ_THREAD_CYCLES
 cd $R
 python3 tools/bench_poseidon.py > $O/poseidon_rate.json 2>&1
 find $O -name "*.csv" -size +6M -delete
+python3 tools/pmc_summary.py $O $TAG | tail -20
+cp profiles/${TAG}_pmc_summary.json $O/ 2>/dev/null
 du -sh $O

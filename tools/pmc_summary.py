@@ -47,7 +47,16 @@ def main():
     for f in glob.glob(os.path.join(root, "stats_*", "*", "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
             dur[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    out = {"units": "counter medians per launch; durations in microseconds from the un-instrumented kernel trace", "kernels": {}}
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench  # the list of kernel sources and their hashes live with the reader of this file (bench.py pmc_summary)
+
+    out = {"units": "counter medians per launch; durations in microseconds from the un-instrumented kernel trace",
+           "source_sha256": bench.source_hashes(repo),
+           "source_sha256_note": "sha256 of the kernel sources these counters were collected on; bench.py quotes the counters only "
+                                 "while the tree's files still hash to these values",
+           "ntt_columns_per_launch": 64,
+           "kernels": {}}
     for key in sorted(counters):
         name, grid = key
         c = {k: med(v) for k, v in counters[key].items()}
