@@ -46,7 +46,8 @@ fn main() {
     println!("cargo:rerun-if-env-changed=ROCM_PATH");
     println!("cargo:rerun-if-changed={}", repo.join("plonky2_gpu_amd/csrc").display());
     println!("cargo:rerun-if-changed={}", repo.join("include/plonky2_hip.h").display());
-    // the reference's build script turned on the "cuda" cfg that plonky2's sources test; keep it on so the GPU
-    // code paths of fri/oracle.rs and plonk/prover.rs are compiled
+    // The reference's build script prints the same line (cuda/build.rs:38). A build-script cfg applies to THIS crate only:
+    // nothing in plonky2's own sources is switched by it (they contain no cfg(feature = "cuda"); the GPU entry points
+    // from_values_with_gpu / my_prove are always compiled), so it is kept only for parity with the crate it replaces.
     println!("cargo:rustc-cfg=feature=\"cuda\"");
 }

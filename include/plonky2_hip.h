@@ -302,7 +302,9 @@ GlError gl_pack_leaf_ranges(const uint64_t *d_lde, uint64_t col_stride, uint32_t
  *   d_coeffs   [poly_num][2^log_n]            in
  *   d_lde      [(poly_num+salt_size)][n_ext]  out, column-major, bit-reversed (n_ext = 2^(log_n+rate_bits));
  *              the salt_size trailing columns are read as given (caller-provided randomness,
- *              oracle.rs:998-1002) and take part in the leaf hash
+ *              oracle.rs:998-1002) and take part in the leaf hash. They are read by kernels on a stream of the library's own
+ *              that starts behind everything queued on ctx's stream at the time of the call: write them on ctx's stream
+ *              (gl_memcpy_*, a kernel launched there) or complete the writes before calling.
  *   d_leaves   [n_ext][poly_num+salt_size]    out, leaf-major (= merkle_tree.leaves); may be NULL
  *   d_digests / d_cap as gl_merkle_tree_*.
  * shift is F::coset_shift() = 7 in the reference (field/src/types.rs:431-433). */

@@ -404,7 +404,10 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     constexpr uint64_t CHUNK = 16;  // columns per pipeline step: two rate blocks
     if (commit_pipeline_enabled() && poly_num >= 3 * CHUNK && n_ext >= (1ull << 16)) {
         const size_t n_chunks = (size_t)((poly_num + CHUNK - 1) / CHUNK);
-        hipStream_t hs;
+        hipStream_t hs = nullptr;
+        // An error after work has been queued on the hash stream or on stream2 must not leave those kernels running behind
+        // the caller's back (its gl_ctx_synchronize and frees only cover its own stream): the failing path waits for both.
+        auto pipelined = [&]() -> GlError {
         std::vector<hipEvent_t> *evs;
         HIP_TRY(get_hash_stream(&hs, &evs, n_chunks + 2));
         // the hash stream starts behind whatever the caller has queued (the buffers may still be in use by earlier work)
@@ -440,6 +443,13 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         HIP_TRY(hipStreamWaitEvent(s->stream, (*evs)[n_chunks + 1], 0));  // the caller's stream continues after the tree
         if (d_leaves) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr2, 0));
         return ok();
+        };
+        GlError r = pipelined();
+        if (r.code != 0) {
+            if (hs) (void)hipStreamSynchronize(hs);
+            (void)hipStreamSynchronize(s->stream2);
+        }
+        return r;
     }
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
     hipEvent_t ev_lde = nullptr, ev_tr = nullptr;
@@ -466,7 +476,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
 
 extern "C" {
 
-const char *gl_version(void) { return "plonky2_hip 0.1.0 gfx950"; }
+const char *gl_version(void) { return "plonky2_hip 0.3.0 gfx950"; }
 
 int gl_device_count(void) {
     int n = 0;

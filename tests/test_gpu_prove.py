@@ -331,6 +331,34 @@ def test_all_25_ed25519_gates_with_honest_rows_proof_bytes(gpu, compile_gates):
     nc.close()
 
 
+def test_all_25_gates_proof_bytes_at_2e14_rows_equal_the_fixture(gpu):
+    """The all-25-gates circuit (tests/ed25519_rows.py) at 2^14 rows — 655 honest rows per gate kind, 234 wires, LDE 2^17,
+    pipelined commits, two-pass transforms — byte for byte against the oracle's proof kept as a fixture
+    (tests/golden/prove_all_gates_2e14.bin, written by tests/golden/gen_prove_all_gates_golden.py in a quarter of an hour);
+    compiled and interpreted gates. Until round 3 this circuit was byte-checked at 2^8 rows only."""
+    import hashlib
+    import json
+    import os
+
+    import ed25519_rows as er
+    import plonky2_gpu_amd as pg
+    from oracle import accel
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "prove_all_gates_2e14.json")))
+    want = open(os.path.join(gold, "prove_all_gates_2e14.bin"), "rb").read()
+    assert hashlib.sha256(want).hexdigest() == meta["sha256"] and len(want) == meta["bytes"]
+    with accel.c_backend():
+        circuit, wires, pis = er.make_all_gates_circuit(meta["degree_bits"], seed=meta["seed"], templates=meta["templates"],
+                                                        fri_params=meta["fri_params"])
+    for compile_gates in (True, False):
+        nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+        assert [int(v) for v in nc.circuit_digest] == meta["circuit_digest"]
+        data = nc.prove_bytes(wires, pis)
+        nc.close()
+        assert data == want, compile_gates
+
+
 def test_full_size_proof_with_all_25_gate_kinds_in_use_is_accepted_by_the_oracle_verifier(gpu):
     """BASELINE.json configs[3] at its full shape (2^18 rows, 234 wires / 80 routed, 88 preprocessed polynomials, rate 8,
     cap height 4, arities [4,4,4,4], 28 queries, 16 PoW bits) with EVERY one of the 25 gate kinds constraining rows

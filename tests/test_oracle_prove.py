@@ -210,3 +210,32 @@ def test_the_2e13_row_proof_fixture_is_what_its_generator_says():
         assert [int(v) for v in proof["public_inputs"]] == pis
         assert serialize_ref.proof_bytes(proof) == data
         assert prove_ref.verify(circuit, proof)
+
+
+def test_the_2e14_row_all_gates_proof_fixture_is_what_its_generator_says():
+    """tests/golden/prove_all_gates_2e14.bin (tests/golden/gen_prove_all_gates_golden.py; compared with gl_prove's bytes on the
+    GPU): recorded hash, wire format of the circuit rebuilt from the recorded seed (whose digest is the recorded one), and the
+    oracle's verifier — which evaluates all 25 gates of the ed25519 table at zeta over F_p^2 on its own — accepts it."""
+    import hashlib
+    import json
+    import os
+
+    import ed25519_rows as er
+    from oracle import accel, serialize_ref
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(gold, "prove_all_gates_2e14.json")))
+    data = open(os.path.join(gold, "prove_all_gates_2e14.bin"), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == meta["sha256"] and len(data) == meta["bytes"]
+    with accel.c_backend():
+        circuit, wires, pis = er.make_all_gates_circuit(meta["degree_bits"], seed=meta["seed"], templates=meta["templates"],
+                                                        fri_params=meta["fri_params"])
+        oc, _ = er.as_oracle_circuit(circuit, wires[:1], prove_ref)
+        assert [int(v) for v in oc["circuit_digest"]] == meta["circuit_digest"]
+        from plonky2_gpu_amd import serialization  # host-side reader of the wire format (no device involved)
+
+        proof = serialization.proof_from_bytes(data, circuit)
+        assert [int(v) for v in proof["public_inputs"]] == pis
+        assert serialize_ref.proof_bytes(proof) == data
+        assert prove_ref.verify(oc, proof)
+

@@ -33,6 +33,26 @@ def test_dump_files_have_the_documented_shapes(dumps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("degree_bits", [10] + ([12] if os.environ.get("PLONKY2_SLOW_TESTS") else []))
+def test_check_at_sizes_with_two_pass_transforms(tmp_path, degree_bits):
+    """The same route at 2^10 rows (LDE 2^13: two-pass transforms and LDEs, the pipelined commit, several selector groups'
+    worth of rows per gate kind), and at 2^12 when PLONKY2_SLOW_TESTS is set (the oracle needs about five minutes for that
+    proof; tools/gpu_runs/slow_parity.sh runs it and profiles/ keeps the report). The oracle's Poseidon / NTT / Merkle
+    primitives come from the C restatement (accel.c_backend), which the reference's known answers pin."""
+    import reference_dump_writer as w
+
+    d = str(tmp_path / "dumps")
+    w.write(d, degree_bits=degree_bits)
+    tool = os.path.join(ROOT, "tools", "reference_dumps.py")
+    p = subprocess.run([sys.executable, tool, "check", d], capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    rep = json.loads(p.stdout[p.stdout.index("{"):])
+    assert rep["ok"] is True and rep["degree_bits"] == degree_bits
+    assert len([k for k, v in rep.items() if isinstance(v, str) and v.startswith("equal")]) >= 14, rep
+    assert rep["5 proof.bin"].startswith("equal")
+
+
+@pytest.mark.gpu
 def test_check_reproduces_every_cpu_dump_on_the_device(dumps):
     tool = os.path.join(ROOT, "tools", "reference_dumps.py")
     p = subprocess.run([sys.executable, tool, "check", dumps], capture_output=True, text=True, timeout=1200)

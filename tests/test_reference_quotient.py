@@ -137,6 +137,87 @@ def test_reference_symbol_equals_the_generic_entry_point(gpu):
     assert (out.download().reshape(2, -1) == got).all()
 
 
+def _poly_at(coeffs, x):
+    """sum_j coeffs[j] x^j mod p with vectorised numpy field arithmetic (tools/synth_circuit.py), no oracle arithmetic involved"""
+    import synth_circuit as sc
+
+    pw = np.ones(1, dtype=np.uint64)
+    for b in range(int(coeffs.size).bit_length() - 1):
+        pw = np.concatenate([pw, sc.np_mul(pw, np.uint64(pow(x, 1 << b, P)))])
+    terms = sc.np_mul(np.ascontiguousarray(coeffs, dtype=np.uint64), pw)
+    while terms.size > 1:
+        half = terms.size // 2
+        terms = sc.np_add(terms[:half], terms[half:])
+    return int(terms[0])
+
+
+@pytest.mark.gpu
+def test_reference_symbol_at_the_size_the_reference_hard_wires(gpu):
+    """log_len = 18 is the only size cuda/plonky2_gpu.cu:665-673, 746 supports (values_num_per_poly = 2^18, 2^21 LDE points,
+    234 + 88 + 20 leaf elements per point = 5.7 GB of leaves). On random leaves, where all 25 gates are live at every point:
+      * the symbol's two quotient polynomials equal gl_compute_quotient_polys given the same circuit as arguments, with the
+        run-time compiled kernel AND with the interpreter;
+      * at sampled LDE points x the polynomials evaluate to what the oracle computes for that point from the leaves
+        (prover.rs:903-991 restated per point: gate constraints, permutation terms, alpha reduction, division by Z_H)."""
+    import ctypes
+    import sys as _sys
+
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import plonky2_gpu_amd as pg
+    from oracle import plonk_ref, prove_ref, pyref
+    from plonky2_gpu_amd import _lib, ed25519_circuit as ed, gate_program as gp
+
+    log_len = 18
+    inst = random_instance(log_len, seed=9200)
+    n, n_ext, bits = 1 << log_len, inst["n_ext"], log_len + ed.RATE_BITS
+    got, bufs = run_symbol(gpu, inst)
+    assert got.shape == (2, n_ext)
+
+    # (1) the generic entry point, both device routes
+    pool = gp.ImmediatePool()
+    prog = pg.GateProgram(gpu, [gp.build_gate(k, p, pool) for k, p in ed.GATES], ed.SELECTOR_INDICES, ed.GROUPS,
+                          ed.REFERENCE_PUBLIC_INPUTS_HASH, immediates=pool.values)
+    a, b, g = (np.ascontiguousarray(inst[k]) for k in ("alphas", "betas", "gammas"))
+    out = pg.DeviceBuffer(gpu, 2 * n_ext)
+    for compiled in (False, True):
+        if compiled:
+            prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)   # the ed25519 table's code object comes from build()'s cache
+        args = _lib.GlQuotientArgs(bufs["wires"].ptr, bufs["cs"].ptr, bufs["zs"].ptr, ed.NUM_WIRES, ed.CONSTANTS_SIGMAS_LEAF_LEN,
+                                   ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN, bufs["k_is"].ptr, None, b.ctypes.data, g.ctypes.data, a.ctypes.data,
+                                   ed.NUM_CONSTANTS, ed.NUM_ROUTED_WIRES, 2, ed.NUM_GATE_CONSTRAINTS, log_len, ed.RATE_BITS,
+                                   ed.QUOTIENT_DEGREE_FACTOR, ed.COSET_SHIFT, ctypes.pointer(prog.struct), 0,
+                                   prog.kernel if compiled else None, None, None)
+        _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, gpu.ptr)
+        assert (out.download().reshape(2, -1) == got).all(), "compiled" if compiled else "interpreted"
+
+    # (2) the oracle, point by point, on a strided sample of the 2^21 LDE points
+    gates = prove_ref.base_gates({"gates": ed.GATES})
+    qdb = (ed.QUOTIENT_DEGREE_FACTOR - 1).bit_length()
+    assert qdb == ed.RATE_BITS  # the ed25519 configuration: every LDE point is a quotient point
+    w = pyref.root_of_unity(bits)
+    shift = ed.COSET_SHIFT
+    g_pow_n = pow(shift, n, P)
+    lst = lambda k: [int(v) for v in inst[k]]  # noqa: E731
+    k_is, betas, gammas, alphas = lst("k_is"), lst("betas"), lst("gammas"), lst("alphas")
+    pih = list(ed.REFERENCE_PUBLIC_INPUTS_HASH)
+    for i in [0, 1, n_ext - 1] + [(977 * 2003 * t + 12345) % n_ext for t in range(9)]:
+        row = lambda m: pyref.reverse_bits(m, bits)  # noqa: E731  leaf j holds the point bitrev(j)
+        x = shift * pow(w, i, P) % P
+        cs = inst["cs"][row(i)].tolist()
+        wires = inst["wires"][row(i)].tolist()
+        zpp = inst["zs"][row(i)].tolist()
+        next_zs = inst["zs"][row((i + (1 << qdb)) % n_ext)].tolist()[:2]
+        zh = (g_pow_n * pow(pyref.root_of_unity(qdb), i % (1 << qdb), P) - 1) % P
+        l_0_x = zh * plonk_ref.inv(n * (x - 1)) % P
+        gate_terms = plonk_ref.evaluate_gate_constraints(gates, ed.SELECTOR_INDICES, ed.GROUPS, ed.NUM_GATE_CONSTRAINTS,
+                                                         cs[:ed.NUM_CONSTANTS], wires, pih)
+        terms = plonk_ref.vanishing_terms_at(x, l_0_x, wires, cs[ed.NUM_CONSTANTS:ed.NUM_CONSTANTS + ed.NUM_ROUTED_WIRES], zpp[:2], next_zs,
+                                             zpp[2:], k_is, betas, gammas, ed.QUOTIENT_DEGREE_FACTOR, gate_terms)
+        red = plonk_ref.reduce_with_powers_multi(terms, alphas)
+        for c in range(2):
+            assert _poly_at(got[c], x) == red[c] * plonk_ref.inv(zh) % P, (i, c)
+
+
 @pytest.mark.gpu
 def test_reference_symbol_rejects_other_shapes(gpu):
     import plonky2_gpu_amd as pg
