@@ -505,7 +505,12 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
         data = nc.prove_bytes(d_wires, pis)  # gl_prove: the whole of prove() in one native call
     ctx.synchronize()
     dist.barrier()
-    elapsed = dist.max(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = dist.max(mine)
+    # per rank: its own rate, and the first entry of its proof's wires cap (the proof starts with the cap, proof.rs /
+    # util/serialization.rs:674-689) gathered over the group's backend — RCCL when every rank has a device of its own
+    rates = dist.gather_caps(np.array([[int(reps / mine * 1e6), 0, 0, 0]], dtype=np.uint64))
+    caps0 = dist.gather_caps(np.frombuffer(data[:32], dtype="<u8").reshape(1, 4).astype(np.uint64))
     timing = {}
     again = nc.prove_bytes(d_wires, pis, timing)  # one more with per-stage synchronisation for the breakdown
     res = None
@@ -527,6 +532,8 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
             "gate_table": table,
             "prove_ms": elapsed / reps * 1e3,
             "proofs_per_s_all_gpus": dist.world * reps / elapsed,
+            "proofs_per_s_per_rank": [int(r[0, 0]) / 1e6 for r in rates],
+            "wires_cap0_per_rank": [[hex(int(x)) for x in c[0]] for c in caps0],
             "proof_bytes": len(data),
             "prover": "gl_prove (native host logic, csrc/prove.hip)",
             "stage_ms": {k: round(v, 3) for k, v in timing.items()},

@@ -115,76 +115,144 @@ class ShardedCommit:
         self.__dict__.update(kw)
 
 
-def sharded_commit_from_values(group, ctx, d_values, col_lo, col_hi, total_cols, log_n, rate_bits, cap_height):
+EXCHANGE_CHUNK_COLS = 16  # columns per LDE + pack + send step: the LDE of chunk k+1 runs under the exchange of chunk k
+
+
+class ShardedCommitPlan:
+    """Everything a column-sharded commit of one shape needs, allocated ONCE: the LDE of this rank's columns, the leaf
+    block of all columns for this rank's leaf range, the pack buffer, the digest block and the cap (round 2 allocated and
+    freed four device buffers per call). `commit(d_values)` may be called any number of times (a prover commits several
+    batches of the same shape); the buffers belong to the plan and are overwritten by the next call."""
+
+    def __init__(self, group, ctx, total_cols, log_n, rate_bits, cap_height):
+        from .device import DeviceBuffer
+
+        W, r = group.world, group.rank
+        if W & (W - 1) or W > (1 << cap_height):
+            raise ValueError("the number of ranks must be a power of two and at most 2^cap_height (whole cap subtrees per rank)")
+        self.group, self.ctx = group, ctx
+        self.total_cols, self.log_n, self.rate_bits, self.cap_height = total_cols, log_n, rate_bits, cap_height
+        self.n, self.n_ext = 1 << log_n, 1 << (log_n + rate_bits)
+        self.bounds = [shard_range(total_cols, W, q) for q in range(W)]
+        self.col_lo, self.col_hi = self.bounds[r]
+        self.mine = self.col_hi - self.col_lo
+        self.L = self.n_ext // W  # leaves per rank
+        self.local_cap_height = cap_height - (W.bit_length() - 1)
+        self.n_dig = 2 * (self.L - (1 << self.local_cap_height))
+        self.d_lde = DeviceBuffer(ctx, max(self.mine, 1) * self.n_ext)
+        self.d_leaves = DeviceBuffer(ctx, total_cols * self.L)
+        self.d_packed = DeviceBuffer(ctx, W * max(self.mine, 1) * self.L) if W > 1 else None
+        self.d_digests = DeviceBuffer(ctx, 4 * max(self.n_dig, 1))
+        self.d_cap = DeviceBuffer(ctx, 4 << self.local_cap_height)
+        self._host = {}  # gloo: staging tensors per (peer, chunk), reused
+
+    def free(self):
+        for b in (self.d_lde, self.d_leaves, self.d_packed, self.d_digests, self.d_cap):
+            if b is not None:
+                b.free()
+
+    @staticmethod
+    def chunks(cols):
+        return [(c0, min(c0 + EXCHANGE_CHUNK_COLS, cols)) for c0 in range(0, cols, EXCHANGE_CHUNK_COLS)]
+
+    def commit(self, d_values):
+        from . import _lib
+
+        g, ctx = self.group, self.ctx
+        W, r, L, mine, n, n_ext = g.world, g.rank, self.L, self.mine, self.n, self.n_ext
+        _lib.call("gl_ntt_batch", d_values.ptr, mine, self.log_n, n, 1, 0, ctx.ptr)
+        if W == 1:
+            _lib.call("gl_coset_lde_batch", d_values.ptr, self.d_lde.ptr, mine, self.log_n, self.rate_bits, 7, n, n_ext, ctx.ptr)
+            _lib.call("gl_memcpy_d2d", self.d_leaves.ptr, self.d_lde.ptr, 8 * mine * n_ext, ctx.ptr)
+        else:
+            td, torch = g.td, g.torch
+            on_device = g.backend == "nccl"
+            reqs, staged = [], []
+            # The path's ONE exchange, chunk by chunk: LDE of sixteen of my columns -> one pack launch groups, for every rank,
+            # the leaf range it hashes of those columns (slice for rank q contiguous at packed[q][c0:c1][L]) -> the sends of
+            # that chunk are posted (point to point, every link of an xGMI mesh carries one pair) and the next chunk's LDE is
+            # queued on the library's stream while they travel: the exchange runs under the remaining LDE.
+            my_chunks = self.chunks(mine)
+            peer_chunks = {q: self.chunks(self.bounds[q][1] - self.bounds[q][0]) for q in range(W) if q != r}
+            steps = max([len(my_chunks)] + [len(v) for v in peer_chunks.values()])
+            for step in range(steps):
+                # step `step`: my chunk goes out, every peer's chunk of the same number comes in — one group per step on
+                # every rank, in the same order everywhere (sends and their receives in one group: no rank waits for a
+                # receive that its peer has queued behind a send)
+                ops = []
+                if step < len(my_chunks):
+                    c0, c1 = my_chunks[step]
+                    k = c1 - c0
+                    _lib.call("gl_coset_lde_batch", d_values.at(c0 * n), self.d_lde.at(c0 * n_ext), k, self.log_n, self.rate_bits, 7, n, n_ext, ctx.ptr)
+                    # pack buffer layout [chunk][q][k][L]: chunk c0 starts at W * c0 * L, its slice for rank q is contiguous
+                    base = W * c0 * L
+                    _lib.call("gl_pack_leaf_ranges", self.d_lde.at(c0 * n_ext), n_ext, k, L, W, self.d_packed.at(base), ctx.ptr)
+                    # my own columns of my own leaf range stay on the device
+                    _lib.call("gl_memcpy_d2d", self.d_leaves.at((self.col_lo + c0) * L), self.d_packed.at(base + r * k * L), 8 * k * L, ctx.ptr)
+                    ctx.synchronize()  # the sends read what the pack wrote (RCCL runs on its own stream)
+                    for q in range(W):
+                        if q == r:
+                            continue
+                        if on_device:  # zero copy: RCCL sends from the pack buffer
+                            send = device_tensor(torch, self.d_packed.at(base + q * k * L), k * L, g.device_index)
+                        else:  # gloo: staged through host memory
+                            send = self._host_tensor(("s", q, c0), k * L)
+                            _lib.call("gl_memcpy_d2h", send.data_ptr(), self.d_packed.at(base + q * k * L), 8 * k * L, ctx.ptr)
+                        ops.append(td.P2POp(td.isend, send, q))
+                        staged.append(send)
+                for q, chunks_q in peer_chunks.items():
+                    if step >= len(chunks_q):
+                        continue
+                    d0, d1 = chunks_q[step]
+                    qlo, cnt = self.bounds[q][0], (d1 - d0) * L
+                    if on_device:  # straight into the leaf block of rank q's columns
+                        recv = device_tensor(torch, self.d_leaves.at((qlo + d0) * L), cnt, g.device_index)
+                    else:
+                        recv = self._host_tensor(("r", q, d0), cnt)
+                        staged.append((q, qlo + d0, recv, cnt))
+                    ops.append(td.P2POp(td.irecv, recv, q))
+                if ops:
+                    reqs += td.batch_isend_irecv(ops)
+            for req in reqs:
+                req.wait()
+            if on_device:
+                torch.cuda.synchronize()
+            else:
+                for item in staged:
+                    if isinstance(item, tuple):
+                        _, col, recv, cnt = item
+                        _lib.call("gl_memcpy_h2d", self.d_leaves.at(col * L), recv.data_ptr(), 8 * cnt, ctx.ptr)
+            ctx.synchronize()
+        _lib.call("gl_merkle_tree_from_columns", self.d_leaves.ptr, self.total_cols, L, L, self.local_cap_height, self.d_digests.ptr,
+                  self.d_cap.ptr, ctx.ptr)
+        my_cap = self.d_cap.download(0, 4 << self.local_cap_height).reshape(-1, 4)
+        cap = np.concatenate(g.gather_caps(my_cap), axis=0)
+        return ShardedCommit(d_coeffs=d_values, d_lde=self.d_lde, d_leaves=self.d_leaves, d_digests=self.d_digests, cap=cap, col_lo=self.col_lo,
+                             col_hi=self.col_hi, total_cols=self.total_cols, leaf_lo=r * L, leaves_per_rank=L, digest_lo=r * self.n_dig,
+                             num_digests=self.n_dig, local_cap_height=self.local_cap_height)
+
+    def _host_tensor(self, key, n_elems):
+        t = self._host.get(key)
+        if t is None or t.numel() != n_elems:
+            t = self.group.torch.empty(n_elems, dtype=self.group.torch.int64)
+            self._host[key] = t
+        return t
+
+
+def sharded_commit_from_values(group, ctx, d_values, col_lo, col_hi, total_cols, log_n, rate_bits, cap_height, plan=None):
     """PolynomialBatch::from_values (fri/oracle.rs:709-731) for ONE trace whose columns [col_lo, col_hi) live on this
     rank (`d_values`: [col_hi - col_lo][2^log_n], transformed in place). Per rank: inverse NTT and coset LDE of its
-    own columns; then the path's ONE exchange — every rank sends, for each of its columns, the leaf range each other
-    rank owns (leaf ranges are contiguous because cap subtrees are), point to point, so that all links work at once
-    on an xGMI mesh; then leaf hashing and the subtrees of its own leaf range; finally an all-gather of the
-    2^cap_height x 32 B cap. With backend "nccl" the exchange runs between device buffers over RCCL; with "gloo" it is
-    staged through host memory (how it is tested with two ranks sharing one GPU)."""
-    from . import _lib
-    from .device import DeviceBuffer
-
-    W, r = group.world, group.rank
-    if W & (W - 1) or W > (1 << cap_height):
-        raise ValueError("the number of ranks must be a power of two and at most 2^cap_height (whole cap subtrees per rank)")
-    n, n_ext = 1 << log_n, 1 << (log_n + rate_bits)
-    mine = col_hi - col_lo
-    bounds = [shard_range(total_cols, W, q) for q in range(W)]
-    if bounds[r] != (col_lo, col_hi):
+    own columns; the path's ONE exchange — every rank sends, for each of its columns, the leaf range each other
+    rank owns (leaf ranges are contiguous because cap subtrees are), point to point, chunk by chunk under the remaining
+    LDE; then leaf hashing and the subtrees of its own leaf range; finally an all-gather of the 2^cap_height x 32 B cap.
+    With backend "nccl" the exchange runs between device buffers over RCCL; with "gloo" it is staged through host memory
+    (how it is tested with ranks sharing one GPU). `plan`: a ShardedCommitPlan of this shape to reuse (its buffers hold
+    the result); without one, a plan is made for this call and its buffers belong to the returned ShardedCommit."""
+    if plan is None:
+        plan = ShardedCommitPlan(group, ctx, total_cols, log_n, rate_bits, cap_height)
+    if (plan.col_lo, plan.col_hi) != (col_lo, col_hi):
         raise ValueError("columns must be sharded contiguously by shard_range(total_cols, world, rank)")
-    L = n_ext // W  # leaves per rank
-    _lib.call("gl_ntt_batch", d_values.ptr, mine, log_n, n, 1, 0, ctx.ptr)
-    d_lde = DeviceBuffer(ctx, mine * n_ext)
-    _lib.call("gl_coset_lde_batch", d_values.ptr, d_lde.ptr, mine, log_n, rate_bits, 7, n, n_ext, ctx.ptr)
-    d_leaves = DeviceBuffer(ctx, total_cols * L)
-    # ONE launch groups, for every rank, the leaf range it hashes of every one of my columns (gl_pack_leaf_ranges); the
-    # slice for rank q is then contiguous: [mine][L] at packed + q * mine * L.
-    d_packed = DeviceBuffer(ctx, W * mine * L)
-    _lib.call("gl_pack_leaf_ranges", d_lde.ptr, n_ext, mine, L, W, d_packed.ptr, ctx.ptr)
-    # my own columns of my own leaf range stay on the device
-    _lib.call("gl_memcpy_d2d", d_leaves.at(col_lo * L), d_packed.at(r * mine * L), 8 * mine * L, ctx.ptr)
-    if W > 1:
-        td, torch = group.td, group.torch
-        on_device = group.backend == "nccl"
-        ops, keep = [], []
-        ctx.synchronize()
-        for q in range(W):
-            if q == r:
-                continue
-            cnt_q = (bounds[q][1] - bounds[q][0]) * L
-            if on_device:
-                # zero copy: RCCL sends from the packed buffer and receives straight into the leaf block of rank q's columns
-                send = device_tensor(torch, d_packed.at(q * mine * L), mine * L, group.device_index)
-                recv = device_tensor(torch, d_leaves.at(bounds[q][0] * L), cnt_q, group.device_index)
-            else:  # gloo: staged through host memory, one copy per peer
-                send = torch.empty(mine * L, dtype=torch.int64)
-                recv = torch.empty(cnt_q, dtype=torch.int64)
-                _lib.call("gl_memcpy_d2h", send.data_ptr(), d_packed.at(q * mine * L), 8 * mine * L, ctx.ptr)
-            keep.append((q, send, recv, cnt_q))
-            ops.append(td.P2POp(td.isend, send, q))
-            ops.append(td.P2POp(td.irecv, recv, q))
-        for req in td.batch_isend_irecv(ops):
-            req.wait()
-        if on_device:
-            torch.cuda.synchronize()
-        else:
-            for q, _, recv, cnt_q in keep:
-                _lib.call("gl_memcpy_h2d", d_leaves.at(bounds[q][0] * L), recv.data_ptr(), 8 * cnt_q, ctx.ptr)
-        ctx.synchronize()
-    d_packed.free()
-    local_cap_height = cap_height - (W.bit_length() - 1)
-    n_dig = 2 * (L - (1 << local_cap_height))
-    d_digests = DeviceBuffer(ctx, 4 * max(n_dig, 1))
-    d_cap = DeviceBuffer(ctx, 4 << local_cap_height)
-    _lib.call("gl_merkle_tree_from_columns", d_leaves.ptr, total_cols, L, L, local_cap_height, d_digests.ptr, d_cap.ptr, ctx.ptr)
-    my_cap = d_cap.download(0, 4 << local_cap_height).reshape(-1, 4)
-    cap = np.concatenate(group.gather_caps(my_cap), axis=0)
-    d_cap.free()
-    return ShardedCommit(d_coeffs=d_values, d_lde=d_lde, d_leaves=d_leaves, d_digests=d_digests, cap=cap, col_lo=col_lo, col_hi=col_hi,
-                         total_cols=total_cols, leaf_lo=r * L, leaves_per_rank=L, digest_lo=r * n_dig, num_digests=n_dig,
-                         local_cap_height=local_cap_height)
+    return plan.commit(d_values)
 
 
 def sharded_open_batch(group, ctx, sc, indices):

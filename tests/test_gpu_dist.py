@@ -75,3 +75,45 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job(gpu, launcher):
     assert d["metric"] and d["unit"] and d["value"] > 0 and d["config"]["ranks"] == 2
     assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
     assert d["extra"]["commit_ms"] > 0 and d["extra"]["prove"]["proofs_per_s_all_gpus"] > 0
+    assert len(d["extra"]["prove"]["proofs_per_s_per_rank"]) == 2 and len(d["extra"]["prove"]["wires_cap0_per_rank"]) == 2
+    assert d["config"]["pairs_per_step"] >= 1 and d["value_windows"]["count"] >= 1
+
+
+def _device_count():
+    import plonky2_gpu_amd as pg
+
+    return pg.load().gl_device_count()
+
+
+def test_two_devices_exchange_over_rccl(gpu):
+    """What a one-GPU box cannot show: the column-sharded commit with each rank on a device of its own and the exchange
+    between device buffers over RCCL/xGMI (zero-copy sends from the pack buffer, receives into the leaf block, chunk by chunk
+    under the LDE), the cap all-gathered over RCCL. Skips on a box with one GPU; runs the day a multi-GPU box runs the suite."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % _device_count())
+    for world, shape in [(2, (135, 16, 3, 4)), (2, (24, 10, 3, 4))] + ([(4, (135, 14, 3, 4))] if _device_count() >= 4 else []):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PLONKY2_DIST_BACKEND="nccl")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29700 + world * 10 + shape[1]), os.path.join(ROOT, "tests", "dist_sharded_commit.py")] + [str(x) for x in shape]
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+        assert p.stdout.count(" ok") == world, p.stdout
+
+
+def test_bench_on_two_devices_synchronises_over_rccl(gpu):
+    """`bench.py --gpus 2` with a device per rank: rank synchronisation and the cap gather go over RCCL ("nccl"), the line reports
+    per-rank proof rates and the gathered caps of the ranks' proofs."""
+    import json
+
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % _device_count())
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-commit"], env=env,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["rank_sync_backend"] == "nccl" and d["config"]["devices_visible"] >= 2
+    pr = d["extra"]["prove"]
+    assert len(pr["proofs_per_s_per_rank"]) == 2 and len(pr["wires_cap0_per_rank"]) == 2

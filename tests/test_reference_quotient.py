@@ -179,16 +179,22 @@ def test_reference_symbol_at_the_size_the_reference_hard_wires(gpu):
                           ed.REFERENCE_PUBLIC_INPUTS_HASH, immediates=pool.values)
     a, b, g = (np.ascontiguousarray(inst[k]) for k in ("alphas", "betas", "gammas"))
     out = pg.DeviceBuffer(gpu, 2 * n_ext)
+    pih_host = np.array(ed.REFERENCE_PUBLIC_INPUTS_HASH, dtype=np.uint64)
     for compiled in (False, True):
+        work = None
         if compiled:
             prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)   # the ed25519 table's code object comes from build()'s cache
+            work = pg.DeviceBuffer(gpu, 2 * n_ext)
         args = _lib.GlQuotientArgs(bufs["wires"].ptr, bufs["cs"].ptr, bufs["zs"].ptr, ed.NUM_WIRES, ed.CONSTANTS_SIGMAS_LEAF_LEN,
                                    ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN, bufs["k_is"].ptr, None, b.ctypes.data, g.ctypes.data, a.ctypes.data,
                                    ed.NUM_CONSTANTS, ed.NUM_ROUTED_WIRES, 2, ed.NUM_GATE_CONSTRAINTS, log_len, ed.RATE_BITS,
-                                   ed.QUOTIENT_DEGREE_FACTOR, ed.COSET_SHIFT, ctypes.pointer(prog.struct), 0,
-                                   prog.kernel if compiled else None, None, None)
+                                   ed.QUOTIENT_DEGREE_FACTOR, ed.COSET_SHIFT, None if compiled else ctypes.pointer(prog.struct), 0,
+                                   prog.kernel if compiled else None, pih_host.ctypes.data if compiled else None,
+                                   work.ptr if compiled else None)
         _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, gpu.ptr)
         assert (out.download().reshape(2, -1) == got).all(), "compiled" if compiled else "interpreted"
+        if work is not None:
+            work.free()
 
     # (2) the oracle, point by point, on a strided sample of the 2^21 LDE points
     gates = prove_ref.base_gates({"gates": ed.GATES})
