@@ -185,6 +185,40 @@ typedef struct GlGateProgram {
     uint64_t public_inputs_hash[4];
 } GlGateProgram;
 
+/* Emitters of the register programs for the gate kinds of the ed25519 gate list, so that a compiled host needs no Python to
+ * describe its circuit: what each gate's eval_unfiltered_base_one computes (plonky2/src/gates/{noop,constant,public_input,
+ * arithmetic_base,base_sum,random_access,poseidon}.rs, u32/src/gates/{add_many_u32,arithmetic_u32,subtraction_u32,
+ * range_check_u32,comparison}.rs), as a program in the encoding above — with the ACC / ACCR accumulators wherever a sum has
+ * small constant weights, and their overflow contract enforced at emission. params by kind:
+ *   NOOP, PUBLIC_INPUT, POSEIDON: none        CONSTANT {num_consts}         ARITHMETIC {num_ops}
+ *   BASE_SUM {B, num_limbs}                   U32_ADD_MANY {num_addends, num_ops}
+ *   U32_ARITHMETIC / U32_SUBTRACTION {num_ops}  U32_RANGE_CHECK {num_input_limbs}
+ *   COMPARISON {num_bits, num_chunks} (chunks of at most 4 bits)   RANDOM_ACCESS {bits, num_copies, num_extra_constants}
+ * gl_gate_programs_emit builds the programs of a whole gate list in circuit order (gate i has selector index
+ * gates[i].selector_index; group_bounds[2 s], group_bounds[2 s + 1] = selectors_info.groups[s], gates/selectors.rs): host arrays
+ * in exactly the form GlCircuitDesc / gl_gate_kernel_build take, immediates deduplicated across the list, num_gate_constraints =
+ * the largest number of constraints of any gate. The arrays are malloc'd by the library: release them with
+ * gl_gate_programs_free. Pure host code: no device is needed. */
+enum GlGateKind {
+    GL_GATE_NOOP = 0, GL_GATE_CONSTANT = 1, GL_GATE_PUBLIC_INPUT = 2, GL_GATE_ARITHMETIC = 3, GL_GATE_BASE_SUM = 4,
+    GL_GATE_U32_ADD_MANY = 5, GL_GATE_U32_ARITHMETIC = 6, GL_GATE_U32_SUBTRACTION = 7, GL_GATE_U32_RANGE_CHECK = 8,
+    GL_GATE_COMPARISON = 9, GL_GATE_RANDOM_ACCESS = 10, GL_GATE_POSEIDON = 11
+};
+typedef struct GlGateSpec {
+    uint32_t kind;      /* GlGateKind */
+    uint32_t params[3];
+    uint32_t selector_index;
+} GlGateSpec;
+typedef struct GlGatePrograms {
+    GlGateInstr *instrs;
+    GlGateDesc *gates;
+    uint64_t *immediates;
+    uint32_t num_instrs, num_gates, num_immediates, num_gate_constraints;
+} GlGatePrograms;
+GlError gl_gate_programs_emit(const GlGateSpec *gates, uint32_t num_gates, const uint32_t *group_bounds, uint32_t num_selectors,
+                              GlGatePrograms *out);
+void gl_gate_programs_free(GlGatePrograms *programs);
+
 /* The same gate programs compiled at run time (hiprtc, gfx950) into a kernel specialised to the circuit:
  * one device function per gate, registers in VGPRs, immediates as literals. Built once per circuit
  * (under a second for a few small gates, about a minute for the 25-gate ed25519 list), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.

@@ -58,6 +58,20 @@ class GlQuotientArgs(ctypes.Structure):
     ]
 
 
+class GlGateSpec(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("params", ctypes.c_uint32 * 3), ("selector_index", ctypes.c_uint32)]
+
+
+class GlGatePrograms(ctypes.Structure):
+    _fields_ = [("instrs", ctypes.c_void_p), ("gates", ctypes.c_void_p), ("immediates", ctypes.c_void_p), ("num_instrs", ctypes.c_uint32),
+                ("num_gates", ctypes.c_uint32), ("num_immediates", ctypes.c_uint32), ("num_gate_constraints", ctypes.c_uint32)]
+
+
+# include/plonky2_hip.h enum GlGateKind, by the names plonky2_gpu_amd/gate_program.py uses
+GATE_KINDS = {"noop": 0, "constant": 1, "public_input": 2, "arithmetic": 3, "base_sum": 4, "u32_add_many": 5, "u32_arithmetic": 6,
+              "u32_subtraction": 7, "u32_range_check": 8, "comparison": 9, "random_access": 10, "poseidon": 11}
+
+
 class GlFriParams(ctypes.Structure):
     _fields_ = [
         ("rate_bits", ctypes.c_uint32),
@@ -137,6 +151,8 @@ SIGNATURES = {
     "gl_coset_lde_batch": (GlError, [_vp, _vp, _u64, _u32, _u32, _u64, _u64, _u64, _vp]),
     "gl_coset_ntt_batch": (GlError, [_vp, _u64, _u32, _u64, _u64, _i, _vp]),
     "gl_permutation_partial_products": (GlError, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "gl_gate_programs_emit": (GlError, [_vp, _u32, _vp, _u32, _vp]),
+    "gl_gate_programs_free": (None, [_vp]),
     "gl_gate_kernel_build": (GlError, [_vp, _u32, _vp, _u32, _vp, _u32, _u32, _u32, _u32, ctypes.POINTER(_vp)]),
     "gl_gate_kernel_destroy": (None, [_vp]),
     "gl_gate_kernel_source": (ctypes.c_char_p, [_vp]),

@@ -1,16 +1,20 @@
-// prove_example.cpp — a compiled host that proves with TWO library calls and no Python: what a Rust
+// prove_example.cpp — a compiled host that proves with THREE library calls and no Python: what a Rust
 // `cuda/`-replacement crate would do through FFI. It reads a circuit + witness
-// file (layout below, written by tests/test_cpp_prove.py), calls gl_circuit_create and gl_prove, and
+// file (layout below, written by tests/test_cpp_prove.py) whose gates are given as plonky2's gate list (kinds and
+// parameters), has the library emit their register programs (gl_gate_programs_emit), calls gl_circuit_create and gl_prove, and
 // writes the proof in the reference's wire format (plonky2/src/util/serialization.rs:674-689).
 //
 // file = little-endian u64 stream:
 //   header[20]: magic 0x706c6f6e6b7932, degree_bits, num_wires, num_routed_wires, num_constants, num_challenges,
 //               quotient_degree_factor, num_gate_constraints, rate_bits, cap_height, proof_of_work_bits,
 //               num_query_rounds, num_reductions, num_selectors, num_gates, num_instrs, num_immediates,
-//               num_public_inputs, compile_gates, reserved
+//               num_public_inputs, compile_gates, gate_list_mode
 //   reduction_arity_bits[num_reductions], k_is[num_routed], constants[num_constants * n], sigmas[num_routed * n],
-//   instrs[num_instrs] (one u64 = {op, dst, a, b} as four u16), gates[num_gates * 3] (six u32),
-//   immediates[num_immediates], wires[num_wires * n], public_inputs[num_public_inputs]
+//   gate_list_mode = 0: instrs[num_instrs] (one u64 = {op, dst, a, b} as four u16), gates[num_gates * 3] (six u32),
+//                       immediates[num_immediates]   — register programs made elsewhere
+//   gate_list_mode = 1: gate_specs[num_gates * 5] (kind, three parameters, selector index), group_bounds[num_selectors * 2]
+//                       — the circuit's GATE LIST; the register programs are emitted here, by gl_gate_programs_emit
+//   wires[num_wires * n], public_inputs[num_public_inputs]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -68,9 +72,28 @@ int main(int argc, char **argv) {
     desc.h_k_is = take(h[3]);
     desc.h_constants = take(h[4] * n);
     desc.h_sigmas = take(h[3] * n);
-    desc.h_instrs = reinterpret_cast<const GlGateInstr *>(take(h[15]));
-    desc.h_gates = reinterpret_cast<const GlGateDesc *>(take(h[14] * 3));
-    desc.h_immediates = take(h[16]);
+    GlGatePrograms programs = {};
+    if (h[19] == 1) {
+        // the gate list of the circuit: kinds and parameters as plonky2 names them; the programs come from the library
+        std::vector<GlGateSpec> specs(h[14]);
+        const uint64_t *sp = take(h[14] * 5);
+        for (uint64_t g = 0; g < h[14]; g++) {
+            specs[g].kind = (uint32_t)sp[5 * g];
+            for (int k = 0; k < 3; k++) specs[g].params[k] = (uint32_t)sp[5 * g + 1 + k];
+            specs[g].selector_index = (uint32_t)sp[5 * g + 4];
+        }
+        std::vector<uint32_t> bounds;
+        for (const uint64_t *p = take(h[13] * 2), *e = p + h[13] * 2; p < e; p++) bounds.push_back((uint32_t)*p);
+        check(gl_gate_programs_emit(specs.data(), (uint32_t)specs.size(), bounds.data(), (uint32_t)h[13], &programs), "gl_gate_programs_emit");
+        if (programs.num_gate_constraints != desc.num_gate_constraints) return fprintf(stderr, "num_gate_constraints: file says %u, the gate list gives %u\n", desc.num_gate_constraints, programs.num_gate_constraints), 1;
+        desc.h_instrs = programs.instrs, desc.num_instrs = programs.num_instrs;
+        desc.h_gates = programs.gates, desc.num_gates = programs.num_gates;
+        desc.h_immediates = programs.immediates, desc.num_immediates = programs.num_immediates;
+    } else {
+        desc.h_instrs = reinterpret_cast<const GlGateInstr *>(take(h[15]));
+        desc.h_gates = reinterpret_cast<const GlGateDesc *>(take(h[14] * 3));
+        desc.h_immediates = take(h[16]);
+    }
     const uint64_t *wires = take(h[2] * n);
     const uint64_t *public_inputs = take(num_public_inputs);
     desc.h_circuit_digest = nullptr;  // derived by the library (circuit_builder.rs:915-927)
@@ -95,6 +118,7 @@ int main(int argc, char **argv) {
     printf("PROOF_BYTES %llu\nDIGEST %llu %llu %llu %llu\n", (unsigned long long)proof_len, (unsigned long long)digest[0],
            (unsigned long long)digest[1], (unsigned long long)digest[2], (unsigned long long)digest[3]);
     gl_bytes_free(proof);
+    gl_gate_programs_free(&programs);
     check(gl_free(d_wires), "gl_free");
     gl_circuit_destroy(circuit);
     gl_ctx_destroy(ctx);
