@@ -10,6 +10,7 @@
 
 #include "../../include/plonky2_hip.h"
 #include "gl_field.h"
+#include "knobs.h"
 #include "merkle.h"
 #include "ntt.h"
 #include "plonk.h"
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void pack_leaf_ranges_kernel(const uint64_t *_
 // side hides most of the LDE. PLONKY2_COMMIT_PIPELINE=0 turns it off (A/B measurements).
 bool commit_pipeline_enabled() {
     static const bool v = [] {
-        const char *e = getenv("PLONKY2_COMMIT_PIPELINE");
+        const char *e = PLONKY2_KNOB("PLONKY2_COMMIT_PIPELINE");
         return !(e && e[0] == '0');
     }();
     return v;

@@ -17,6 +17,7 @@
 // row i, so a wavefront reads 64 consecutive u64 (512 B) of one column per load instruction —
 // fully coalesced without materialising the leaf-major matrix first.
 #include "merkle.h"
+#include "knobs.h"
 
 #include <mutex>
 
@@ -556,7 +557,7 @@ hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64
 // PLONKY2_TRANSPOSE=tile keeps the 64 x 64 tiles (A/B measurements)
 static bool strips_enabled() {
     static const bool v = [] {
-        const char *e = getenv("PLONKY2_TRANSPOSE");
+        const char *e = PLONKY2_KNOB("PLONKY2_TRANSPOSE");
         return !(e && e[0] == 't');
     }();
     return v;

@@ -25,6 +25,7 @@
 //  * The inverse transform is the forward one with the index flip i -> n-i and the n^-1 scale
 //    (fft.rs:92-101) folded into the last pass's store addresses.
 #include "ntt.h"
+#include "knobs.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -310,19 +311,6 @@ constexpr int WIDE_MIN_LOGR = 7;           // wide (16-wave) tiles are instantia
 constexpr int WBUF = EW + EW / 16 + 2;    // padded wave buffer; the skew of 2 words spreads the eight buffers over
                                           // the banks for the cooperative (cross-buffer) accesses
 
-#ifdef PLONKY2_NTT_STAMPS
-// In-kernel stamps (diagnostic build, never the product): every wave adds the shader-clock cycles it spent in each phase of
-// its tile loop; lane 0 adds the totals to p.stamps[phase] at the end. Stamping costs a wait for outstanding LDS / scalar
-// memory operations per stamp, so the phases are slightly serialised compared with the product kernel.
-#define STAMP(k)                                          \
-    do {                                                  \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime(); \
-        stamp_acc[k] += now_ - stamp_last;                \
-        stamp_last = now_;                                \
-    } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
 
 
 // LOGW = log2 of the wavefronts per workgroup: 3 (tile of 8192 elements, two workgroups per CU) or 4 (16384 elements, one
@@ -488,10 +476,6 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
     };
     uint32_t step = 0;
     uint32_t id = tile_at(0);
-#ifdef PLONKY2_NTT_STAMPS
-    uint64_t stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t stamp_last = __builtin_amdgcn_s_memtime();
-#endif
     auto chain_of = [&](uint32_t tile) {
         if constexpr (TWIDDLE) {
             uint32_t b, a, z;
@@ -520,7 +504,6 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
         chain_of(id);
         if (tile_at(1) < total) issue_loads(tile_at(1), pre);
     }
-    STAMP(0);  // prologue: twiddle table, first tile's loads and landing
 
     for (; id < total; id = tile_at(++step)) {
         const uint32_t nid = tile_at(step + 1);
@@ -533,10 +516,7 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
         asm volatile("" : "+v"(tid_i), "+v"(lane_i));
 
         // ---- R-point DIFs of this wave's TW columns, no workgroup barrier ------------------------
-#ifndef PLONKY2_NTT_SKELETON  // diagnostic builds only: the pass without its arithmetic (memory and LDS traffic alone)
         tile_transform<LOGEW, WT, LOGR, TWIDDLE>(data, tw, p, lane_i, b * WAVES + wave, z, TWIDDLE ? chain : nullptr);
-#endif
-        STAMP(1);  // radix rounds
 
         // ---- results: LDS -> registers ----------------------------------------------------------------
         u64x2 res[8];
@@ -563,20 +543,16 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 res[it].y = data[phys(((m + 1) << logtw) + tl, logtw)];
             }
         }
-        STAMP(2);  // barrier (all waves done) + results LDS -> registers
         // the next tile's arrival overwrites buffers that a cooperative load / store lets other waves touch
         if constexpr (!(rows_in && rows_out))
             lds_barrier();
         else
             tile_sync<WT>();
-        STAMP(3);  // barrier (all results read)
 
         // ---- tile k+1 lands ---------------------------------------------------------------------------
         if (nid < total) {
             land(nid, pre);
-            STAMP(4);  // wait for the prefetched loads, registers -> LDS, barrier
             chain_of(nid);
-            STAMP(5);  // twiddle-chain look-ups
         }
 
         // ---- stores of tile k -------------------------------------------------------------------------
@@ -653,61 +629,25 @@ __global__ __launch_bounds__(64 << LOGW) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
             }
         }
-        STAMP(6);  // stores issued
         // ---- loads of tile k+2 ------------------------------------------------------------------------
         if (tile_at(step + 2) < total) issue_loads(tile_at(step + 2), pre);
-        STAMP(7);  // loads issued
-#ifdef PLONKY2_NTT_STAMPS
-        stamp_acc[8] += 1;  // tiles
-#endif
     }
-#ifdef PLONKY2_NTT_STAMPS
-    if (p.stamps && lane == 0)
-        for (int k = 0; k < 9; k++) atomicAdd(reinterpret_cast<unsigned long long *>(p.stamps + k), (unsigned long long)stamp_acc[k]);
-#endif
 }
 
 // PLONKY2_NTT_KERNEL=tile selects the workgroup-tile kernel for every size (A/B measurements, tests of both)
 static bool use_wave_kernel() {
     static const bool v = [] {
-        const char *e = getenv("PLONKY2_NTT_KERNEL");
+        const char *e = PLONKY2_KNOB("PLONKY2_NTT_KERNEL");
         return !(e && e[0] == 't');
     }();
     return v;
 }
 
-#ifdef PLONKY2_NTT_STAMPS
-// three groups of 16 counters (column pass, transposed-store row pass, in-place row pass) in device memory; the file named by
-// PLONKY2_NTT_STAMPS_OUT receives them when the process exits
-static uint64_t *g_stamps = nullptr;
-static void ntt_stamps_dump() {
-    const char *path = getenv("PLONKY2_NTT_STAMPS_OUT");
-    if (!g_stamps || !path) return;
-    uint64_t h[48];
-    if (hipMemcpy(h, g_stamps, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
-    FILE *f = fopen(path, "w");
-    if (!f) return;
-    for (int g = 0; g < 3; g++) {
-        fprintf(f, "{\"pass\": \"%s\"", g == 0 ? "column" : g == 1 ? "row_transposed_store" : "row_in_place");
-        for (int k = 0; k < 9; k++) fprintf(f, ", \"c%d\": %llu", k, (unsigned long long)h[16 * g + k]);
-        fprintf(f, "}\n");
-    }
-    fclose(f);
-}
-static uint64_t *ntt_stamp_buffer(int group) {
-    if (!g_stamps) {
-        if (hipMalloc(&g_stamps, 48 * sizeof(uint64_t)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_stamps, 0, 48 * sizeof(uint64_t));
-        atexit(ntt_stamps_dump);
-    }
-    return g_stamps + 16 * group;
-}
-#endif
 
 // PLONKY2_NTT_DIRECT=0: the wave-tile kernels also where a direct pass exists (A/B measurements)
 static bool direct_mode() {
     static const bool v = [] {
-        const char *e = getenv("PLONKY2_NTT_DIRECT");
+        const char *e = PLONKY2_KNOB("PLONKY2_NTT_DIRECT");
         return !(e && e[0] == '0');
     }();
     return v;
@@ -716,7 +656,7 @@ static bool direct_mode() {
 // PLONKY2_NTT_XCD=0: workgroups walk tiles w, w+G, ... instead of the XCD-aware order (A/B measurements)
 static bool xcd_map_enabled() {
     static const bool v = [] {
-        const char *e = getenv("PLONKY2_NTT_XCD");
+        const char *e = PLONKY2_KNOB("PLONKY2_NTT_XCD");
         return !(e && e[0] == '0');
     }();
     return v;
@@ -728,7 +668,7 @@ static uint32_t persistent_workgroups() {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        if (const char *e = getenv("PLONKY2_NTT_WG_PER_CU")) {
+        if (const char *e = PLONKY2_KNOB("PLONKY2_NTT_WG_PER_CU")) {
             int k = atoi(e);
             if (k >= 1 && k <= 8) return (uint32_t)(cus * k);
         }
@@ -751,12 +691,7 @@ hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t 
     if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t resident = persistent_workgroups() >> (LOGW - 3);  // the LDS holds two 8-wave or one 16-wave workgroup per CU
     const uint32_t wgs = (uint32_t)(total < resident ? total : resident);
-#ifdef PLONKY2_NTT_STAMPS
-    PassParams p = p_in;
-    p.stamps = ntt_stamp_buffer(TWIDDLE ? 0 : (ROWS_OUT ? 2 : 1));
-#else
     const PassParams &p = p_in;
-#endif
     hipLaunchKernelGGL((ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW, SPLIT>), dim3(wgs), dim3(64 << LOGW), lds_bytes, stream, p,
                        (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)total, (uint32_t)(xcd_map_enabled() && wgs % 8 == 0 ? 1 : 0));
     return hipGetLastError();
@@ -880,7 +815,7 @@ static void base_params(PassParams &p, const NttTables &tb) {
 // PLONKY2_NTT_WIDE=0 keeps the 8192-element tiles (A/B measurements).
 static bool wide_ok(uint32_t logr, uint64_t t_limit) {
     static const bool enabled = [] {
-        const char *e = getenv("PLONKY2_NTT_WIDE");
+        const char *e = PLONKY2_KNOB("PLONKY2_NTT_WIDE");
         return !(e && e[0] == '0');
     }();
     return enabled && use_wave_kernel() && logr >= (uint32_t)WIDE_MIN_LOGR && logr <= (uint32_t)LOGEW + 1 &&  // LOGEW + 1: split columns
@@ -948,7 +883,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             chunk = tb.scratch_elems / n;
             if (chunk > 65535) chunk = 65535;
         }
-        if (const char *ev = getenv("PLONKY2_NTT_CHUNK_COLS")) {  // tuning knob (tools/ntt_chunk_sweep.py)
+        if (const char *ev = PLONKY2_KNOB("PLONKY2_NTT_CHUNK_COLS")) {  // tuning knob (tools/ntt_chunk_sweep.py)
             uint64_t c = strtoull(ev, nullptr, 10);
             if (c >= 1 && c < chunk) chunk = c;
         }

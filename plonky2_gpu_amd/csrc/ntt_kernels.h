@@ -34,7 +34,6 @@ struct PassParams {
     uint32_t tw_hi;      // inter-pass twiddle root = w_{2^tw_hi}
     uint32_t cs_hi_len;  // entries per coset in cs_hi
     uint32_t rate_bits;  // F_COSET: blockIdx.z = coset r, written to block bitrev(r)
-    uint64_t *stamps;    // diagnostic builds only (-DPLONKY2_NTT_STAMPS): per-phase cycle totals, see tools/ntt_stamps.py
     uint32_t row_shift;  // inverse natural-order row pass: rotate the row tile by one so that the
                          // flipped 64-byte output segments are aligned (t_limit is a power of two)
 };

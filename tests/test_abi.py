@@ -97,3 +97,19 @@ def test_no_gpu_means_loud_failure(lib):
         pytest.skip("a GPU is visible")
     with pytest.raises(RuntimeError):
         pg.Context(0)
+
+
+def test_the_product_library_has_no_ab_knobs():
+    """The A/B switches of the kernels (csrc/knobs.h) are compiled into the diagnostic build only: the product library does not
+    even contain their names, the diagnostic one does."""
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    product = open(os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip.so"), "rb").read()
+    for knob in (b"PLONKY2_NTT_DIRECT", b"PLONKY2_NTT_KERNEL", b"PLONKY2_NTT_WIDE", b"PLONKY2_NTT_XCD", b"PLONKY2_NTT_WG_PER_CU", b"PLONKY2_NTT_CHUNK_COLS",
+                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE"):
+        assert knob not in product, knob
+    assert b"PLONKY2_HIP_KERNEL_CACHE" in product  # an operational setting, not a knob
+    debug = os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so")
+    if os.path.exists(debug):
+        assert b"PLONKY2_NTT_DIRECT" in open(debug, "rb").read()

@@ -338,5 +338,7 @@ assert (d_r.download(n_rows * n_cols, 128) == guard[:128]).all(), "wrote past th
 print("ok")
 """
     env = dict(os.environ, PLONKY2_TRANSPOSE=kernel)
+    if kernel != "strip":  # knobs exist in the diagnostic build only (csrc/knobs.h)
+        env["PLONKY2_HIP_LIBRARY"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plonky2_gpu_amd", "libplonky2_hip_debug.so")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1000:] + r.stderr[-2000:]

@@ -200,18 +200,24 @@ def test_more_distinct_cosets_than_the_table_cache_holds(gpu, oracle):
         {"PLONKY2_NTT_KERNEL": "tile"},  # workgroup-tile kernel everywhere, three passes from 2^21
         {"PLONKY2_NTT_WIDE": "0"},  # 8192-element tiles only: no 128-byte column pass, no split columns (2^21 in three passes)
         {"PLONKY2_NTT_XCD": "0", "PLONKY2_NTT_WG_PER_CU": "1"},  # plain tile order, one workgroup per CU
+        {"PLONKY2_NTT_DIRECT": "0"},  # the wave-tile kernels also where a direct pass exists (round 2's kernels for 2^16 - 2^20)
+        {"PLONKY2_NTT_DIRECT": "0", "PLONKY2_NTT_CHUNK_COLS": "1"},  # natural order through the workspace one column at a time
     ],
-    ids=["tile-kernel", "narrow-tiles", "plain-order"],
+    ids=["tile-kernel", "narrow-tiles", "plain-order", "wave-tiles", "one-column-chunks"],
 )
 def test_alternative_kernel_selections(gpu, env):
-    """The library picks its pass kernels once per process from the environment (A/B knobs of DESIGN section 3.1); every
-    selection must give the oracle's results. Runs tests/ntt_variant_child.py under each."""
+    """The DIAGNOSTIC build of the library (csrc/knobs.h, libplonky2_hip_debug.so) picks its pass kernels once per process
+    from the environment; every selection must give the oracle's results: the kernels that the product library uses only
+    for ragged tiles, long columns or sizes without a direct pass stay under test at every size. Runs
+    tests/ntt_variant_child.py under each."""
     import os
     import subprocess
     import sys
 
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ntt_variant_child.py")
-    r = subprocess.run([sys.executable, child], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    debug_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plonky2_gpu_amd", "libplonky2_hip_debug.so")
+    assert os.path.exists(debug_lib), "make -C plonky2_gpu_amd/csrc debug (done by __graft_entry__.build())"
+    r = subprocess.run([sys.executable, child], env=dict(os.environ, PLONKY2_HIP_LIBRARY=debug_lib, **env), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
 
 
