@@ -720,6 +720,10 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
     if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false>(p, grid, stream);
     if constexpr (!TWIDDLE) {  // row passes carry no inter-pass twiddle
         if (ri && !ro) return launch_pass_wave_mode<LOGR, false, true, false>(p, grid, stream);
+        if constexpr (LOGR == 10)
+            if (ri && ro && direct_mode() && !(p.flags & (F_NATURAL | F_INVERSE | F_COSET | F_RAW_OUT)) && p.scale == 1 && p.in_m == 1 && p.out_m == 1 &&
+                p.row_shift == 0)
+                return nttk::launch_row_inplace_direct(p, grid, stream);
         if (ri && ro) return launch_pass_wave_mode<LOGR, false, true, true>(p, grid, stream);
     }
     return hipErrorInvalidValue;

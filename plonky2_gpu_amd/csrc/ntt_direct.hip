@@ -554,6 +554,172 @@ hipError_t launch_row_natural_direct_t(const PassParams &p, dim3 grid, hipStream
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row pass in place (bit-reversed output: every pass of the LDE / commit path's last stage), rows of R = 1024 points, one row
+// per wave, no workgroup barrier at all: three exchanges inside the wave through its own 1084-slot buffer.
+//   load as the natural-order row pass (position 64 i + lane) -> radix 16 over i -> twiddle -> E1 (h <-> kA) -> radix 16 over h
+//   -> twiddle w_64^(kB q) -> E2 (lane (kA, kBhi), registers (kBlo, q)) -> radix 4 over q -> E3 into the store layout
+//   (register = position >> 6, lane = position & 63, position = bitrev10(k2)) -> 512 contiguous bytes per store.
+// Slots (8 bytes each; every access of the three exchanges is conflict-free, tests/ntt_direct_inplace_model.py):
+//   E1: 4 kA + 68 h + q        E2: 64 kB + 4 kA + (q ^ (kB >> 2))        E3: (pos & ~3) | ((pos & 3) ^ (pos >> 8))
+// Pipeline: [E1 read .. stores of row k] then [first round of row k+1 -> E1 write] then the loads of row k+2: at the loop
+// back-edge the loads are the youngest vector-memory operations (see the column pass).
+// ---------------------------------------------------------------------------------------------
+struct RowInplaceGeom {
+    static constexpr uint32_t WBUF_BYTES = 1084 * 8;   // per wave
+    static constexpr uint32_t XBYTES = 16 * WBUF_BYTES;
+    static constexpr uint32_t LDS_BYTES = XBYTES + RowGeom::TW1_BYTES + RowGeom::TW2_BYTES;
+};
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_row_inplace_direct_kernel(const PassParams p, const uint32_t rows_total, const uint32_t rows_per_poly, const uint32_t gy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char *TW1 = ldsb + RowInplaceGeom::XBYTES;
+    unsigned char *TW2 = TW1 + RowGeom::TW1_BYTES;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *X = ldsb + wave * RowInplaceGeom::WBUF_BYTES;   // this wave's buffer
+
+    for (uint32_t e = tid; e < 64 * 16; e += 1024) {
+        const uint32_t l = e >> 4, ka = e & 15;
+        *reinterpret_cast<uint64_t *>(TW1 + l * RowGeom::TW1_STRIDE + ka * 8) = p.twh[(ka * l) << 2];
+    }
+    if (tid < 64) {
+        const uint32_t q = tid >> 4, kb = tid & 15;
+        *reinterpret_cast<uint64_t *>(TW2 + q * RowGeom::TW2_STRIDE + kb * 8) = p.twh[(kb * q) << 6];
+    }
+
+    // which rows this wave walks: row u of the launch = (z, a, row inside the polynomial), row fastest
+    const uint32_t W = gridDim.x * 16;
+    const uint32_t u0 = blockIdx.x * 16 + wave;
+    const uint32_t n_rows = u0 < rows_total ? (rows_total - u0 + W - 1) / W : 0;
+    auto row_ptr = [&](uint32_t k, bool out) -> uint64_t {
+        const uint32_t u = u0 + k * W;
+        const uint32_t row = u % rows_per_poly, r2 = u / rows_per_poly, a = r2 % gy, z = r2 / gy;
+        return out ? a * p.out_sa + z * p.out_sz + (uint64_t)row * p.out_t : a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t;
+    };
+
+    const uint32_t q = lane & 3, hi4 = lane >> 2;
+    const uint32_t tw1_base = lane * RowGeom::TW1_STRIDE, tw2_base = q * RowGeom::TW2_STRIDE;
+    const uint32_t e1w = (hi4 * 68 + q) * 8;        // + kA * 32
+    const uint32_t e1r = (hi4 * 4 + q) * 8;         // lane = (kA', q): + h * 544; E2 writes at + kB * 512 with q swizzled
+    const uint32_t e2w0 = hi4 * 32;                 // + kB * 512 + ((q ^ (kB >> 2)) * 8)
+    auto opaque_lane = [&]() {
+        uint32_t l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+
+    uint64_t A[16], B[16];
+    auto issue_loads = [&](uint32_t k) {
+        const uint64_t *base = p.src + row_ptr(k, false);
+        const uint32_t off = opaque_lane() * 8;
+        static_for<0, 16>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            A[i] = g_ld(base, off + i * 512);
+        });
+    };
+    // radix 16 over i on A, twiddle, E1 write
+    auto first_round = [&]() {
+        radix_dif<4, 0>(A);
+        static_for<1, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int ka = brev_c(s, 4);
+            A[s] = gl::mul(A[s], lds_ld(TW1, tw1_base + ka * 8));
+        });
+        static_for<0, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int ka = brev_c(s, 4);
+            lds_st(X, e1w + ka * 32, A[s]);
+        });
+        tile_sync<64>();
+    };
+    // everything after E1 of the row whose first round is in the buffer, up to its stores
+    auto rest_of_row = [&](uint32_t k) {
+        static_for<0, 16>([&](auto H_) {
+            constexpr int h = decltype(H_)::value;
+            B[h] = lds_ld(X, e1r + h * 544);
+        });
+        tile_sync<64>();
+        radix_dif<4, 0>(B);
+        static_for<0, 16>([&](auto S_) {
+            constexpr int s = decltype(S_)::value;
+            constexpr int kb = brev_c(s, 4);
+            uint64_t val = B[s];
+            if constexpr (kb != 0) val = gl::mul(val, lds_ld(TW2, tw2_base + kb * 8));
+            lds_st(X, e2w0 + kb * 512 + ((q ^ (uint32_t)(kb >> 2)) * 8), val);
+        });
+        tile_sync<64>();
+        {
+            // lane = (kA, kBhi): registers (kBlo, q) from slot 64 (4 kBhi + kBlo) + 4 kA + (q ^ kBhi)
+            const uint32_t l = opaque_lane();
+            const uint32_t kbhi = l & 3, base = (l >> 2) * 32 + kbhi * 2048;
+            static_for<0, 16>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;
+                B[r] = lds_ld(X, base + (r >> 2) * 512 + (((uint32_t)(r & 3) ^ kbhi) * 8));
+            });
+        }
+        tile_sync<64>();
+        static_for<0, 4>([&](auto J_) { radix_dif<2, decltype(J_)::value * 4>(B); });
+        {
+            // E3 write: position = bitrev4(kA) * 64 + bitrev2(kBlo) * 16 + bitrev2(kBhi) * 4 + s2, slot low bits ^ (position >> 8)
+            const uint32_t l = opaque_lane();
+            const uint32_t ka = l >> 2, kbhi = l & 3;
+            const uint32_t pa = brev_rt(ka, 4), sw = pa >> 2;
+            const uint32_t base = (pa * 64 + brev_rt(kbhi, 2) * 4) * 8;
+            static_for<0, 16>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;
+                constexpr uint32_t kblo = r >> 2, s2 = r & 3;
+                lds_st(X, base + brev_c(kblo, 2) * 128 + ((s2 ^ sw) * 8), gl::canon(B[r]));
+            });
+        }
+        tile_sync<64>();
+        {
+            const uint32_t l = opaque_lane();
+            uint64_t *obase = p.dst + row_ptr(k, true);
+            static_for<0, 16>([&](auto R_) {
+                constexpr int r = decltype(R_)::value;   // position >> 6
+                const uint32_t slot = r * 64 + (l & ~3u) + ((l & 3) ^ (uint32_t)(r >> 2));
+                const uint64_t v = lds_ld(X, slot * 8);
+                g_st(obase, l * 8 + r * 512, v);
+            });
+        }
+        tile_sync<64>();
+    };
+
+    lds_barrier();  // tables
+    if (n_rows == 0) return;
+    issue_loads(0);
+    first_round();
+    if (n_rows > 1) issue_loads(1);
+#pragma unroll 1
+    for (uint32_t k = 0; k < n_rows; k++) {
+        rest_of_row(k);
+        if (k + 1 < n_rows) {
+            first_round();
+            if (k + 2 < n_rows) issue_loads(k + 2);
+        }
+    }
+}
+
+hipError_t launch_row_inplace_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_row_inplace_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowInplaceGeom::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t rows_total = (uint64_t)p.t_limit * grid.y * grid.z;
+    if (rows_total == 0) return hipSuccess;
+    if (rows_total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t need = (rows_total + 15) / 16;
+    const uint32_t wgs = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
+    hipLaunchKernelGGL(ntt_row_inplace_direct_kernel, dim3(wgs), dim3(1024), RowInplaceGeom::LDS_BYTES, stream, p, (uint32_t)rows_total, p.t_limit, (uint32_t)grid.y);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream) {
@@ -566,6 +732,8 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
     }
 }
 
+
+hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream) { return launch_row_inplace_direct_t(p, grid, stream); }
 
 hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t stream) {
     return (p.flags & F_INVERSE) ? launch_row_natural_direct_t<true>(p, grid, stream) : launch_row_natural_direct_t<false>(p, grid, stream);

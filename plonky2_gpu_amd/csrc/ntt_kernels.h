@@ -145,6 +145,9 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
 // Row pass of 1024-point rows with natural-order (transposed) output on tiles of SIXTEEN rows: the planner lays the pass out
 // with logt = 4 (in_sb = 16 rows, out_sb = 16); forward and inverse (index flip, row_shift).
 hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t stream);
+// Row pass of 1024-point rows IN PLACE (bit-reversed output), any tile geometry of the planner: the rows are
+// src + a * in_sa + z * in_sz + row * in_t for row < t_limit, a < grid.y, z < grid.z (in_m == 1), written to the same place in dst.
+hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream);
 
 }  // namespace nttk
 }  // namespace plonky2_hip
