@@ -355,6 +355,16 @@ __global__ __launch_bounds__(256) void pack_leaf_ranges_kernel(const uint64_t *_
 // lower-priority stream absorbs the finished chunks into the leaves' sponges (hash_leaves_chunk). The LDE passes are
 // latency-bound and leave half of the vector ALU idle; the hashing is ALU-bound: running them side by
 // side hides most of the LDE. PLONKY2_COMMIT_PIPELINE=0 turns it off (A/B measurements).
+// The leaf-major copy of a commit is written by the leaf-hashing lanes themselves (merkle.h); PLONKY2_FUSED_LEAVES=0 (diagnostic
+// build) goes back to the separate transposition on stream2.
+bool fused_leaves_enabled() {
+    static const bool v = [] {
+        const char *e = PLONKY2_KNOB("PLONKY2_FUSED_LEAVES");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 bool commit_pipeline_enabled() {
     static const bool v = [] {
         const char *e = PLONKY2_KNOB("PLONKY2_COMMIT_PIPELINE");
@@ -414,6 +424,15 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         // the hash stream starts behind whatever the caller has queued (the buffers may still be in use by earlier work)
         HIP_TRY(hipEventRecord((*evs)[n_chunks], s->stream));
         HIP_TRY(hipStreamWaitEvent(hs, (*evs)[n_chunks], 0));
+        const bool fused = d_leaves && fused_leaves_enabled();
+        if (fused) {
+            // d_leaves may still be read by what the caller queued on stream2 (the reference's caller has its D2H of the
+            // coefficients there, oracle.rs:403-407, and region A is overwritten by the leaves, plonky2_gpu.cu:586)
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            HIP_TRY(get_events(&ev_a, &ev_b));
+            HIP_TRY(hipEventRecord(ev_a, s->stream2));
+            HIP_TRY(hipStreamWaitEvent(hs, ev_a, 0));
+        }
         // A launch that starts in the middle of the leaf (c0 != 0) carries only the capacity, so its first block must be a
         // full one: if the last chunk (with the salt columns and a trailing partial block) would be shorter than a rate
         // block, the chunk before it is not absorbed on its own but together with the last.
@@ -428,11 +447,12 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
             HIP_TRY(hipStreamWaitEvent(hs, (*evs)[c], 0));
             if (!last && merge_last_two && c + 2 == n_chunks) continue;
             const uint64_t upto = last ? leaf_len : c1;  // the last launch also takes the salt columns (already in d_lde)
-            HIP_TRY(hash_leaves_chunk(d_lde, (uint32_t)absorbed, (uint32_t)upto, leaf_len, n_ext, n_ext, cap_height, d_digests, d_cap, hs));
+            HIP_TRY(hash_leaves_chunk(d_lde, (uint32_t)absorbed, (uint32_t)upto, leaf_len, n_ext, n_ext, cap_height, d_digests, d_cap, hs,
+                                      fused ? d_leaves : nullptr));
             absorbed = upto;
         }
         hipEvent_t ev_lde2 = nullptr, ev_tr2 = nullptr;
-        if (d_leaves) {
+        if (d_leaves && !fused) {
             HIP_TRY(get_events(&ev_lde2, &ev_tr2));
             HIP_TRY(hipEventRecord(ev_lde2, s->stream));
             HIP_TRY(hipStreamWaitEvent(s->stream2, ev_lde2, 0));
@@ -442,7 +462,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         HIP_TRY(merkle_tree_layers(d_digests, d_cap, n_ext, cap_height, hs));
         HIP_TRY(hipEventRecord((*evs)[n_chunks + 1], hs));
         HIP_TRY(hipStreamWaitEvent(s->stream, (*evs)[n_chunks + 1], 0));  // the caller's stream continues after the tree
-        if (d_leaves) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr2, 0));
+        if (d_leaves && !fused) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr2, 0));
         return ok();
         };
         GlError r = pipelined();
@@ -454,7 +474,12 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     }
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_lde, poly_num, n, n_ext, s->stream));
     hipEvent_t ev_lde = nullptr, ev_tr = nullptr;
-    if (d_leaves) {
+    const bool fused = d_leaves && fused_leaves_enabled();
+    if (fused) {
+        HIP_TRY(get_events(&ev_lde, &ev_tr));  // stream2's earlier work (see above) before d_leaves is written
+        HIP_TRY(hipEventRecord(ev_lde, s->stream2));
+        HIP_TRY(hipStreamWaitEvent(s->stream, ev_lde, 0));
+    } else if (d_leaves) {
         // The leaf-major copy is pure HBM traffic and the Poseidon hashing pure integer ALU work:
         // run the transpose on stream2, concurrently with the tree on stream. It starts after the LDE
         // (event) and after whatever the caller queued on stream2 before this call — the reference's
@@ -468,8 +493,8 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         HIP_TRY(hipEventRecord(ev_tr, s->stream2));
     }
     HIP_TRY(merkle_tree_from_columns(d_lde, (uint32_t)(poly_num + salt_size), n_ext, n_ext, cap_height, d_digests, d_cap,
-                                     s->stream));
-    if (d_leaves) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr, 0));
+                                     s->stream, fused ? d_leaves : nullptr));
+    if (d_leaves && !fused) HIP_TRY(hipStreamWaitEvent(s->stream, ev_tr, 0));
     return ok();
 }
 

@@ -7,13 +7,15 @@ namespace plonky2_hip {
 
 // MerkleTree::new over leaves given column-major: cols[j*col_stride + i] = element j of leaf i.
 // digests: 4*2*(n_leaves - 2^cap_height) u64 in the reference layout; cap: 4*2^cap_height u64.
+// rows (optional): the leaf-major copy rows[i*leaf_len + j], written by the hashing lanes as they absorb (each lane has its
+// leaf's elements in registers anyway; the 8-byte stores of a rate block are merged in L2 and cost the ALU-bound kernel nothing).
 hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream);
+                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows = nullptr);
 // The leaf hashing of merkle_tree_from_columns cut at column boundaries: absorbs columns [c0, c1) of every leaf (c0 a
 // multiple of 8; c1 - c0 a multiple of 8 unless c1 == leaf_len); the sponge's capacity travels between launches in the leaf's
 // digest slot, the launch with c1 == leaf_len leaves the digest there. Then merkle_tree_layers builds the tree above.
 hipError_t hash_leaves_chunk(const uint64_t *cols, uint32_t c0, uint32_t c1, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream);
+                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows = nullptr);
 hipError_t merkle_tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t cap_height, hipStream_t stream);
 // Same for leaf-major rows[i*leaf_len + j].
 hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,

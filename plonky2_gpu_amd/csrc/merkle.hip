@@ -49,29 +49,40 @@ __device__ __forceinline__ uint64_t digest_slot(uint64_t idx, uint32_t L) {
 __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__restrict__ cols, uint32_t leaf_len,
                                                           uint64_t n_leaves, uint64_t col_stride,
                                                           uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
-                                                          uint32_t log_sub_leaves) {
+                                                          uint32_t log_sub_leaves, uint64_t *__restrict__ rows) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     uint64_t s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
+    uint64_t *row = rows ? rows + i * leaf_len : nullptr;  // the leaf-major copy, written by the lane that holds the leaf anyway
     if (leaf_len <= 4) {
         // not hashed: copied, zero padded, canonicalised by store_hash (config.rs:57-63)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if ((uint32_t)k < leaf_len) s[k] = cols[(uint64_t)k * col_stride + i];
+            if ((uint32_t)k < leaf_len) {
+                s[k] = cols[(uint64_t)k * col_stride + i];
+                if (row) row[k] = s[k];
+            }
     } else {
         uint32_t j = 0;
         for (; j + 8 <= leaf_len; j += 8) {
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+            if (row) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) row[j + k] = s[k];
+            }
             poseidon::permute(s);
         }
         if (j < leaf_len) {
             // short last chunk overwrites only its own lanes (hashing.rs:89-92)
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (j + k < leaf_len) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+                if (j + k < leaf_len) {
+                    s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+                    if (row) row[j + k] = s[k];
+                }
             poseidon::permute(s);
         }
     }
@@ -93,9 +104,10 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
 __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *__restrict__ cols, uint32_t c0, uint32_t c1,
                                                                 uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
                                                                 uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
-                                                                uint32_t log_sub_leaves) {
+                                                                uint32_t log_sub_leaves, uint64_t *__restrict__ rows) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
+    uint64_t *row = rows ? rows + i * leaf_len : nullptr;
     uint64_t *slot;
     if (log_sub_leaves == 0) {
         slot = cap + 4 * i;
@@ -115,6 +127,10 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
     for (; j + 8 <= c1; j += 8) {
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+        if (row) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) row[j + k] = s[k];
+        }
         poseidon::permute(s);
     }
     if (c1 == leaf_len) {
@@ -124,7 +140,10 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
             // have — the host never makes such a chunk (see merkle_tree_from_columns_chunked)
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (j + k < leaf_len) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+                if (j + k < leaf_len) {
+                    s[k] = cols[(uint64_t)(j + k) * col_stride + i];
+                    if (row) row[j + k] = s[k];
+                }
             poseidon::permute(s);
         }
         store_hash(slot, s);
@@ -487,25 +506,25 @@ static int log2_exact(uint64_t n) {
 }
 
 hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream) {
+                                    uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows) {
     int lg = log2_exact(n_leaves);
     if (lg < 0 || (int)cap_height > lg) return hipErrorInvalidValue;
     uint32_t log_sub = lg - cap_height;
     hipLaunchKernelGGL(hash_leaves_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, cols, leaf_len, n_leaves,
-                       col_stride, digests, cap, log_sub);
+                       col_stride, digests, cap, log_sub, rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return tree_layers(digests, cap, n_leaves, log_sub, stream);
 }
 
 hipError_t hash_leaves_chunk(const uint64_t *cols, uint32_t c0, uint32_t c1, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream) {
+                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows) {
     int lg = log2_exact(n_leaves);
     if (lg < 0 || (int)cap_height > lg || leaf_len <= 4 || (c0 & 7) || c0 >= c1 || c1 > leaf_len) return hipErrorInvalidValue;
     if (c1 != leaf_len && ((c1 - c0) & 7)) return hipErrorInvalidValue;       // inner chunks are whole rate blocks
     if (c1 == leaf_len && (leaf_len & 7) && c1 - c0 < 8 && c0 != 0) return hipErrorInvalidValue;  // see the kernel
     hipLaunchKernelGGL(hash_leaves_chunk_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, cols, c0, c1, leaf_len, n_leaves,
-                       col_stride, digests, cap, (uint32_t)(lg - cap_height));
+                       col_stride, digests, cap, (uint32_t)(lg - cap_height), rows);
     return hipGetLastError();
 }
 

@@ -8,4 +8,5 @@ run() { tag=$1; shift; env "$@" timeout 1500 python3 -m pytest tests -x -q -m gp
 run tile PLONKY2_HIP_LIBRARY=$DBG PLONKY2_NTT_KERNEL=tile
 run wave_tiles PLONKY2_HIP_LIBRARY=$DBG PLONKY2_NTT_DIRECT=0
 run narrow_nopipe PLONKY2_HIP_LIBRARY=$DBG PLONKY2_NTT_WIDE=0 PLONKY2_COMMIT_PIPELINE=0
+run separate_leaves PLONKY2_HIP_LIBRARY=$DBG PLONKY2_FUSED_LEAVES=0
 run plain_wg1 PLONKY2_HIP_LIBRARY=$DBG PLONKY2_NTT_XCD=0 PLONKY2_NTT_WG_PER_CU=1
