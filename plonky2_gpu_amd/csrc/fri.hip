@@ -71,18 +71,18 @@ __global__ __launch_bounds__(256) void reduce_polys_base_kernel(const uint64_t *
                                                                 const uint64_t *__restrict__ pw, uint64_t n, uint64_t *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    poseidon::DotAcc a, b;
+    gl::DotAcc a, b;
     for (uint32_t j = 0; j < m; j++) {
         uint64_t c = polys[j][i];
         uint64_t pa = uniform64(pw[2 * j]), pb = uniform64(pw[2 * j + 1]);
         // the hazard recognizer does not look inside inline asm: v_readfirstlane (VALU writes SGPR) must be
         // two wait states away from dot_term's first VALU read of that SGPR
         asm volatile("s_nop 2" : "+s"(pa), "+s"(pb));
-        poseidon::dot_term(a, c, pa);
-        poseidon::dot_term(b, c, pb);
+        gl::dot_term(a, c, pa);
+        gl::dot_term(b, c, pb);
     }
-    out[i] = gl::canon(poseidon::dot_finish(a));
-    out[n + i] = gl::canon(poseidon::dot_finish(b));
+    out[i] = gl::canon(gl::dot_finish(a));
+    out[n + i] = gl::canon(gl::dot_finish(b));
 }
 
 // two-level power tables of z: lo[e] = z^e (e < 1024), hi[e] = z^(1024 e) (e < hi_len); 2 u64 per entry
@@ -211,8 +211,10 @@ struct PowState {
 // candidates base .. base + count: smallest one whose response has enough leading zeros (atomicMin)
 __global__ __launch_bounds__(256) void pow_kernel(PowState st, uint32_t pos, uint32_t min_leading_zeros, uint64_t base, uint64_t count,
                                                   unsigned long long *best) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= count) return;
+    const bool live = g < count;  // whole waves to the end (poseidon.h): lanes past the end try the last candidate once more
+    if (!live) g = count - 1;
     uint64_t cand = base + g;
     uint64_t s[12];
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void pow_kernel(PowState st, uint32_t pos, uin
 #pragma unroll
     for (int k = 0; k < 12; k++)
         if ((uint32_t)k == pos) s[k] = cand;
-    poseidon::permute(s);
+    poseidon::permute(s, ops);
     uint64_t resp = gl::canon(s[7]);  // duplex_state[SPONGE_RATE - 1]
     uint32_t lz = resp ? (uint32_t)__clzll((long long)resp) : 64u;
     if (lz >= min_leading_zeros) atomicMin(best, (unsigned long long)cand);

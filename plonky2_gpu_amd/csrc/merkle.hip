@@ -50,12 +50,16 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
                                                           uint64_t n_leaves, uint64_t col_stride,
                                                           uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
                                                           uint32_t log_sub_leaves, uint64_t *__restrict__ rows) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_leaves) return;
+    // every lane stays in step to the end (poseidon.h: the matrix instructions want whole waves): lanes past the end hash the
+    // last leaf once more and store nothing
+    const bool live = i < n_leaves;
+    if (!live) i = n_leaves - 1;
     uint64_t s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
-    uint64_t *row = rows ? rows + i * leaf_len : nullptr;  // the leaf-major copy, written by the lane that holds the leaf anyway
+    uint64_t *row = rows && live ? rows + i * leaf_len : nullptr;  // the leaf-major copy, written by the lane that holds the leaf anyway
     if (leaf_len <= 4) {
         // not hashed: copied, zero padded, canonicalised by store_hash (config.rs:57-63)
 #pragma unroll
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
 #pragma unroll
                 for (int k = 0; k < 8; k++) row[j + k] = s[k];
             }
-            poseidon::permute(s);
+            poseidon::permute(s, ops);
         }
         if (j < leaf_len) {
             // short last chunk overwrites only its own lanes (hashing.rs:89-92)
@@ -83,9 +87,10 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
                     s[k] = cols[(uint64_t)(j + k) * col_stride + i];
                     if (row) row[j + k] = s[k];
                 }
-            poseidon::permute(s);
+            poseidon::permute(s, ops);
         }
     }
+    if (!live) return;
     if (log_sub_leaves == 0) {
         store_hash(cap + 4 * i, s);
     } else {
@@ -105,9 +110,11 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
                                                                 uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
                                                                 uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
                                                                 uint32_t log_sub_leaves, uint64_t *__restrict__ rows) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_leaves) return;
-    uint64_t *row = rows ? rows + i * leaf_len : nullptr;
+    const bool live = i < n_leaves;  // see hash_leaves_kernel
+    if (!live) i = n_leaves - 1;
+    uint64_t *row = rows && live ? rows + i * leaf_len : nullptr;
     uint64_t *slot;
     if (log_sub_leaves == 0) {
         slot = cap + 4 * i;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
 #pragma unroll
             for (int k = 0; k < 8; k++) row[j + k] = s[k];
         }
-        poseidon::permute(s);
+        poseidon::permute(s, ops);
     }
     if (c1 == leaf_len) {
         if (j < leaf_len) {
@@ -144,10 +151,10 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
                     s[k] = cols[(uint64_t)(j + k) * col_stride + i];
                     if (row) row[j + k] = s[k];
                 }
-            poseidon::permute(s);
+            poseidon::permute(s, ops);
         }
-        store_hash(slot, s);
-    } else {
+        if (live) store_hash(slot, s);
+    } else if (live) {
         reinterpret_cast<u64x2 *>(slot)[0] = u64x2{s[8], s[9]};
         reinterpret_cast<u64x2 *>(slot)[1] = u64x2{s[10], s[11]};
     }
@@ -157,8 +164,10 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
 __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restrict__ rows, uint32_t leaf_len,
                                                         uint64_t n_leaves, uint64_t *__restrict__ digests,
                                                         uint64_t *__restrict__ cap, uint32_t log_sub_leaves) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_leaves) return;
+    const bool live = i < n_leaves;  // see hash_leaves_kernel
+    if (!live) i = n_leaves - 1;
     const uint64_t *row = rows + i * leaf_len;
     uint64_t s[12];
 #pragma unroll
@@ -172,15 +181,16 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restri
         for (; j + 8 <= leaf_len; j += 8) {
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = row[j + k];
-            poseidon::permute(s);
+            poseidon::permute(s, ops);
         }
         if (j < leaf_len) {
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (j + k < leaf_len) s[k] = row[j + k];
-            poseidon::permute(s);
+            poseidon::permute(s, ops);
         }
     }
+    if (!live) return;
     if (log_sub_leaves == 0) {
         store_hash(cap + 4 * i, s);
     } else {
@@ -194,8 +204,10 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restri
 // Thread g handles pair q = g mod pairs_per_sub of subtree g / pairs_per_sub at layer L.
 __global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
                                                          uint32_t L, uint32_t log_sub_leaves, uint64_t total_pairs) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_pairs) return;
+    const bool live = g < total_pairs;  // see hash_leaves_kernel
+    if (!live) g = total_pairs - 1;
     uint32_t log_pairs = log_sub_leaves - L - 1;
     uint64_t sub = g >> log_pairs, q = g & ((1ull << log_pairs) - 1);
     uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
@@ -206,7 +218,8 @@ __global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ 
     s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y;
     s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
     s[8] = s[9] = s[10] = s[11] = 0;
-    poseidon::permute(s);
+    poseidon::permute(s, ops);
+    if (!live) return;
     if (log_pairs == 0)
         store_hash(cap + 4 * sub, s);
     else
@@ -214,15 +227,33 @@ __global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void permute_batch_kernel(uint64_t *states, uint64_t count) {
+    const poseidon::MdsOperands ops = poseidon::mds_operands();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < count;  // see hash_leaves_kernel
+    if (!live) i = count - 1;
+    uint64_t s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
+    poseidon::permute(s, ops);
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
+}
+
+#ifdef PLONKY2_DEBUG_KNOBS
+// The diagnostic build answers gl_poseidon_permute_batch from the vector-ALU permutation under PLONKY2_POSEIDON=vector: the second,
+// independent implementation (poseidon_vector.h) that tests/test_gpu_merkle.py holds against the matrix-core one.
+__global__ __launch_bounds__(256) void permute_batch_vector_kernel(uint64_t *states, uint64_t count) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint64_t s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = states[i * 12 + k];
-    poseidon::permute(s);
+    poseidon_vector::permute(s);
 #pragma unroll
     for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
 }
+#endif
 
 // The transcript's sponge (iop/challenger.rs:131-149 run over several full rate blocks): serial by
 // definition, so ONE wavefront computes each permutation cooperatively (poseidon_coop.h); state[0..8)
@@ -548,6 +579,16 @@ hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64
 
 hipError_t poseidon_permute_batch(uint64_t *states, uint64_t count, hipStream_t stream) {
     if (count == 0) return hipSuccess;
+#ifdef PLONKY2_DEBUG_KNOBS
+    static const bool vector_alu = [] {
+        const char *e = PLONKY2_KNOB("PLONKY2_POSEIDON");
+        return e && e[0] == 'v';
+    }();
+    if (vector_alu) {
+        hipLaunchKernelGGL(permute_batch_vector_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, states, count);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(permute_batch_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, states, count);
     return hipGetLastError();
 }

@@ -1,150 +1,148 @@
 // poseidon.h — Poseidon permutation over Goldilocks (width 12, 4+22+4 rounds, x^7) for gfx950.
 //
-// Same permutation as Poseidon::poseidon (plonky2/src/hash/poseidon.rs:602-616) with the "fast"
-// partial rounds (poseidon.rs:312-365, 400-427), restructured in blocks of eleven rounds (see
-// partial_rounds). One thread owns one permutation; the 12-word state lives in 24 VGPRs for the whole
-// permutation, inner loops are unrolled so table indices are uniform and the constants arrive as
-// s_load / literals, not per-lane loads.
-// Integer modular arithmetic only — no MFMA use is possible or attempted.
+// Same permutation as Poseidon::poseidon (plonky2/src/hash/poseidon.rs:602-616), computed the way `poseidon_naive`
+// (poseidon.rs:565-585) states it: thirty rounds of constant layer, s-box layer (all twelve elements in rounds 0-3 and 26-29,
+// element 0 in the 22 rounds between) and MDS layer (poseidon.rs:174-194, 238-260, 484-493). One thread owns one permutation;
+// the 12-word state lives in 24 VGPRs throughout.
+//
+// The MDS layer runs on the MATRIX CORES — as an integer product, the only use this code base has for them.
+// state' = (circ(C) + diag(D)) state with C[i] <= 41: split every state word into its eight bytes and the layer is eight
+// independent 12 x 12 products of small integers, one per byte plane, recombined with weights 2^(8b):
+//     plane_b[r] = sum_j M[r][j] * byte_b(s_j)  <=  256 * 255 < 2^16        (every row of circ(C) sums to 256)
+// `v_mfma_i32_16x16x64_i8` multiplies a 16 x 64 by a 64 x 16 matrix of signed bytes; lane l supplies 16 consecutive k of column
+// l & 15 — k-group l >> 4 — and receives rows 4 (l >> 4) .. + 3 of that column. The four lanes that share a column therefore
+// feed DIFFERENT k-groups and read DIFFERENT rows: with an A operand that is block-diagonal over the four groups (rows
+// 4g .. 4g+3 non-zero only in k-group g) each lane's sixteen bytes meet four rows of the MDS matrix and the four results come
+// back to the very same lane. No state moves between lanes; three instructions (row blocks 0-3, 4-7, 8-11) per byte plane,
+// 24 per layer, 16 cycles each on a pipe the vector ALU does not wait for. What the vector ALU still does per layer:
+//   * 4 x 4 byte transpositions (v_perm_b32) so that one dword holds the same byte of four state words, and ^ 0x80 because
+//     the matrix cores read SIGNED bytes (byte - 128; the accumulator input C = 128 * 256 puts the offset back),
+//   * per output word: pack the eight 16-bit plane sums into four dwords (planes 0|2, 1|3, 4|6, 5|7), two multiply-adds
+//     (x 256) to make the two 64-bit column sums of gl::fold96, and the reduction. The high dword of each sum's register pair
+//     has to be initialised anyway: the NEXT layer's additive constant rides there as (X, Y) with
+//     X 2^32 + Y 2^64 = c (mod p)  (tools/gen_poseidon_limb_tables.py solve_xy),
+//   * the one diagonal entry (8 * s_0), two multiply-adds.
+// 242 vector instructions per layer instead of 288 multiply-adds + 100: 34 against 54 us per layer and 2^22 states
+// (tools/experiments/mds_mfma.hip, profiles/r03_poseidon_matrix_cores.jsonl).
+//
+// The matrix instruction reads and writes ALL 64 lanes' registers whatever EXEC says, and the A operand of lane l serves the
+// lanes of its group: a kernel must build MdsOperands, and keep calling permute, with every lane of the wave active (clamp
+// indices and predicate the stores instead of returning early). permute() traps when that is not so.
 #pragma once
-#include "gl_field.h"
-
-#define POSEIDON_CONST __device__ const
-#include "poseidon_constants.h"
-#include "poseidon_limb_constants.h"
+#include "poseidon_vector.h"
 
 namespace poseidon {
 
-constexpr int W = 12;
-constexpr int HALF_FULL = 4;
-constexpr int N_PARTIAL = 22;
+using poseidon_vector::HALF_FULL;
+using poseidon_vector::N_PARTIAL;
+using poseidon_vector::W;
 
-// MDS layer, state' = (circ(C) + diag(D)) * state  (poseidon.rs:174-194, 238-260), plus the NEXT
-// layer's additive constants `rc_next` (constant_layer of the following round, poseidon.rs:484-493, or
-// partial_first_constant_layer, :312-320): they ride on the accumulators' initial values for free.
-// All C[i] <= 41 and D[0] = 8, so each row is accumulated exactly in two u64 lanes (low and high
-// 32-bit halves of the state words; 2^32 + 12*41*2^32 < 2^42) and reduced once.
-__device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const uint64_t *__restrict__ rc_next) {
-    uint64_t lo[W], hi[W];
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+struct MdsOperands {
+    v4i32 A[3];  // row blocks 0-3, 4-7, 8-11 of the MDS matrix, block-diagonal over the k-groups
+    v4i32 C;     // 128 * (row sum) in every element
+};
+
+// Pure function of the lane number; call it before anything diverges.
+__device__ __forceinline__ MdsOperands mds_operands() {
+    constexpr uint32_t ROW_WORDS[12] = POSEIDON_MDS_ROW_WORDS;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t m = lane & 15, g = lane >> 4, v = m & 3;
+    const bool on = (m >> 2) == g;
+    MdsOperands o;
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-        lo[i] = s[i] & 0xFFFFFFFFull;
-        hi[i] = s[i] >> 32;
-    }
+    for (int R = 0; R < 3; R++) {
 #pragma unroll
-    for (int r = 0; r < W; r++) {
-        const uint64_t rc = rc_next[r];
-        uint64_t al = rc & 0xFFFFFFFFull, ah = rc >> 32;
-#pragma unroll
-        for (int i = 0; i < W; i++) {
-            al += lo[(i + r) % W] * POSEIDON_MDS_CIRC[i];
-            ah += hi[(i + r) % W] * POSEIDON_MDS_CIRC[i];
+        for (int w = 0; w < 3; w++) {
+            // word w of row r = 4R + v of the matrix: bytes CIRC[(4w + t - r) mod 12], t = 0..3
+            const int base = ((4 * (w - R)) % 12 + 12) % 12;
+            const uint32_t x = v == 0 ? ROW_WORDS[base] : v == 1 ? ROW_WORDS[(base + 11) % 12] : v == 2 ? ROW_WORDS[(base + 10) % 12] : ROW_WORDS[(base + 9) % 12];
+            o.A[R][w] = on ? (int)x : 0;
         }
-        al += lo[r] * POSEIDON_MDS_DIAG[r];
-        ah += hi[r] * POSEIDON_MDS_DIAG[r];
-        s[r] = gl::fold96(al, ah);  // al + ah*2^32 (< 2^75) mod p
+        o.A[R][3] = 0;  // k = 12..15 of every group: the fourth dword of a B operand may hold anything
     }
+    o.C = v4i32{POSEIDON_MDS_PLANE_OFFSET, POSEIDON_MDS_PLANE_OFFSET, POSEIDON_MDS_PLANE_OFFSET, POSEIDON_MDS_PLANE_OFFSET};
+    // keep the operands in registers of their own for the whole kernel instead of re-deriving them per use
+    asm volatile("" : "+v"(o.A[0]), "+v"(o.A[1]), "+v"(o.A[2]), "+v"(o.C));
+    return o;
 }
 
-__device__ const uint64_t POSEIDON_ZERO_ROW[W] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ void require_full_wave() {
+    if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+}
+
+// MDS layer + the additive constants of whatever follows, xy = [12][X, Y] (poseidon_limb_constants.h).
+__device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const MdsOperands &ops, const uint32_t *__restrict__ xy) {
+    v4i32 T[8];  // T[b] = byte b of words 0-3 | 4-7 | 8-11 | (never written: meets zero columns of A)
+#pragma unroll
+    for (int G = 0; G < 3; G++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r0 = (uint32_t)(s[4 * G] >> (32 * h)), r1 = (uint32_t)(s[4 * G + 1] >> (32 * h));
+            const uint32_t r2 = (uint32_t)(s[4 * G + 2] >> (32 * h)), r3 = (uint32_t)(s[4 * G + 3] >> (32 * h));
+            // v_perm_b32 D, S0, S1, sel: bytes 0-3 of the selector space are S1's, 4-7 S0's
+            const uint32_t a01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), c01 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+            const uint32_t a23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), c23 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+            T[4 * h + 0][G] = (int)(__builtin_amdgcn_perm(a23, a01, 0x05040100u) ^ 0x80808080u);
+            T[4 * h + 1][G] = (int)(__builtin_amdgcn_perm(a23, a01, 0x07060302u) ^ 0x80808080u);
+            T[4 * h + 2][G] = (int)(__builtin_amdgcn_perm(c23, c01, 0x05040100u) ^ 0x80808080u);
+            T[4 * h + 3][G] = (int)(__builtin_amdgcn_perm(c23, c01, 0x07060302u) ^ 0x80808080u);
+        }
+    const uint32_t x0l = (uint32_t)s[0], x0h = (uint32_t)(s[0] >> 32);
+#pragma unroll
+    for (int R = 0; R < 3; R++) {
+        v4i32 D[8];
+#pragma unroll
+        for (int b = 0; b < 8; b++) D[b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ops.A[R], T[b], ops.C, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = 4 * R + v;
+            // The packing is left to the compiler: it knows the wait states between a matrix instruction and the first vector
+            // instruction that reads its result; inline asm is opaque to that.
+            const uint32_t Al = (uint32_t)D[0][v] | ((uint32_t)D[2][v] << 16), Bl = (uint32_t)D[1][v] | ((uint32_t)D[3][v] << 16);
+            const uint32_t Ah = (uint32_t)D[4][v] | ((uint32_t)D[6][v] << 16), Bh = (uint32_t)D[5][v] | ((uint32_t)D[7][v] << 16);
+            uint64_t al = ((uint64_t)xy[2 * r] << 32) | Al, ah = ((uint64_t)xy[2 * r + 1] << 32) | Ah;
+            asm("v_mad_u64_u32 %0, vcc, %2, %4, %0\n\t"
+                "v_mad_u64_u32 %1, vcc, %3, %4, %1"
+                : "+v"(al), "+v"(ah)
+                : "v"(Bl), "v"(Bh), "s"(256u)
+                : "vcc");
+            if (r == 0)  // the diagonal entry stays out of the matrix product (it would push a plane's sum past 16 bits)
+                asm("v_mad_u64_u32 %0, vcc, %2, %4, %0\n\t"
+                    "v_mad_u64_u32 %1, vcc, %3, %4, %1"
+                    : "+v"(al), "+v"(ah)
+                    : "v"(x0l), "v"(x0h), "n"(POSEIDON_MDS_DIAG0)
+                    : "vcc");
+            s[r] = gl::fold96(al, ah);  // al + ah 2^32 mod p; al < 2^41 + X 2^32, ah < 2^41 + Y 2^32, X and Y leave the room
+        }
+    }
+}
 
 // s-box layer + MDS layer; the round's own constants were added by the previous layer
-__device__ __forceinline__ void full_round(uint64_t (&s)[W], const uint64_t *__restrict__ rc_next) {
+__device__ __forceinline__ void full_round(uint64_t (&s)[W], const MdsOperands &ops, const uint32_t *__restrict__ xy) {
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = gl::pow7(s[i]);
-    mds_layer(s, rc_next);
+    mds_layer(s, ops, xy);
 }
 
-// lazy dot products (one reduction per sum): gl::DotAcc / dot_term / dot_finish in gl_field.h
-using gl::DotAcc;
-using gl::dot_finish;
-using gl::dot_term;
-
-// The 22 partial rounds (poseidon.rs:400-427, 587-599; partial_first_constant_layer has already been
-// added by the preceding MDS layer). The reference's recurrence per round is
-//     u_r = sbox(s0) + rc_r;   d_r = c*u_r + sum_i s_i*w_hat[r][i];   s_i += u_r*v[r][i];   s0 = d_r
-// i.e. eleven multiply-REDUCE-adds per round just to keep the s_i current. The s_i are linear in the
-// u_q, so inside a block of eleven rounds they are left at their block-start values and the missing
-// part is added through precomputed cross terms,
-//     d_r = c*u_r + sum_i s_i(block start)*w_hat[r][i] + sum_{q in block, q < r} CROSS[r][q]*u_q,
-//     CROSS[r][q] = sum_i w_hat[r][i]*v[q][i]      (tools/gen_poseidon_constants.py)
-// and the s_i are brought up to date once per block, s_i += sum_q v[q][i]*u_q — all of it lazy dot
-// products instead of 22-instruction macs: 638 terms and 44 reductions for the 22 rounds instead of 264 terms, 242 macs
-// and 22 reductions — and, since round 2, carry-free ones: the multiplicand is split once into 21/21/22-bit limbs and every
-// constant comes with its 2^21 and 2^42 multiples, six multiply-adds per term and a seven-instruction reduction per sum
-// (gl::dot_term3 / fold96; before: four multiply-adds + four carry counters per term and twenty instructions per sum).
-__device__ __forceinline__ void partial_rounds(uint64_t (&s)[W]) {
-    using gl::DotAcc2;
-    using gl::Limbs3;
-    using gl::dot_term3;
-    // mds_partial_layer_init (poseidon.rs:339-365): out[c] = sum_r s[r] * M[r-1][c-1]; constants in consumption order
-    {
-        Limbs3 sl[W];
-#pragma unroll
-        for (int r = 1; r < W; r++) sl[r] = gl::split21(s[r]);
-#pragma unroll
-        for (int c = 1; c < W; c++) {
-            DotAcc2 acc;
-#pragma unroll
-            for (int r = 1; r < W; r++) {
-                const int t = (c - 1) * 11 + (r - 1);
-                dot_term3(acc, sl[r], POSEIDON_INIT_STREAM_C0[t], POSEIDON_INIT_STREAM_C21[t], POSEIDON_INIT_STREAM_C42[t]);
-            }
-            s[c] = gl::fold96(acc.lo, acc.hi);
-        }
-    }
-    constexpr int B = 11;
-#pragma unroll 1
-    for (int blk = 0; blk < N_PARTIAL / B; blk++) {
-        // this block's constants: [round k: 11 W_HATS, k CROSS] x 11, then VS [i][q] (tools/gen_poseidon_limb_tables.py)
-        const uint64_t *__restrict__ c0 = POSEIDON_PARTIAL_STREAM_C0 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
-        const uint64_t *__restrict__ c21 = POSEIDON_PARTIAL_STREAM_C21 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
-        const uint64_t *__restrict__ c42 = POSEIDON_PARTIAL_STREAM_C42 + blk * POSEIDON_PARTIAL_BLOCK_TERMS;
-        Limbs3 sl[W], ul[B];
-#pragma unroll
-        for (int i = 1; i < W; i++) sl[i] = gl::split21(s[i]);  // block-start values, used by all eleven rounds of the block
-        uint64_t x = s[0];
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-            const uint64_t u = gl::add_canonical(gl::pow7(x), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[blk * B + k]);
-            ul[k] = gl::split21(u);
-            DotAcc2 acc;
-            gl::dot_term_small(acc, u, (uint32_t)(POSEIDON_MDS_CIRC[0] + POSEIDON_MDS_DIAG[0]));
-            const int off = k * 11 + k * (k - 1) / 2;
-#pragma unroll
-            for (int i = 1; i < W; i++) dot_term3(acc, sl[i], c0[off + i - 1], c21[off + i - 1], c42[off + i - 1]);
-#pragma unroll
-            for (int q = 0; q < k; q++) dot_term3(acc, ul[q], c0[off + 11 + q], c21[off + 11 + q], c42[off + 11 + q]);
-            x = gl::fold96(acc.lo, acc.hi);
-        }
-        s[0] = x;
-#pragma unroll
-        for (int i = 1; i < W; i++) {
-            DotAcc2 acc;
-            acc.lo = (uint32_t)s[i], acc.hi = s[i] >> 32;  // the block-start value, weight 2^0
-#pragma unroll
-            for (int q = 0; q < B; q++) {
-                const int t = 176 + (i - 1) * 11 + q;
-                dot_term3(acc, ul[q], c0[t], c21[t], c42[t]);
-            }
-            s[i] = gl::fold96(acc.lo, acc.hi);
-        }
-    }
-}
-
-__device__ __forceinline__ void permute(uint64_t (&s)[W]) {
-    // constant_layer of round 0; every later constant layer is folded into the MDS layer before it
+// All thirty rounds with their plain MDS layer — `poseidon_naive` (poseidon.rs:565-585), which the reference's own tests hold equal
+// to Poseidon::poseidon. With the layer on the matrix cores a partial round (one s-box + one layer) is cheaper than its share of
+// the "fast" partial rounds' 64-bit dot products: 2.61 G permutations/s against 2.52 with the blocked partial rounds between
+// matrix-core full rounds and 2.25 on the vector ALU alone (tools/experiments/mds_mfma.hip, profiles/r03_poseidon_matrix_cores.jsonl).
+__device__ __forceinline__ void permute(uint64_t (&s)[W], const MdsOperands &ops) {
+    require_full_wave();
 #pragma unroll
     for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i]);
 #pragma unroll 1
-    for (int r = 0; r < HALF_FULL; r++)
-        full_round(s, r + 1 < HALF_FULL ? POSEIDON_ALL_ROUND_CONSTANTS + W * (r + 1) : POSEIDON_FAST_PARTIAL_FIRST_ROUND_CONSTANT);
-    partial_rounds(s);
-#pragma unroll
-    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i + W * (HALF_FULL + N_PARTIAL)]);
+    for (int r = 0; r < HALF_FULL; r++) full_round(s, ops, POSEIDON_MDS_XY + 2 * W * r);
 #pragma unroll 1
-    for (int r = 0; r < HALF_FULL; r++)
-        full_round(s, r + 1 < HALF_FULL ? POSEIDON_ALL_ROUND_CONSTANTS + W * (HALF_FULL + N_PARTIAL + r + 1) : POSEIDON_ZERO_ROW);
+    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; r++) {
+        s[0] = gl::pow7(s[0]);
+        mds_layer(s, ops, POSEIDON_MDS_XY + 2 * W * r);
+    }
+#pragma unroll 1
+    for (int r = HALF_FULL + N_PARTIAL; r < 2 * HALF_FULL + N_PARTIAL; r++) full_round(s, ops, POSEIDON_MDS_XY + 2 * W * r);
 }
 
 }  // namespace poseidon

@@ -108,12 +108,12 @@ __device__ __forceinline__ uint64_t permute(uint64_t x, const Tables &tb, uint64
     if (active) lds[lane] = x;
     __syncthreads();
     const uint64_t s0 = lds[0];
-    poseidon::DotAcc acc;
+    gl::DotAcc acc;
 #pragma unroll 1
     for (int j = 1; j <= 11; j++) {
         uint64_t sj = uniform64(lds[j]);
         asm volatile("s_nop 2" : "+s"(sj));  // v_readfirstlane -> SGPR read inside inline asm (see fri.hip)
-        poseidon::dot_term(acc, tb.t0[(j - 1) * LANES + lane], sj);
+        gl::dot_term(acc, tb.t0[(j - 1) * LANES + lane], sj);
     }
     __syncthreads();
     uint64_t u = gl::add_canonical(gl::pow7(s0), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[0]);
@@ -122,8 +122,8 @@ __device__ __forceinline__ uint64_t permute(uint64_t x, const Tables &tb, uint64
     for (int q = 0; q < T_ROWS; q++) {
         uint64_t us = uniform64(u);
         asm volatile("s_nop 2" : "+s"(us));
-        poseidon::dot_term(acc, tb.t[q * LANES + lane], us);
-        d = poseidon::dot_finish(acc);
+        gl::dot_term(acc, tb.t[q * LANES + lane], us);
+        d = gl::dot_finish(acc);
         dq = lane_value(d, q);
         if (q + 1 < T_ROWS) u = gl::add_canonical(gl::pow7(dq), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[q + 1]);
     }

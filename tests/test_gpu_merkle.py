@@ -40,6 +40,52 @@ def test_poseidon_random_and_noncanonical(gpu, oracle):
         assert (got[i] == oracle.canon(oracle.poseidon(x[i]))).all(), i
 
 
+def test_poseidon_edge_states_and_ragged_counts(gpu, oracle):
+    """The matrix-core MDS layer (csrc/poseidon.h) works on the state's BYTES (as byte - 128) and on whole waves: states made of
+    the bytes where that could go wrong (0x00, 0x7f, 0x80, 0xff, mixed), counts that leave a wave partly or almost empty."""
+    pats = [0x0000000000000000, 0xFFFFFFFFFFFFFFFF, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFF00FF00FF00FF00, 0x00FF00FF00FF00FF,
+            0x80FF7F0001FE8081, 0xFFFFFFFF00000000, 0xFFFFFFFF00000001, 0x00000000FFFFFFFF]
+    x = np.array([[pats[(i + 3 * j) % len(pats)] for j in range(12)] for i in range(2 * len(pats))], dtype=np.uint64)
+    x[len(pats):] = np.array(pats, dtype=np.uint64)[:, None]  # all twelve words the same
+    got = permute(gpu, x)
+    for i in range(x.shape[0]):
+        assert (got[i] == oracle.canon(oracle.poseidon(x[i]))).all(), i
+    rnd = oracle.random_field((321, 12), seed=5)
+    exp = np.array([oracle.canon(oracle.poseidon(r)) for r in rnd[:70]])
+    for count in (1, 2, 63, 65, 129, 321):
+        got = permute(gpu, rnd[:count])
+        assert (got[:min(count, 70)] == exp[:min(count, 70)]).all(), count
+        assert (got[-1] == oracle.canon(oracle.poseidon(rnd[count - 1]))).all(), count
+
+
+def test_two_poseidon_implementations_agree(gpu):
+    """gl_poseidon_permute_batch from the product (all thirty MDS layers on the matrix cores, `poseidon_naive`'s round structure)
+    and from the diagnostic build under PLONKY2_POSEIDON=vector (vector ALU, the "fast" partial rounds in blocks of eleven:
+    csrc/poseidon_vector.h) on 2^16 random 64-bit states, canonical or not — bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, numpy as np, hashlib
+sys.path.insert(0, {root!r})
+import plonky2_gpu_amd as pg
+from plonky2_gpu_amd import _lib
+ctx = pg.Context(0)
+x = np.random.default_rng(17).integers(0, 2**64, size=(1 << 16, 12), dtype=np.uint64)
+buf = pg.DeviceBuffer.from_host(ctx, x)
+_lib.call("gl_poseidon_permute_batch", buf.ptr, x.shape[0], ctx.ptr)
+print("digest", hashlib.sha256(buf.download().tobytes()).hexdigest())
+"""
+    outs = []
+    for env in ({}, {"PLONKY2_HIP_LIBRARY": os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so"), "PLONKY2_POSEIDON": "vector"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and outs[0].startswith("digest ")
+
+
 @pytest.mark.parametrize("n,k,h", [(256, 7, 1), (256, 7, 8), (256, 7, 0), (2, 5, 1), (1, 9, 0), (16, 4, 2), (16, 3, 0),
                                    (8, 1, 1), (64, 8, 3), (64, 9, 3), (32, 16, 2), (128, 135, 4), (4096, 20, 4),
                                    (1024, 88, 10), (512, 17, 5)])
