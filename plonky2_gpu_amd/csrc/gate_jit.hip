@@ -20,13 +20,18 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <algorithm>
 #include <sstream>
+#include <thread>
 #include <vector>
 
 #include "gl_field.h"
@@ -57,14 +62,27 @@ std::string kernel_cache_dir() {
 }
 }  // namespace
 
-struct GateKernel {
+// A circuit's gates are compiled as several UNITS — each a hiprtc program of its own with some of the gates and a kernel
+// that adds their share to the output — so that the units compile side by side (the ed25519 table: 56 s of compilation, 8.5 of
+// them the Poseidon gate; eight units on eight cores take about as long as the largest) and a unit that another circuit
+// shares comes out of the on-disk cache. The units' kernels run one after the other on the caller's stream; every one is bound
+// by the vector ALU's issue rate, so their sum takes what the single kernel took.
+struct GateUnit {
+    std::vector<uint32_t> gates;  // indices into the circuit's gate list
+    std::string source;
+    std::vector<char> code;
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
-    uint64_t *d_pih = nullptr;   // the module's g_pih[4]
+    uint64_t *d_pih = nullptr;  // the module's g_pih[4]
+    std::string error;
+};
+
+struct GateKernel {
+    std::vector<GateUnit> units;
     uint32_t num_challenges = 0, num_constraints = 0;
     uint32_t wires_needed = 0, constants_needed = 0;  // 1 + the largest wire / constant column any gate loads
-    std::string source;
+    std::string source;  // all units, for inspection
 };
 
 // What every consumer of gate programs checks before running them (the compiled kernel when it is generated, the
@@ -113,7 +131,8 @@ bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const u
     return true;
 }
 
-static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
+// Source of one unit: the device functions of `unit_gates` and the kernel that calls them.
+static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, const std::vector<uint32_t> &unit_gates,
                                    const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
                                    std::string *error) {
     std::ostringstream o;
@@ -123,7 +142,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     // alpha powers and the public-inputs hash live at link-time-constant addresses, so every read is a scalar
     // load (a pointer ARGUMENT of a non-inlined device function arrives in VGPRs and would be read per lane)
     o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n";
-    for (uint32_t g = 0; g < num_gates; g++) {
+    for (uint32_t g : unit_gates) {
         const uint32_t *d = gates + 6 * g;
         const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
         if (ps + pl > num_instrs || si >= num_selectors || gs > ge) {
@@ -137,8 +156,10 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
         for (uint32_t i = gs; i < ge; i++)
             if (i != row) o << "  filt = gl::mul(filt, gl::sub(" << i << "ull, s));\n";
         if (num_selectors > 1) o << "  filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));\n";  // UNUSED_SELECTOR (selectors.rs:11)
-        // the gate's constraints are reduced with powers of alpha lazily: one 192-bit column accumulator per
-        // challenge, one reduction per gate (gl::DotAcc) instead of a multiply-reduce-add per constraint
+        // The gate's constraints are reduced with powers of alpha lazily: one 192-bit column accumulator per challenge, one
+        // reduction per gate (gl::DotAcc: four multiply-adds and four carry counts per term) instead of a multiply-reduce-add per
+        // constraint. (Tried in round 3: the powers in 22-bit limbs, six multiply-adds per term and no carry counts — 5 % fewer
+        // vector instructions and 2.5 % SLOWER: a v_mad_u64_u32 costs about two plain instructions here. LABNOTES.md 10.)
         o << "  gl::DotAcc ga[NCH];\n";
         bool used[MAX_REGS] = {};
         bool acc_used[4] = {};
@@ -224,15 +245,95 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
         }
         o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::dot_finish(ga[c]));\n  return out;\n}\n";
     }
+    // `accumulate`: the output already holds the sum of the units that ran before this one
     o << "extern \"C\" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
-         "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, uint64_t lde_size, uint64_t* __restrict__ out) {\n"
+         "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, uint64_t lde_size, uint64_t* __restrict__ out, int accumulate) {\n"
          "  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;\n  if (t >= lde_size) return;\n"
          "  const uint64_t* W = wires + t * wrs;\n  const uint64_t* C = cs + t * crs;\n"
-         "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = 0;\n";
-    for (uint32_t g = 0; g < num_gates; g++)
+         "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = accumulate ? out[(uint64_t)c * lde_size + t] : 0;\n";
+    for (uint32_t g : unit_gates)
         o << "  { GateSum s = gate_" << g << "(W, wes, C, ces); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
     o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t] = gl::canon(acc[c]);\n}\n";
     return o.str();
+}
+
+// How many units a circuit is cut into: PLONKY2_HIP_JIT_UNITS (1 = one program, as before round 3), else one per hardware
+// thread up to eight.
+static uint32_t jit_unit_limit() {
+    if (const char *e = getenv("PLONKY2_HIP_JIT_UNITS")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 64) return (uint32_t)v;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 4 : hw > 8 ? 8 : hw;
+}
+
+// Cache file name of a unit (kernel_cache_dir()): keyed by a hash of the generated source and of what turns the same source
+// into a different code object — the hiprtc version and the target.
+static std::string unit_cache_path(const std::string &dir, const std::string &source) {
+    if (dir.empty()) return "";
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    const std::string salt = "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + JIT_ARCH + "\n";
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
+    for (unsigned char ch : salt) h = (h ^ ch) * 0x100000001b3ull;
+    for (unsigned char ch : source) h = (h ^ ch) * 0x100000001b3ull;
+    char name[64];
+    snprintf(name, sizeof name, "/gate_%016llx", (unsigned long long)h);
+    return dir + name;
+}
+
+// hiprtc on one unit's source; the code object (and the source, for inspection) goes to the cache. Runs on a thread of its own.
+static bool compile_unit(GateUnit &u, const std::string &cache_path) {
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, u.source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) {
+        u.error = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
+        return false;
+    }
+    const std::string arch = std::string("--offload-arch=") + JIT_ARCH;
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        u.error = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000);
+        hiprtcDestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    u.code.resize(cs);
+    hiprtcGetCode(prog, u.code.data());
+    hiprtcDestroyProgram(&prog);
+    if (!cache_path.empty()) {
+        // Several processes (one per GPU) may build the same circuit at once: each writes a file of its own and
+        // renames it into place, so a reader sees either nothing or a whole code object.
+        const std::string pid = std::to_string((long long)getpid()) + "." + std::to_string((unsigned long long)(uintptr_t)&u);
+        const std::string tmp = cache_path + ".tmp." + pid, tmp_src = cache_path + ".hip." + pid;
+        std::ofstream(tmp_src) << u.source;
+        (void)rename(tmp_src.c_str(), (cache_path + ".hip").c_str());
+        bool written = false;
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(u.code.data(), (std::streamsize)u.code.size());
+            f.flush();
+            written = f.good();
+        }
+        if (!written || rename(tmp.c_str(), (cache_path + ".hsaco").c_str()) != 0) (void)remove(tmp.c_str());
+    }
+    return true;
+}
+
+static hipError_t load_unit(GateUnit &u) {
+    hipError_t e = hipModuleLoadData(&u.module, u.code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&u.fn, u.module, "gate_constraints_kernel");
+    size_t bytes = 0;
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_apow), &bytes, u.module, "g_apow");
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_pih), &bytes, u.module, "g_pih");
+    return e;
 }
 
 GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
@@ -250,114 +351,163 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         delete k;
         return nullptr;
     }
-    k->source = generate_source(instrs, num_instrs, gates, num_gates, imms, num_imms, num_selectors, num_gate_constraints,
-                                num_challenges, error);
-    if (k->source.empty()) {
-        delete k;
-        return nullptr;
+    // Units of about equal program length: longest gate first, each into the unit that is shortest so far; inside a unit the
+    // gates keep the circuit's order.
+    const uint32_t n_units = std::min(jit_unit_limit(), num_gates);
+    std::vector<uint32_t> order(num_gates);
+    for (uint32_t g = 0; g < num_gates; g++) order[g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return gates[6 * x + 5] > gates[6 * y + 5]; });
+    k->units.resize(n_units);
+    std::vector<uint64_t> load(n_units, 0);
+    for (uint32_t g : order) {
+        const uint32_t u = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        k->units[u].gates.push_back(g);
+        load[u] += gates[6 * g + 5] + 16;  // + the gate's fixed part (filter, reduction)
     }
-    // On-disk cache (kernel_cache_dir()): the code object is keyed by a hash of the generated source, so a
-    // circuit is compiled once per machine instead of once per process; the source is stored next to it for
-    // inspection.
-    // The key also covers what turns the same source into a different code object: the hiprtc version and the target.
-    std::string cache_path;
-    if (std::string dir = kernel_cache_dir(); !dir.empty()) {
-        int rtc_major = 0, rtc_minor = 0;
-        (void)hiprtcVersion(&rtc_major, &rtc_minor);
-        const std::string salt = "hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) + " " + JIT_ARCH + "\n";
-        uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a
-        for (unsigned char ch : salt) h = (h ^ ch) * 0x100000001b3ull;
-        for (unsigned char ch : k->source) h = (h ^ ch) * 0x100000001b3ull;
-        char name[64];
-        snprintf(name, sizeof name, "/gate_%016llx", (unsigned long long)h);
-        cache_path = dir + name;
-    }
-    auto compile = [&](std::vector<char> &code) -> bool {
-        hiprtcProgram prog;
-        hiprtcResult r = hiprtcCreateProgram(&prog, k->source.c_str(), "gate_constraints.hip", 0, nullptr, nullptr);
-        if (r != HIPRTC_SUCCESS) {
-            *error = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r);
-            return false;
-        }
-        const std::string arch = std::string("--offload-arch=") + JIT_ARCH;
-        const char *opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-        r = hiprtcCompileProgram(prog, 3, opts);
-        if (r != HIPRTC_SUCCESS) {
-            size_t ls = 0;
-            hiprtcGetProgramLogSize(prog, &ls);
-            std::string log(ls, '\0');
-            if (ls) hiprtcGetProgramLog(prog, &log[0]);
-            *error = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000);
-            hiprtcDestroyProgram(&prog);
-            return false;
-        }
-        size_t cs = 0;
-        hiprtcGetCodeSize(prog, &cs);
-        code.resize(cs);
-        hiprtcGetCode(prog, code.data());
-        hiprtcDestroyProgram(&prog);
-        if (!cache_path.empty()) {
-            // Several processes (one per GPU) may build the same circuit at once: each writes a file of its own and
-            // renames it into place, so a reader sees either nothing or a whole code object.
-            const std::string tmp = cache_path + ".tmp." + std::to_string((long long)getpid());
-            std::ofstream(cache_path + ".hip." + std::to_string((long long)getpid())) << k->source;
-            (void)rename((cache_path + ".hip." + std::to_string((long long)getpid())).c_str(), (cache_path + ".hip").c_str());
-            bool written = false;
-            {
-                std::ofstream f(tmp, std::ios::binary);
-                f.write(code.data(), (std::streamsize)code.size());
-                f.flush();
-                written = f.good();
-            }
-            if (!written || rename(tmp.c_str(), (cache_path + ".hsaco").c_str()) != 0) (void)remove(tmp.c_str());
-        }
-        return true;
-    };
-    auto load = [&](const std::vector<char> &code) -> hipError_t {
-        hipError_t e = hipModuleLoadData(&k->module, code.data());
-        if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "gate_constraints_kernel");
-        size_t bytes = 0;
-        if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_apow), &bytes, k->module, "g_apow");
-        if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&k->d_pih), &bytes, k->module, "g_pih");
-        return e;
-    };
-    std::vector<char> code;
-    bool from_cache = false;
-    if (!cache_path.empty()) {
-        std::ifstream f(cache_path + ".hsaco", std::ios::binary);
-        if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-        from_cache = !code.empty();
-    }
-    if (code.empty() && !compile(code)) {
-        delete k;
-        return nullptr;
-    }
-    hipError_t e = load(code);
-    int ndev = 0;
-    if (e != hipSuccess && from_cache && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
-        // a cached object that does not load (written by another ROCm, damaged): drop it and compile
-        (void)hipGetLastError();
-        if (k->module) (void)hipModuleUnload(k->module);
-        k->module = nullptr;
-        (void)remove((cache_path + ".hsaco").c_str());
-        code.clear();
-        if (!compile(code)) {
+    k->units.erase(std::remove_if(k->units.begin(), k->units.end(), [](const GateUnit &u) { return u.gates.empty(); }), k->units.end());
+    const std::string dir = kernel_cache_dir();
+    std::vector<std::string> cache_paths;
+    for (GateUnit &u : k->units) {
+        std::sort(u.gates.begin(), u.gates.end());
+        u.source = generate_source(instrs, num_instrs, gates, u.gates, imms, num_imms, num_selectors, num_gate_constraints, num_challenges, error);
+        if (u.source.empty()) {
             delete k;
             return nullptr;
         }
-        e = load(code);
+        k->source += u.source;
+        cache_paths.push_back(unit_cache_path(dir, u.source));
     }
-    if (e != hipSuccess) {
-        *error = std::string("loading the compiled gate kernel: ") + hipGetErrorString(e);
-        gate_kernel_destroy(k);
+    auto from_cache = [&](size_t i) {
+        if (cache_paths[i].empty()) return false;
+        std::ifstream f(cache_paths[i] + ".hsaco", std::ios::binary);
+        if (f) k->units[i].code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        return !k->units[i].code.empty();
+    };
+    // Compile what the cache does not have. hiprtc serialises concurrent compilations of one process behind a lock of its own
+    // (eight threads took the 68 s one thread takes), so every unit but the first goes to a forked child: the child runs
+    // hiprtc only — nothing that touches a device — writes the code object to a file and leaves with _exit; the parent compiles
+    // the first unit itself meanwhile, then collects the files. A child that fails, or a platform where fork is unwelcome
+    // (PLONKY2_HIP_JIT_FORK=0), falls back to compiling in this process, one unit after the other.
+    auto compile_missing = [&](const std::vector<size_t> &which) -> bool {
+        const char *fk = getenv("PLONKY2_HIP_JIT_FORK");
+        const bool may_fork = !(fk && fk[0] == '0') && which.size() > 1;
+        struct Child {
+            pid_t pid;
+            size_t unit;
+            std::string file;
+        };
+        std::vector<Child> children;
+        if (may_fork) {
+            for (size_t j = 1; j < which.size(); j++) {
+                const size_t i = which[j];
+                char tmpl[] = "/tmp/plonky2_hip_jit_XXXXXX";
+                const int fd = mkstemp(tmpl);
+                if (fd < 0) break;
+                close(fd);
+                const pid_t pid = fork();
+                if (pid < 0) {
+                    (void)remove(tmpl);
+                    break;
+                }
+                if (pid == 0) {
+                    GateUnit &u = k->units[i];
+                    bool ok = compile_unit(u, cache_paths[i]);
+                    if (ok) {
+                        std::ofstream f(tmpl, std::ios::binary);
+                        f.write(u.code.data(), (std::streamsize)u.code.size());
+                        f.flush();
+                        ok = f.good();
+                    }
+                    _exit(ok ? 0 : 1);
+                }
+                children.push_back(Child{pid, i, tmpl});
+            }
+        }
+        std::vector<char> done(k->units.size(), 0);
+        // this process: the first unit, and whatever could not be forked
+        for (size_t j = 0; j < which.size(); j++) {
+            const size_t i = which[j];
+            bool forked = false;
+            for (const Child &c : children) forked |= c.unit == i;
+            if (forked) continue;
+            if (!compile_unit(k->units[i], cache_paths[i])) {
+                *error = k->units[i].error;
+                for (const Child &c : children) {
+                    (void)kill(c.pid, SIGKILL);
+                    (void)waitpid(c.pid, nullptr, 0);
+                    (void)remove(c.file.c_str());
+                }
+                return false;
+            }
+            done[i] = 1;
+        }
+        const time_t deadline = time(nullptr) + 900;
+        for (const Child &c : children) {
+            int status = 0;
+            pid_t w = 0;
+            while ((w = waitpid(c.pid, &status, WNOHANG)) == 0 && time(nullptr) < deadline) usleep(20000);
+            if (w == 0) {
+                (void)kill(c.pid, SIGKILL);
+                (void)waitpid(c.pid, &status, 0);
+                status = -1;
+            }
+            if (w >= 0 && WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+                std::ifstream f(c.file, std::ios::binary);
+                if (f) k->units[c.unit].code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+                done[c.unit] = !k->units[c.unit].code.empty();
+            }
+            (void)remove(c.file.c_str());
+        }
+        for (const Child &c : children)
+            if (!done[c.unit] && !compile_unit(k->units[c.unit], cache_paths[c.unit])) {  // here the error text is available
+                *error = k->units[c.unit].error;
+                return false;
+            }
+        return true;
+    };
+    std::vector<size_t> missing;
+    std::vector<char> cached(k->units.size(), 0);
+    for (size_t i = 0; i < k->units.size(); i++) {
+        cached[i] = from_cache(i) ? 1 : 0;
+        if (!cached[i]) missing.push_back(i);
+    }
+    if (!compile_missing(missing)) {
+        delete k;
         return nullptr;
+    }
+    int ndev = 0;
+    const bool have_device = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+    for (size_t i = 0; i < k->units.size(); i++) {
+        GateUnit &u = k->units[i];
+        hipError_t e = load_unit(u);
+        if (e != hipSuccess && cached[i] && have_device) {
+            // a cached object that does not load (written by another ROCm, damaged): drop it and compile
+            (void)hipGetLastError();
+            if (u.module) (void)hipModuleUnload(u.module);
+            u.module = nullptr;
+            (void)remove((cache_paths[i] + ".hsaco").c_str());
+            u.code.clear();
+            if (!compile_missing({i})) {
+                gate_kernel_destroy(k);
+                return nullptr;
+            }
+            e = load_unit(u);
+        }
+        if (e != hipSuccess) {
+            *error = std::string("loading the compiled gate kernel: ") + hipGetErrorString(e);
+            gate_kernel_destroy(k);
+            return nullptr;
+        }
+        u.code.clear();
+        u.code.shrink_to_fit();
     }
     return k;
 }
 
 void gate_kernel_destroy(GateKernel *k) {
     if (!k) return;
-    if (k->module) (void)hipModuleUnload(k->module);
+    for (GateUnit &u : k->units)
+        if (u.module) (void)hipModuleUnload(u.module);
     delete k;
 }
 
@@ -378,17 +528,25 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
             p = glh::mul(p, a);
         }
     }
-    // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
-    hipError_t e = hipMemcpyAsync(k->d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
     const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
-    e = hipMemcpyAsync(k->d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
+    for (const GateUnit &u : k->units) {
+        // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
+        hipError_t e = hipMemcpyAsync(u.d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(u.d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    void *args[] = {&wires, &w_rs, &w_es, &cs, &c_rs, &c_es, &lde_size, &out};
     const unsigned grid = (unsigned)((lde_size + 127) / 128);
-    return hipModuleLaunchKernel(k->fn, grid, 1, 1, 128, 1, 1, 0, stream, args, nullptr);
+    int accumulate = 0;
+    for (const GateUnit &u : k->units) {
+        void *args[] = {&wires, &w_rs, &w_es, &cs, &c_rs, &c_es, &lde_size, &out, &accumulate};
+        e = hipModuleLaunchKernel(u.fn, grid, 1, 1, 128, 1, 1, 0, stream, args, nullptr);
+        if (e != hipSuccess) return e;
+        accumulate = 1;
+    }
+    return hipSuccess;
 }
 
 }  // namespace plonky2_hip

@@ -1,0 +1,79 @@
+"""gl_gate_kernel_build cuts a circuit's gates into units that hiprtc compiles side by side (csrc/gate_jit.hip): hiprtc needs no
+GPU, so the cutting, the cache files and the error path are checked here; without a device the build stops at loading the code
+objects, after they have been written. tests/test_gpu_plonk.py compares the kernels' results with the interpreter and the oracle."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import ctypes, os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from plonky2_gpu_amd import _lib, gate_program as gp
+pool = gp.ImmediatePool()
+kinds = [("arithmetic", 20), ("constant", 2), ("public_input", None), ("noop", None), ("base_sum", (2, 63)), ("u32_range_check", 8), ("comparison", (32, 16))]
+programs = [gp.build_gate(k, p, pool) for k, p in kinds]
+instrs = np.concatenate([np.asarray(p, dtype=np.uint16).reshape(-1, 4) for p in programs if len(p)] or [np.zeros((0, 4), np.uint16)]).reshape(-1)
+descs, pc = [], 0
+for g, p in enumerate(programs):
+    descs += [g, 0, 0, len(programs), pc, len(p)]
+    pc += len(p)
+descs = np.asarray(descs, dtype=np.uint32)
+imms = np.asarray(pool.values, dtype=np.uint64)
+ngc = max(1, max(sum(1 for ins in p if ins[0] == gp.EMIT) for p in programs))
+wires = 1 + max([ins[2] for p in programs for ins in p if ins[0] == gp.LOAD_WIRE] or [0])
+if os.environ.get("BREAK"):
+    instrs = instrs.copy(); instrs[0] = 99  # unknown opcode
+k = ctypes.c_void_p()
+t = time.perf_counter()
+try:
+    _lib.call("gl_gate_kernel_build", instrs, instrs.size // 4, descs, descs.size // 6, imms, imms.size, 1, ngc, 2, ctypes.byref(k))
+    print("built")
+except _lib.Plonky2HipError as e:
+    print("error:", str(e)[:300].replace("\n", " "))
+print("seconds %.2f" % (time.perf_counter() - t))
+"""
+
+
+def run(tmp, **env):
+    e = dict(os.environ, PLONKY2_HIP_KERNEL_CACHE=str(tmp), AMD_COMGR_CACHE="0", **env)
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def objects(tmp):
+    return sorted(f for f in os.listdir(tmp) if f.endswith(".hsaco"))
+
+
+def test_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path):
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (a, b, c):
+        d.mkdir()
+    out = run(a, PLONKY2_HIP_JIT_UNITS="3")
+    assert "built" in out or "loading the compiled gate kernel" in out, out  # no device here: the build ends at the module load
+    assert len(objects(a)) == 3 and len([f for f in os.listdir(a) if f.endswith(".hip")]) == 3, os.listdir(a)
+    assert not [f for f in os.listdir(a) if ".tmp." in f or f.count(".hip.")], os.listdir(a)  # nothing half-written left behind
+    # the same units from this process alone, one after the other: same sources -> same names, same code objects
+    run(b, PLONKY2_HIP_JIT_UNITS="3", PLONKY2_HIP_JIT_FORK="0")
+    assert objects(a) == objects(b)
+    for f in objects(a):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    # one unit: one program with every gate in it
+    run(c, PLONKY2_HIP_JIT_UNITS="1")
+    assert len(objects(c)) == 1
+    # a second build finds everything in the cache (no compilation: well under a second of hiprtc)
+    out = run(a, PLONKY2_HIP_JIT_UNITS="3")
+    assert float(out.split("seconds")[1]) < 2.0, out
+
+
+def test_a_program_that_cannot_be_generated_is_reported(tmp_path):
+    out = run(tmp_path, BREAK="1")
+    assert "error:" in out and "opcode" in out, out
+    assert objects(tmp_path) == []
