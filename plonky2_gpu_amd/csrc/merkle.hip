@@ -38,6 +38,22 @@ __device__ __forceinline__ void store_hash(uint64_t *dst, const uint64_t (&s)[12
     reinterpret_cast<u64x2 *>(dst)[1] = b;
 }
 
+// Eight consecutive elements of a leaf-major row from the lane that has just absorbed them. A lane's 64 bytes lie alone (the next
+// lane's row is leaf_len * 8 bytes away), so what counts is the number of write requests: 16-byte pieces, with a single element
+// before and after them where the row position is only 8-byte aligned (rows of odd length alternate) — 4 or 5 requests
+// instead of 8.
+__device__ __forceinline__ void store_row_block(uint64_t *dst, const uint64_t (&s)[12]) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 8) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) reinterpret_cast<u64x2 *>(dst)[q] = u64x2{s[2 * q], s[2 * q + 1]};
+    } else {
+        dst[0] = s[0];
+#pragma unroll
+        for (int q = 0; q < 3; q++) reinterpret_cast<u64x2 *>(dst + 1)[q] = u64x2{s[2 * q + 1], s[2 * q + 2]};
+        dst[7] = s[7];
+    }
+}
+
 // hash index (in units of 4 u64) of node `idx` of layer L inside a cap subtree
 __device__ __forceinline__ uint64_t digest_slot(uint64_t idx, uint32_t L) {
     uint64_t q = idx >> 1, parity = idx & 1;
@@ -73,10 +89,7 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
         for (; j + 8 <= leaf_len; j += 8) {
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
-            if (row) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) row[j + k] = s[k];
-            }
+            if (row) store_row_block(row + j, s);
             poseidon::permute(s, ops);
         }
         if (j < leaf_len) {
@@ -134,10 +147,7 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
     for (; j + 8 <= c1; j += 8) {
 #pragma unroll
         for (int k = 0; k < 8; k++) s[k] = cols[(uint64_t)(j + k) * col_stride + i];
-        if (row) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) row[j + k] = s[k];
-        }
+        if (row) store_row_block(row + j, s);
         poseidon::permute(s, ops);
     }
     if (c1 == leaf_len) {
