@@ -168,7 +168,7 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")  # tools/pm
 POSEIDON_RATE = os.path.join(ROOT, "profiles", "r03_poseidon_rate.json")
 # the kernel sources whose counters the summary holds: tools/pmc_summary.py records their sha256 next to the counters
 PMC_SOURCES = ["plonky2_gpu_amd/csrc/ntt.hip", "plonky2_gpu_amd/csrc/ntt_direct.hip", "plonky2_gpu_amd/csrc/ntt_kernels.h",
-               "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/gl_field.h"]
+               "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/poseidon_limb_constants.h", "plonky2_gpu_amd/csrc/gl_field.h"]
 
 
 def source_hashes(root=ROOT):

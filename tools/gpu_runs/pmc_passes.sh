@@ -22,6 +22,8 @@ P="python3 $R/tools/bench_poseidon.py"
 pp() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/perm_$n -- $P > $O/perm_$n.log 2>&1; }
 pp sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pp sq2 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_IFETCH SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
+# the matrix-core side of the permutation (csrc/poseidon.h): instruction count and the cycles the pipe is busy
+pp mfma SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 cd $R
 python3 tools/bench_poseidon.py > $O/poseidon_rate.json 2>&1
 find $O -name "*.csv" -size +6M -delete

@@ -21,7 +21,7 @@ SIMDS = 1024  # 256 CUs x 4
 
 
 def short(name):
-    for key in ("ntt_col_direct_kernel", "ntt_row_natural_direct_kernel", "ntt_row_inplace_direct_kernel", "ntt_pass_wave_kernel", "ntt_pass_kernel", "hash_leaves_kernel", "tree_layer_coop_kernel", "tree_layer_kernel",
+    for key in ("ntt_col_direct_kernel", "ntt_row_natural_direct_kernel", "ntt_row_inplace_direct_kernel", "ntt_pass_wave_kernel", "ntt_pass_kernel", "hash_leaves_chunk_kernel", "hash_leaves_kernel", "gate_constraints_kernel", "tree_layer_coop_kernel", "tree_layer_kernel",
                 "transpose_kernel", "permute_batch_kernel", "copy16_kernel", "coset_tables_kernel"):
         if key in name:
             if "ntt_" in name and "<" in name:
