@@ -705,7 +705,8 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
     if constexpr (LOGR >= WIDE_MIN_LOGR) {
         if (p.flags & F_WIDE) {
             if constexpr (TWIDDLE && LOGR >= 8 && LOGR <= 10)
-                if (!ri && !ro && direct_mode() && !(p.flags & F_COSET) && (p.flags & F_RAW_OUT) && p.scale == 1 && p.in_t == 1 && p.out_t == 1)
+                if (!ri && !ro && direct_mode() && (p.flags & F_RAW_OUT) && p.scale == 1 && p.in_t == 1 && p.out_t == 1 &&
+                    (!(p.flags & F_COSET) || (!(p.flags & F_NATURAL) && p.in_sz == 0 && p.chain_scale == 1 && nttk::col_direct_coset_ok(LOGR - 8, grid))))
                     return nttk::launch_col_direct(LOGR - 8, p, grid, stream);
             if (!ri && !ro) return launch_pass_wave_mode<LOGR, TWIDDLE, false, false, 4>(p, grid, stream);
             if constexpr (!TWIDDLE && LOGR == 10)

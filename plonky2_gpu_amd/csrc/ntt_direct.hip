@@ -96,9 +96,22 @@ struct ColGeom {
     static constexpr uint32_t XBYTES = 16 * G * SA;
     static constexpr uint32_t TWBYTES = 16 * G * 16 * 8;               // per wave: w_R^(kA (16 g + w)), [g][kA]
     static constexpr uint32_t LDS_BYTES = XBYTES + TWBYTES;
+    // coset LDE (first pass of coset_lde_batch): per coset z the powers of its shift that this pass needs, see the kernel
+    static constexpr uint32_t cu_entries(uint32_t gz) { return gz * (G > 1 ? G * 16 : 256); }   // [z][g][i], or [z][w][i] when G = 1
+    static constexpr uint32_t t2z_entries(uint32_t gz) { return G > 1 ? gz * 16 * G : 0; }         // [z][w][kB]
+    static constexpr uint32_t cs_entries(uint32_t gz) { return gz * C; }                          // [z][c]
+    static constexpr uint32_t coset_bytes(uint32_t gz) { return (cu_entries(gz) + t2z_entries(gz) + cs_entries(gz)) * 8; }
 };
 
-template <int LOGG, bool NATURAL>
+// COSET (the first pass of the coset LDE, F_COSET): grid z = coset, every coset reads the same coefficients (in_sz = 0) scaled by the
+// powers of its shift s_z and writes block bitrev(z). With j = m in_m + L (m = row = (R/16) i + 16 g + w, L = column):
+//   s^(in_m ((R/16) i + 16 g))  multiplies the loaded element  (table CU [z][g][i] in LDS: depends on the register, so it cannot
+//                               ride on a twiddle of an OUTPUT index),
+//   s^(in_m w)                  is constant through the first two radix rounds and rides on their closing twiddle (T2Z [z][w][kB];
+//                               for R = 256, which has no such twiddle, it is part of CU [z][w][i]),
+//   s^L                         rides on the start of the inter-pass twiddle chain (CS [z][c]; the workgroup keeps its column tile).
+// Sixteen + 16/G + 1 multiplications per lane and tile more than the plain pass; the tables are built once per workgroup.
+template <int LOGG, bool NATURAL, bool COSET = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_direct_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t gz, const uint32_t per_b) {
     using GEO = ColGeom<LOGG>;
     constexpr int G = GEO::G, LOGC = GEO::LOGC, C = GEO::C, LOGR = GEO::LOGR;
@@ -106,6 +119,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char *X = ldsb;
     unsigned char *TW = ldsb + GEO::XBYTES;
+    unsigned char *CU = TW + GEO::TWBYTES, *T2Z = CU + GEO::cu_entries(gz) * 8, *CS = T2Z + GEO::t2z_entries(gz) * 8;   // COSET only
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,10 +146,24 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         reinterpret_cast<uint64_t *>(TW)[e] = p.twh[(ka * (16 * g_ + w_)) << (12 - LOGR)];
     }
     uint64_t t2[G > 1 ? G : 1];  // w_16G^(kB w), wave-uniform
-    static_for<1, G>([&](auto K_) {
-        constexpr int kb = decltype(K_)::value;
-        t2[kb] = p.twh[(kb * wave) << (12 - 4 - LOGG)];
-    });
+    if constexpr (!COSET)
+        static_for<1, G>([&](auto K_) {
+            constexpr int kb = decltype(K_)::value;
+            t2[kb] = p.twh[(kb * wave) << (12 - 4 - LOGG)];
+        });
+    if constexpr (COSET) {
+        auto cs_pow = [&](uint32_t z, uint64_t ex) { return gl::mul(p.cs_hi[z * p.cs_hi_len + (uint32_t)(ex >> 10)], p.cs_lo[z * 1024 + (uint32_t)(ex & 1023)]); };
+        for (uint32_t e = tid; e < GEO::cu_entries(gz); e += 1024) {
+            const uint32_t i = e & 15, mid = G > 1 ? 16 * ((e >> 4) % G) : (e >> 4) & 15, z = G > 1 ? e / (16 * G) : e >> 8;
+            reinterpret_cast<uint64_t *>(CU)[e] = cs_pow(z, (uint64_t)p.in_m * (((uint32_t)i << (LOGR - 4)) + mid));
+        }
+        for (uint32_t e = tid; e < GEO::t2z_entries(gz); e += 1024) {
+            const uint32_t kb = e % G, w_ = (e / G) & 15, z = e / (16 * G);
+            reinterpret_cast<uint64_t *>(T2Z)[e] = gl::mul(p.twh[(kb * w_) << (12 - 4 - LOGG)], cs_pow(z, (uint64_t)p.in_m * w_));
+        }
+        for (uint32_t e = tid; e < GEO::cs_entries(gz); e += 1024)   // the launcher makes sure the workgroup keeps one column tile (per_b != 0)
+            reinterpret_cast<uint64_t *>(CS)[e] = cs_pow(e / C, (uint64_t)b0 * C + (e % C));
+    }
 
     // ---- per-lane constants ------------------------------------------------------------------------------------------
     // Everything below is a function of (lane, wave) and the same for every tile. What the first rounds use stays in registers;
@@ -210,8 +238,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #ifdef DIRECT_DIAG_SAME_STORES
         tile_of(0, b, a, z);
 #endif
-        obase = p.dst + (a * p.out_sa + b * p.out_sb + z * p.out_sz);
-        cc = cc0;
+        obase = p.dst + (a * p.out_sa + b * p.out_sb + (COSET ? brev_rt(z, p.rate_bits) : z) * p.out_sz);
+        if constexpr (COSET) cc = gl::mul(cc0, lds_ld(CS, (z * C + (opaque_lane() & (C - 1))) * 8));
+        else cc = cc0;
         so = st_off_of(opaque_lane());
     };
     auto tail_unit = [&](auto J_) {
@@ -229,8 +258,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     // first rounds of the tile whose elements are in A: radix 16 over i, twiddle, exchange inside the wave, radix G over g,
     // twiddle, and the results into the exchange image; the sixteen tail steps of the previous tile are spread through it
-    auto first_rounds = [&](auto WITH_TAIL_) {
+    auto first_rounds = [&](auto WITH_TAIL_, uint32_t t_in_a) {
         constexpr bool with_tail = decltype(WITH_TAIL_)::value;   // false: the prologue, nothing to finish
+        uint32_t zc = 0;   // COSET: the coset of the tile whose elements are in A
+        if constexpr (COSET) {
+            uint32_t b_, a_;
+            tile_of(t_in_a, b_, a_, zc);
+        }
 #ifdef DIRECT_DIAG_TAIL_FRONT
         if constexpr (with_tail) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
 #define TAIL(lo, hi) do { } while (0)
@@ -238,6 +272,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
 #endif
         TAIL(0, 4);   // four results leave before the butterflies need their temporaries
+        if constexpr (COSET) {
+            const uint32_t cu_base = (G > 1 ? (zc * G + (opaque_lane() >> LOGC)) * 16 : (zc * 16 + wave) * 16) * 8;
+            static_for<0, 16>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                A[i] = gl::mul(A[i], lds_ld(CU, cu_base + i * 8));
+            });
+        }
         radix_dif_stage<4, 0, 3>(A);
         TAIL(4, 6);
         radix_dif_stage<4, 0, 2>(A);
@@ -276,7 +317,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     constexpr int s2 = decltype(S_)::value;
                     constexpr int kb = brev_c(s2, LOGG);
                     uint64_t val = A[j * G + s2];
-                    if constexpr (kb != 0) val = gl::mul(val, t2[kb]);
+                    if constexpr (COSET) val = gl::mul(val, lds_ld(T2Z, ((zc * 16 + wave) * G + kb) * 8));
+                    else if constexpr (kb != 0) val = gl::mul(val, t2[kb]);
                     lds_st(X, pr_base + (G * j + 16 * kb) * SA, val);
                 });
             });
@@ -298,7 +340,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     lds_barrier();  // tables
     issue_loads(0);
     const uint32_t last = n_tiles - 1;
-    first_rounds(std::false_type{});
+    first_rounds(std::false_type{}, 0);
     if (last > 0) issue_loads(1);
 #pragma unroll 1
     for (uint32_t k = 0; k <= last; k++) {
@@ -312,7 +354,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         radix_dif<4, 0>(B);
         tail_begin(k);
         if (k < last) {
-            first_rounds(std::true_type{});
+            first_rounds(std::true_type{}, k + 1);
             if (k + 1 < last) issue_loads(k + 2);
         } else {
             tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
@@ -320,14 +362,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 }
 
-template <int LOGG, bool NATURAL>
+template <int LOGG, bool NATURAL, bool COSET = false>
 hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
     using GEO = ColGeom<LOGG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::LDS_BYTES);
+    const uint32_t lds_bytes = GEO::LDS_BYTES + (COSET ? GEO::coset_bytes(grid.z) : 0);
+    static uint32_t attr_set = 0;
+    if (attr_set < lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = lds_bytes;
     }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -344,7 +387,8 @@ hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t strea
     } else {
         wgs = (uint32_t)cus;
     }
-    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL>), dim3(wgs), dim3(1024), GEO::LDS_BYTES, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
+    if (COSET && per_b == 0) return hipErrorInvalidValue;   // col_direct_coset_ok() said otherwise
+    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL, COSET>), dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
     return hipGetLastError();
 }
 
@@ -722,8 +766,32 @@ hipError_t launch_row_inplace_direct_t(const PassParams &p, dim3 grid, hipStream
 
 }  // namespace
 
+// Can the coset column pass run as a direct pass? The workgroup must keep one column tile (as many column tiles as CUs at most) and
+// the per-coset tables must fit beside the exchange image.
+bool col_direct_coset_ok(int logg, dim3 grid) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (grid.x > (uint32_t)cus || grid.z == 0) return false;
+    const uint32_t limit = 160 * 1024;
+    switch (logg) {
+        case 0: return ColGeom<0>::LDS_BYTES + ColGeom<0>::coset_bytes(grid.z) <= limit;
+        case 1: return ColGeom<1>::LDS_BYTES + ColGeom<1>::coset_bytes(grid.z) <= limit;
+        case 2: return ColGeom<2>::LDS_BYTES + ColGeom<2>::coset_bytes(grid.z) <= limit;
+        default: return false;
+    }
+}
+
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream) {
     const bool nat = p.flags & F_NATURAL;
+    if (p.flags & F_COSET) {
+        if (nat || !col_direct_coset_ok(logg, grid)) return hipErrorInvalidValue;
+        switch (logg) {
+            case 0: return launch_col_direct_t<0, false, true>(p, grid, stream);
+            case 1: return launch_col_direct_t<1, false, true>(p, grid, stream);
+            case 2: return launch_col_direct_t<2, false, true>(p, grid, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (logg) {
         case 0: return nat ? launch_col_direct_t<0, true>(p, grid, stream) : launch_col_direct_t<0, false>(p, grid, stream);
         case 1: return nat ? launch_col_direct_t<1, true>(p, grid, stream) : launch_col_direct_t<1, false>(p, grid, stream);

@@ -142,6 +142,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---- direct passes (ntt_direct.hip) -------------------------------------------------------------------------------------
 // Column pass of R = 2^(8 + logg) rows on tiles of 64 >> logg adjacent columns (the planner's F_WIDE geometry), logg = 0, 1, 2.
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream);
+// F_COSET passes (first pass of the coset LDE): only when this says so
+bool col_direct_coset_ok(int logg, dim3 grid);
 // Row pass of 1024-point rows with natural-order (transposed) output on tiles of SIXTEEN rows: the planner lays the pass out
 // with logt = 4 (in_sb = 16 rows, out_sb = 16); forward and inverse (index flip, row_shift).
 hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t stream);
