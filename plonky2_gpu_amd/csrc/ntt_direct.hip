@@ -131,7 +131,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const uint32_t P = gy * gz;
     uint32_t b0, bstep, p0, pstep;
     if (per_b) {
-        b0 = u % gx, bstep = gx, p0 = u / gx, pstep = per_b;
+        // COSET: the per_b workgroups of a column tile are neighbours (one XCD, one L2) and a workgroup takes the cosets of a
+        // polynomial one after the other: all of them read the same coefficients
+        if constexpr (COSET) b0 = u / per_b, p0 = u % per_b;
+        else b0 = u % gx, p0 = u / gx;
+        bstep = gx, pstep = per_b;
     } else {
         b0 = u, bstep = W, p0 = 0, pstep = 1;
     }
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const uint32_t bi = t / np_local, pi = t - bi * np_local;
         b = b0 + bi * bstep;
         const uint32_t pp = p0 + pi * pstep;
-        a = pp % gy;
-        z = pp / gy;
+        if constexpr (COSET) a = pp / gz, z = pp % gz;
+        else a = pp % gy, z = pp / gy;
     };
 
     uint64_t A[16];   // tile in flight / first rounds
