@@ -870,7 +870,10 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
     if (log_n <= 20 || (log_n == 21 && wide_ok(11, 1024))) {
         // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass); 2^21 = 2048 x 1024 with the
         // column pass on split columns
-        const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+        uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+        // 2^18 = 256 x 1024 and 2^19 = 512 x 1024 instead of 512 x 512 / 1024 x 512: both passes then have a direct kernel (columns of
+        // 256 / 512 points, rows of 1024)
+        if (direct_mode() && (log_n == 18 || log_n == 19)) lb = 10, la = log_n - 10;
         const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
         // measured at 2^20 on one device: wide tiles make the column pass 6 % faster and the transposed-store row pass 4 % slower
         // the direct row pass (1024-point rows, natural order) works on tiles of sixteen rows
@@ -1251,7 +1254,8 @@ hipError_t coset_lde_batch(const NttTables &tb, const CosetTables &ct, const uin
     // two-pass sizes: the coset scaling is fused into pass A (input scale (s^N2)^j1 on load,
     // s^j2 folded into the inter-pass twiddle chain); coefficients are read once per coset from
     // L2/Infinity Cache and each coset block is written in place by pass B.
-    const uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+    uint32_t la = (log_n + 1) / 2, lb = log_n - la;
+    if (direct_mode() && (log_n == 18 || log_n == 19)) lb = 10, la = log_n - 10;  // as ntt_batch: direct kernels for both passes
     const uint64_t N1 = 1ull << la, N2 = 1ull << lb;
     for (uint64_t off = 0; off < n_polys; off += 65535) {
         uint64_t cnt = n_polys - off < 65535 ? n_polys - off : 65535;
