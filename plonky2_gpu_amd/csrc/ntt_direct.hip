@@ -218,6 +218,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     uint64_t B[16];   // tile being finished: sixteen w for one (kAB, c)
     uint64_t cc0 = 1, cstep = 1;   // inter-pass twiddle chain of this lane: w^(L kAB) (times 1/n, coset power), w^(L 16 G)
+    // Without cosets a lane's sixteen twiddles are the same for every tile of the workgroup (it keeps its column tile): the first
+    // eight stay in registers, the other eight are one multiplication by step^8 away — 24 multiplications per tile instead of the
+    // chain's 31. (With cosets the chain starts from a different power per tile and is walked as before.)
+    constexpr bool kept_twiddles = !COSET;
+    uint64_t cw[kept_twiddles ? 8 : 1], cstep8 = 1;
     uint32_t chain_b = 0xFFFFFFFFu;
     const uint32_t st_row = (uint32_t)(p.out_m * 8);
 
@@ -238,6 +243,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             // the look-ups are complete when this block ends: at the join below the compiler would otherwise wait for "possibly
             // pending" loads with vmcnt(0) in every iteration, which also waits for the prefetched tile
             asm volatile("" : "+v"(cc0), "+v"(cstep));
+            if constexpr (kept_twiddles) {
+                cw[0] = cc0;
+                static_for<1, 8>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value;
+                    cw[j] = gl::mul(cw[j - 1], cstep);
+                });
+                const uint64_t s2 = gl::mul(cstep, cstep), s4 = gl::mul(s2, s2);
+                cstep8 = gl::mul(s4, s4);
+            }
         }
 #ifdef DIRECT_DIAG_SAME_STORES
         tile_of(0, b, a, z);
@@ -250,8 +264,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto tail_unit = [&](auto J_) {
         constexpr int j = decltype(J_)::value;   // kC
         constexpr int s3 = brev_c(j, 4);
-        B[s3] = gl::mul(B[s3], cc);
-        if constexpr (j < 15) cc = gl::mul(cc, cstep);
+        if constexpr (kept_twiddles) {
+            if constexpr (j < 8) B[s3] = gl::mul(B[s3], cw[j]);
+            else B[s3] = gl::mul(B[s3], gl::mul(cw[j - 8], cstep8));
+        } else {
+            B[s3] = gl::mul(B[s3], cc);
+            if constexpr (j < 15) cc = gl::mul(cc, cstep);
+        }
         const uint32_t row = natural ? (uint32_t)(j << (4 + LOGG)) : (uint32_t)s3;
         g_st<NT_STORE_COL>(obase, so + row * st_row, B[s3]);   // unconditional: a branch here would make the compiler forget how many stores are pending
         __builtin_amdgcn_sched_barrier(0);
