@@ -412,7 +412,11 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
     (void)sync_stream2_before_leaves;
     const uint32_t leaf_len = (uint32_t)(poly_num + salt_size);
-    constexpr uint64_t CHUNK = 16;  // columns per pipeline step: two rate blocks
+    uint64_t CHUNK = 16;  // columns per pipeline step: two rate blocks
+    if (const char *e = PLONKY2_KNOB("PLONKY2_COMMIT_CHUNK")) {  // diagnostic build: another multiple of 8
+        const unsigned long v = strtoul(e, nullptr, 10);
+        if (v >= 8 && v <= 1024 && v % 8 == 0) CHUNK = v;
+    }
     if (commit_pipeline_enabled() && poly_num >= 3 * CHUNK && n_ext >= (1ull << 16)) {
         const size_t n_chunks = (size_t)((poly_num + CHUNK - 1) / CHUNK);
         hipStream_t hs = nullptr;

@@ -107,7 +107,7 @@ def test_the_product_library_has_no_ab_knobs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     product = open(os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip.so"), "rb").read()
     for knob in (b"PLONKY2_NTT_DIRECT", b"PLONKY2_NTT_KERNEL", b"PLONKY2_NTT_WIDE", b"PLONKY2_NTT_XCD", b"PLONKY2_NTT_WG_PER_CU", b"PLONKY2_NTT_CHUNK_COLS",
-                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON"):
+                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_COMMIT_CHUNK", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON"):
         assert knob not in product, knob
     for setting in (b"PLONKY2_HIP_KERNEL_CACHE", b"PLONKY2_HIP_JIT_UNITS", b"PLONKY2_HIP_JIT_FORK"):  # operational settings, not knobs
         assert setting in product, setting
