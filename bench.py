@@ -232,6 +232,8 @@ def poseidon_issue_bound():
     rate = json.load(open(POSEIDON_RATE))
     clock = cycles / (rate["ms"] * 1e-3)
     return {"valu_insts_per_wavefront_permutation": insts, "issue_cycles_per_valu_inst": 4,
+            "matrix_insts_per_wavefront_permutation": e["derived"].get("matrix_insts_per_wave"),
+            "matrix_pipe_busy_frac": e["derived"].get("matrix_pipe_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / kernel cycles)"),
             "valu_issue_frac_of_kernel_cycles": e["derived"]["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"],
             "clock_GHz_during_kernel": clock / 1e9, "bound_permutations_per_s": 64 * 1024 * clock / (insts * 4.0),
             "standalone_permutations_per_s": rate["permutations_per_s"],

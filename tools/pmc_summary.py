@@ -75,6 +75,10 @@ def main():
             cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
             d["kernel_cycles"] = cyc
             d["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"] = c["SQ_INSTS_VALU"] * 4.0 / (SIMDS * cyc)
+        if c.get("SQ_INSTS_MFMA") and c.get("SQ_WAVES"):
+            d["matrix_insts_per_wave"] = c["SQ_INSTS_MFMA"] / c["SQ_WAVES"]
+            if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                d["matrix_pipe_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / kernel cycles)"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * c["GRBM_GUI_ACTIVE"] / 8.0)
         if c.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
         if "FETCH_SIZE" in c:
