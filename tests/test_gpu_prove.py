@@ -494,7 +494,9 @@ def test_device_memory_does_not_grow_over_proofs_circuits_and_commits(gpu):
         nc.close()
         if i == 3:
             base = free_bytes()
-    assert free_bytes() == base, "circuits leak device memory"
+    # ">=": creating and destroying a circuit also loads and unloads its gate-kernel modules (eight code objects since round 3), and the
+    # HIP runtime returns pooled code-object memory when it likes: more free memory than at the reference point is not a leak
+    assert free_bytes() >= base, "circuits leak device memory"
     nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
     first = nc.prove_bytes(wires, pis)
     base = free_bytes()
