@@ -339,7 +339,9 @@ GlError gl_pack_leaf_ranges(const uint64_t *d_lde, uint64_t col_stride, uint32_t
  *              oracle.rs:998-1002) and take part in the leaf hash. They are read by kernels on a stream of the library's own
  *              that starts behind everything queued on ctx's stream at the time of the call: write them on ctx's stream
  *              (gl_memcpy_*, a kernel launched there) or complete the writes before calling.
- *   d_leaves   [n_ext][poly_num+salt_size]    out, leaf-major (= merkle_tree.leaves); may be NULL
+ *   d_leaves   [n_ext][poly_num+salt_size]    out, leaf-major (= merkle_tree.leaves); may be NULL. MAY overlap d_coeffs (the
+ *              reference's caller passes one region for both, fri/oracle.rs:409-422): the coefficients are then consumed --
+ *              the leaves replace them. d_lde must not overlap d_coeffs or d_leaves.
  *   d_digests / d_cap as gl_merkle_tree_*.
  * shift is F::coset_shift() = 7 in the reference (field/src/types.rs:431-433). */
 GlError gl_commit_from_coeffs(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t log_n, uint32_t rate_bits,

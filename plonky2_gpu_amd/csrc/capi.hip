@@ -1,4 +1,5 @@
 // capi.hip — the extern "C" boundary of libplonky2_hip.so (declared in include/plonky2_hip.h).
+#include <algorithm>
 #include <list>
 #include <mutex>
 #include <string>
@@ -429,13 +430,28 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         HIP_TRY(hipEventRecord((*evs)[n_chunks], s->stream));
         HIP_TRY(hipStreamWaitEvent(hs, (*evs)[n_chunks], 0));
         const bool fused = d_leaves && fused_leaves_enabled();
+        // The reference's caller passes ONE region as coefficients and as leaves (merkle_tree_from_coeffs(values_device,
+        // values_device, ..), fri/oracle.rs:409-422): the coefficients [poly_num][n] occupy the slots of the first
+        // ceil(poly_num*n / leaf_len) leaf rows, and the LDE of chunk c+1.. still reads them while chunk c is hashed. The
+        // hashing lanes therefore leave those rows alone; one transposition of just these rows (1/2^rate_bits of the copy)
+        // runs on the hash stream after the last chunk, i.e. behind the last LDE launch.
+        uint64_t rows_from = 0;
+        if (fused) {
+            const uintptr_t c_lo = (uintptr_t)d_coeffs, c_hi = (uintptr_t)(d_coeffs + poly_num * n);
+            const uintptr_t l_lo = (uintptr_t)d_leaves, l_hi = (uintptr_t)(d_leaves + (uint64_t)leaf_len * n_ext);
+            if (c_lo < l_hi && l_lo < c_hi) {
+                const uint64_t past = (uint64_t)(c_hi - l_lo) / 8;  // u64 slots of the leaf region up to the end of the coefficients
+                rows_from = std::min<uint64_t>(n_ext, (past + leaf_len - 1) / leaf_len);
+            }
+        }
         if (fused) {
             // d_leaves may still be read by what the caller queued on stream2 (the reference's caller has its D2H of the
             // coefficients there, oracle.rs:403-407, and region A is overwritten by the leaves, plonky2_gpu.cu:586)
             hipEvent_t ev_a = nullptr, ev_b = nullptr;
             HIP_TRY(get_events(&ev_a, &ev_b));
             HIP_TRY(hipEventRecord(ev_a, s->stream2));
-            HIP_TRY(hipStreamWaitEvent(hs, ev_a, 0));
+            if (!PLONKY2_KNOB("PLONKY2_DROP_STREAM2_WAIT"))  // diagnostic build: shows that tests/test_gpu_stream2.py notices the loss
+                HIP_TRY(hipStreamWaitEvent(hs, ev_a, 0));
         }
         // A launch that starts in the middle of the leaf (c0 != 0) carries only the capacity, so its first block must be a
         // full one: if the last chunk (with the salt columns and a trailing partial block) would be shorter than a rate
@@ -452,9 +468,10 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
             if (!last && merge_last_two && c + 2 == n_chunks) continue;
             const uint64_t upto = last ? leaf_len : c1;  // the last launch also takes the salt columns (already in d_lde)
             HIP_TRY(hash_leaves_chunk(d_lde, (uint32_t)absorbed, (uint32_t)upto, leaf_len, n_ext, n_ext, cap_height, d_digests, d_cap, hs,
-                                      fused ? d_leaves : nullptr));
+                                      fused ? d_leaves : nullptr, rows_from));
             absorbed = upto;
         }
+        if (rows_from) HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, leaf_len, rows_from, n_ext, hs));
         hipEvent_t ev_lde2 = nullptr, ev_tr2 = nullptr;
         if (d_leaves && !fused) {
             HIP_TRY(get_events(&ev_lde2, &ev_tr2));
@@ -482,7 +499,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     if (fused) {
         HIP_TRY(get_events(&ev_lde, &ev_tr));  // stream2's earlier work (see above) before d_leaves is written
         HIP_TRY(hipEventRecord(ev_lde, s->stream2));
-        HIP_TRY(hipStreamWaitEvent(s->stream, ev_lde, 0));
+        if (!PLONKY2_KNOB("PLONKY2_DROP_STREAM2_WAIT")) HIP_TRY(hipStreamWaitEvent(s->stream, ev_lde, 0));
     } else if (d_leaves) {
         // The leaf-major copy is pure HBM traffic and the Poseidon hashing pure integer ALU work:
         // run the transpose on stream2, concurrently with the tree on stream. It starts after the LDE
@@ -1053,6 +1070,10 @@ GlError merkle_tree_from_coeffs(uint64_t *d_values_flatten, uint64_t *d_ext_valu
                                         digests, digests + 4 * num_digests, S(ctx), true);
     if (e.code) return e;
     HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    // the reference's body ends its hashing with cudaStreamSynchronize(ctx->stream2) (plonky2_gpu.cu:586) and its caller reads the
+    // destination of the copy it queued there as soon as this returns (fri/oracle.rs:403-407, 462): stream order already put
+    // that copy before the first write of region A; this makes its completion visible to the host as well
+    if (!PLONKY2_KNOB("PLONKY2_DROP_STREAM2_WAIT")) HIP_TRY(hipStreamSynchronize(S(ctx)->stream2));
     return ok();
 }
 

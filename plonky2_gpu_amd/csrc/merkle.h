@@ -14,8 +14,11 @@ hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uin
 // The leaf hashing of merkle_tree_from_columns cut at column boundaries: absorbs columns [c0, c1) of every leaf (c0 a
 // multiple of 8; c1 - c0 a multiple of 8 unless c1 == leaf_len); the sponge's capacity travels between launches in the leaf's
 // digest slot, the launch with c1 == leaf_len leaves the digest there. Then merkle_tree_layers builds the tree above.
+// rows_from: the leaf-major copy is written for leaves i >= rows_from only (the caller transposes the others later: their slots
+// in `rows` may hold the coefficients that the producer of later columns still reads, see commit_from_coeffs_impl).
 hipError_t hash_leaves_chunk(const uint64_t *cols, uint32_t c0, uint32_t c1, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows = nullptr);
+                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows = nullptr,
+                             uint64_t rows_from = 0);
 hipError_t merkle_tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t cap_height, hipStream_t stream);
 // Same for leaf-major rows[i*leaf_len + j].
 hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64_t n_leaves, uint32_t cap_height,

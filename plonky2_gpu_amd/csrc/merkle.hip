@@ -122,12 +122,13 @@ __global__ __launch_bounds__(256) void hash_leaves_kernel(const uint64_t *__rest
 __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *__restrict__ cols, uint32_t c0, uint32_t c1,
                                                                 uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
                                                                 uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
-                                                                uint32_t log_sub_leaves, uint64_t *__restrict__ rows) {
+                                                                uint32_t log_sub_leaves, uint64_t *__restrict__ rows, uint64_t rows_from) {
     const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n_leaves;  // see hash_leaves_kernel
     if (!live) i = n_leaves - 1;
-    uint64_t *row = rows && live ? rows + i * leaf_len : nullptr;
+    // rows below rows_from are not written here: their slots may still hold data that later chunks' producers read
+    uint64_t *row = rows && live && i >= rows_from ? rows + i * leaf_len : nullptr;
     uint64_t *slot;
     if (log_sub_leaves == 0) {
         slot = cap + 4 * i;
@@ -559,13 +560,13 @@ hipError_t merkle_tree_from_columns(const uint64_t *cols, uint32_t leaf_len, uin
 }
 
 hipError_t hash_leaves_chunk(const uint64_t *cols, uint32_t c0, uint32_t c1, uint32_t leaf_len, uint64_t n_leaves, uint64_t col_stride,
-                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows) {
+                             uint32_t cap_height, uint64_t *digests, uint64_t *cap, hipStream_t stream, uint64_t *rows, uint64_t rows_from) {
     int lg = log2_exact(n_leaves);
     if (lg < 0 || (int)cap_height > lg || leaf_len <= 4 || (c0 & 7) || c0 >= c1 || c1 > leaf_len) return hipErrorInvalidValue;
     if (c1 != leaf_len && ((c1 - c0) & 7)) return hipErrorInvalidValue;       // inner chunks are whole rate blocks
     if (c1 == leaf_len && (leaf_len & 7) && c1 - c0 < 8 && c0 != 0) return hipErrorInvalidValue;  // see the kernel
     hipLaunchKernelGGL(hash_leaves_chunk_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, cols, c0, c1, leaf_len, n_leaves,
-                       col_stride, digests, cap, (uint32_t)(lg - cap_height), rows);
+                       col_stride, digests, cap, (uint32_t)(lg - cap_height), rows, rows_from);
     return hipGetLastError();
 }
 

@@ -66,8 +66,29 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 # ("oracles" is also FRI's own word for committed polynomial batches, fri/oracle.rs)
-                for needle in ("import oracle", "from oracle", "oracle/", "oracle.", "gl_oracle", "pyref", "_ref import", "fri_ref", "plonk_ref"):
+                for needle in ("import oracle", "from oracle", "oracle/", "oracle.", "gl_oracle", "pyref", "_ref import", "fri_ref", "plonk_ref",
+                               "libplonky2_ref", "ref_gpu", "ref_harness", "#include \"plonky2_gpu_impl"):
                     assert needle not in src.replace("oracle.rs", ""), (needle, os.path.join(dirpath, f))
+    # nor do the built libraries know the checkers' names (the reference's kernels of oracle/_ref included)
+    for so in ("libplonky2_hip.so", "libplonky2_hip_debug.so"):
+        path = os.path.join(ROOT, "plonky2_gpu_amd", so)
+        if os.path.exists(path):
+            blob = open(path, "rb").read()
+            for needle in (b"libplonky2_ref", b"libgl_oracle", b"ref_compute_quotient"):
+                assert needle not in blob, (needle, so)
+
+
+def test_reference_kernel_library_exports_its_entry_points():
+    """oracle/_ref/libplonky2_ref.so (the reference's own kernels for gfx950, oracle/ref_harness.hip): every entry point the GPU
+    tests call resolves. Built only where /root/reference is mounted; absent -> skipped with the reason."""
+    from oracle import ref_gpu
+
+    if not ref_gpu.build():
+        pytest.skip(ref_gpu.why_absent())
+    lib = ref_gpu.lib()
+    for name in ref_gpu.SIGNATURES:
+        assert getattr(lib, name) is not None
+    assert b"no error" in lib.ref_error_string(0).lower() or lib.ref_error_string(0)
 
 
 def _imports_of_oracle(src):
@@ -107,7 +128,7 @@ def test_the_product_library_has_no_ab_knobs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     product = open(os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip.so"), "rb").read()
     for knob in (b"PLONKY2_NTT_DIRECT", b"PLONKY2_NTT_KERNEL", b"PLONKY2_NTT_WIDE", b"PLONKY2_NTT_XCD", b"PLONKY2_NTT_WG_PER_CU", b"PLONKY2_NTT_CHUNK_COLS",
-                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_COMMIT_CHUNK", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON"):
+                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_COMMIT_CHUNK", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON", b"PLONKY2_DROP_STREAM2_WAIT"):
         assert knob not in product, knob
     for setting in (b"PLONKY2_HIP_KERNEL_CACHE", b"PLONKY2_HIP_JIT_UNITS", b"PLONKY2_HIP_JIT_FORK"):  # operational settings, not knobs
         assert setting in product, setting
