@@ -80,9 +80,14 @@ struct GateAsm {
     void free(std::initializer_list<int> regs) {
         for (int r : regs) free1(r);
     }
+    // operands are 16-bit fields of the instruction word: an index that does not fit is an error, never a wrapped "valid" program
+    static uint16_t field(long v) {
+        if (v < 0 || v > 0xFFFF) throw std::runtime_error("gate program operand (wire, constant, immediate or register index) does not fit 16 bits");
+        return (uint16_t)v;
+    }
     int op(uint16_t code, int a, int b = 0, int dst = -1) {
         const int r = dst < 0 ? reg() : dst;
-        instrs.push_back(GlGateInstr{code, (uint16_t)r, (uint16_t)a, (uint16_t)b});
+        instrs.push_back(GlGateInstr{code, field(r), field(a), field(b)});
         return r;
     }
     int wire(int i) { return op(LOAD_WIRE, i); }
@@ -97,7 +102,7 @@ struct GateAsm {
     int sub(int a, int b, int dst = -1) { return op(SUB, a, b, dst); }
     int mul(int a, int b, int dst = -1) { return op(MUL, a, b, dst); }
     int mulk(int a, int shift, int dst = -1) { return op(MULK, a, shift, dst); }
-    void emit(int a) { instrs.push_back(GlGateInstr{EMIT, 0, (uint16_t)a, 0}); }
+    void emit(int a) { instrs.push_back(GlGateInstr{EMIT, 0, field(a), 0}); }
 
     // may r * weight still be added to accumulator q without either half being able to reach 2^63?
     bool acc_fits(u128 weight, int q = 0) const { return weight < ((u128)1 << 32) && acc_bound[q] + weight * 0xFFFFFFFFull < ACC_LIMIT; }
@@ -106,7 +111,7 @@ struct GateAsm {
         ImmediatePool &pl = need_pool();
         if (!acc_fits(weight, q)) throw std::runtime_error("accumulator could overflow: reduce (accr) earlier");
         acc_bound[q] += weight * 0xFFFFFFFFull;
-        instrs.push_back(GlGateInstr{ACC, (uint16_t)q, (uint16_t)a, (uint16_t)pl.index(weight)});
+        instrs.push_back(GlGateInstr{ACC, field(q), field(a), field((long)pl.index(weight))});
     }
     // register <- acc[q] mod p; acc[q] <- 0 (ACCR)
     int accr(int q = 0, int dst = -1) {
@@ -612,8 +617,35 @@ Program poseidon_gate(ImmediatePool &pool) {
     return g.instrs;
 }
 
+// Sane parameter ranges per kind, checked BEFORE anything is emitted or allocated: every wire / constant index of the program must
+// fit the 16-bit instruction fields (GateAsm::field throws as the backstop) and nothing may grow without limit. The largest real
+// gates are far inside (ed25519: arithmetic 20 ops, base_sum 63 limbs, u32_add_many 16 addends x 4 ops, random_access 4 bits).
+void check_params(const GlGateSpec &s) {
+    const uint32_t *p = s.params;
+    auto need = [&](bool ok, const char *what) {
+        if (!ok) throw std::invalid_argument(std::string("gate kind ") + std::to_string(s.kind) + ": " + what);
+    };
+    switch (s.kind) {
+        case GL_GATE_CONSTANT: need(p[0] >= 1 && p[0] <= 4096, "num_consts must be in 1..4096"); break;
+        case GL_GATE_ARITHMETIC: need(p[0] >= 1 && p[0] <= 4096, "num_ops must be in 1..4096"); break;
+        case GL_GATE_BASE_SUM: need(p[0] >= 2 && p[0] <= 256, "base B must be in 2..256"); need(p[1] >= 1 && p[1] <= 64, "num_limbs must be in 1..64"); break;
+        case GL_GATE_U32_ADD_MANY: need(p[0] <= 256, "num_addends must be at most 256"); need(p[1] >= 1 && p[1] <= 256, "num_ops must be in 1..256"); break;
+        case GL_GATE_U32_ARITHMETIC:
+        case GL_GATE_U32_SUBTRACTION: need(p[0] >= 1 && p[0] <= 1024, "num_ops must be in 1..1024"); break;
+        case GL_GATE_U32_RANGE_CHECK: need(p[0] <= 1024, "num_input_limbs must be at most 1024"); break;
+        case GL_GATE_COMPARISON: need(p[0] >= 1 && p[0] <= 64, "num_bits must be in 1..64"); need(p[1] >= 1 && p[1] <= p[0], "num_chunks must be in 1..num_bits"); break;
+        case GL_GATE_RANDOM_ACCESS:
+            need(p[0] <= 10, "bits must be at most 10");
+            need(p[1] >= 1 && p[1] <= 256, "num_copies must be in 1..256");
+            need(p[2] <= 256, "num_extra_constants must be at most 256");
+            break;
+        default: break;
+    }
+}
+
 Program build_gate(const GlGateSpec &s, ImmediatePool &pool) {
     const uint32_t *p = s.params;
+    check_params(s);
     switch (s.kind) {
         case GL_GATE_NOOP: return Program();
         case GL_GATE_CONSTANT: return constant_gate(p[0]);
@@ -674,6 +706,11 @@ extern "C" GlError gl_gate_programs_emit(const GlGateSpec *gates, uint32_t num_g
         memcpy(out->instrs, instrs.data(), instrs.size() * sizeof(GlGateInstr));
         if (!descs.empty()) memcpy(out->gates, descs.data(), descs.size() * sizeof(GlGateDesc));
         if (!pool.values.empty()) memcpy(out->immediates, pool.values.data(), pool.values.size() * sizeof(uint64_t));
+    } catch (const std::invalid_argument &ex) {
+        gl_gate_programs_free(out);
+        GlError e = emit_error(std::string("gl_gate_programs_emit: ") + ex.what());
+        e.code = GL_E_INVALID;
+        return e;
     } catch (const std::exception &ex) {
         gl_gate_programs_free(out);
         return emit_error(std::string("gl_gate_programs_emit: ") + ex.what());

@@ -386,11 +386,14 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
     // Compile what the cache does not have. hiprtc serialises concurrent compilations of one process behind a lock of its own
     // (eight threads took the 68 s one thread takes), so every unit but the first goes to a forked child: the child runs
     // hiprtc only — nothing that touches a device — writes the code object to a file and leaves with _exit; the parent compiles
-    // the first unit itself meanwhile, then collects the files. A child that fails, or a platform where fork is unwelcome
-    // (PLONKY2_HIP_JIT_FORK=0), falls back to compiling in this process, one unit after the other.
+    // the first unit itself meanwhile, then collects the files. Forking is OPT-IN (PLONKY2_HIP_JIT_FORK=1): a library must not
+    // fork a host that is multi-threaded and has HIP/ROCr initialised (locks held by other threads stay locked in the child,
+    // the child inherits the KFD descriptors), so by default the units are compiled in this process, one after the other, and the
+    // on-disk cache is what makes the second call fast. build() (__graft_entry__.py) opts in: it runs before any HIP call, in a
+    // single-threaded process. A child that fails falls back to compiling here.
     auto compile_missing = [&](const std::vector<size_t> &which) -> bool {
         const char *fk = getenv("PLONKY2_HIP_JIT_FORK");
-        const bool may_fork = !(fk && fk[0] == '0') && which.size() > 1;
+        const bool may_fork = fk && fk[0] == '1' && which.size() > 1;
         struct Child {
             pid_t pid;
             size_t unit;
@@ -441,7 +444,7 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
             }
             done[i] = 1;
         }
-        const time_t deadline = time(nullptr) + 900;
+        const time_t deadline = time(nullptr) + 180;  // a unit of the largest table (ed25519 / 8) compiles in about 10 s
         for (const Child &c : children) {
             int status = 0;
             pid_t w = 0;

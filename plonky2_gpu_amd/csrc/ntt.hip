@@ -680,13 +680,10 @@ static uint32_t persistent_workgroups() {
 template <int LOGR, bool TWIDDLE, bool ROWS_IN, bool ROWS_OUT, int LOGW = 3, bool SPLIT = false>
 hipError_t launch_pass_wave_mode(const PassParams &p_in, dim3 grid, hipStream_t stream) {
     size_t lds_bytes = (size_t)((WBUF << LOGW) + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW, SPLIT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynamicLds attr;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_pass_wave_kernel<LOGR, TWIDDLE, ROWS_IN, ROWS_OUT, LOGW, SPLIT>), (uint32_t)lds_bytes);
+        e != hipSuccess)
+        return e;
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
     if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint32_t resident = persistent_workgroups() >> (LOGW - 3);  // the LDS holds two 8-wave or one 16-wave workgroup per CU
@@ -740,13 +737,8 @@ hipError_t launch_pass_wave_split(const PassParams &p, dim3 grid, hipStream_t st
 template <int LOGR, bool TWIDDLE>
 hipError_t launch_pass(const PassParams &p, dim3 grid, hipStream_t stream) {
     size_t lds_bytes = (size_t)(LDS_DATA + (LOGR >= 5 ? (1 << LOGR) : 0)) * sizeof(uint64_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<LOGR, TWIDDLE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynamicLds attr;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_pass_kernel<LOGR, TWIDDLE>), (uint32_t)lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL((ntt_pass_kernel<LOGR, TWIDDLE>), grid, dim3(NT), lds_bytes, stream, p);
     return hipGetLastError();
 }

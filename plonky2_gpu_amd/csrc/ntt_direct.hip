@@ -389,12 +389,8 @@ template <int LOGG, bool NATURAL, bool COSET = false>
 hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
     using GEO = ColGeom<LOGG>;
     const uint32_t lds_bytes = GEO::LDS_BYTES + (COSET ? GEO::coset_bytes(grid.z) : 0);
-    static uint32_t attr_set = 0;
-    if (attr_set < lds_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = lds_bytes;
-    }
+    static DynamicLds attr;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET>), lds_bytes); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t pairs = (uint64_t)grid.y * grid.z, total = pairs * grid.x;
@@ -605,12 +601,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
 template <bool INVERSE>
 hipError_t launch_row_natural_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_row_natural_direct_kernel<INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowGeom::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynamicLds attr;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_row_natural_direct_kernel<INVERSE>), RowGeom::LDS_BYTES); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
@@ -770,12 +762,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 }
 
 hipError_t launch_row_inplace_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_row_inplace_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RowInplaceGeom::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynamicLds attr;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_row_inplace_direct_kernel), RowInplaceGeom::LDS_BYTES); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t rows_total = (uint64_t)p.t_limit * grid.y * grid.z;
@@ -795,7 +783,7 @@ bool col_direct_coset_ok(int logg, dim3 grid) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (grid.x > (uint32_t)cus || grid.z == 0) return false;
-    const uint32_t limit = 160 * 1024;
+    const uint32_t limit = device_lds_limit();
     switch (logg) {
         case 0: return ColGeom<0>::LDS_BYTES + ColGeom<0>::coset_bytes(grid.z) <= limit;
         case 1: return ColGeom<1>::LDS_BYTES + ColGeom<1>::coset_bytes(grid.z) <= limit;

@@ -2,6 +2,7 @@
 // twiddle look-ups, the in-register radix butterflies and the two kinds of synchronisation. Included by ntt.hip (planner,
 // tile kernels) and ntt_direct.hip (direct passes); everything is inline device code in an internal namespace.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -138,6 +139,31 @@ __device__ __forceinline__ void tile_sync() {
 // flight across the whole transform of the current one.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// ---- dynamic LDS above the default limit ---------------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, DEVICE): remembered per device, raised once to the
+// device's own limit (so that concurrent first calls set the same value), in a slot that concurrent callers may race on freely.
+struct DynamicLds {
+    std::atomic<uint8_t> set[64] = {};
+};
+inline uint32_t device_lds_limit() {
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || bytes <= 0)
+        return 64 * 1024;
+    return (uint32_t)bytes;
+}
+inline hipError_t allow_dynamic_lds(DynamicLds &st, const void *fn, uint32_t lds_bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<uint8_t> &slot = st.set[dev & 63];
+    if (slot.load(std::memory_order_acquire)) return hipSuccess;
+    const uint32_t limit = device_lds_limit();
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes > limit ? lds_bytes : limit));  // too much: HIP says so
+    if (e != hipSuccess) return e;
+    slot.store(1, std::memory_order_release);
+    return hipSuccess;
+}
 
 // ---- direct passes (ntt_direct.hip) -------------------------------------------------------------------------------------
 // Column pass of R = 2^(8 + logg) rows on tiles of 64 >> logg adjacent columns (the planner's F_WIDE geometry), logg = 0, 1, 2.

@@ -89,3 +89,24 @@ def test_errors_are_reported_not_crashed():
     out = _lib.GlGatePrograms()
     err = _lib.load().gl_gate_programs_emit(ctypes.byref(bad), 1, np.zeros(2, dtype=np.uint32).ctypes.data, 1, ctypes.byref(out))
     assert err.code != 0 and b"no register-program emitter" in ctypes.string_at(err.message)
+
+
+@pytest.mark.parametrize("kind,param,what", [
+    ("arithmetic", 16384, "num_ops"), ("arithmetic", 0, "num_ops"), ("constant", 70000, "num_consts"), ("base_sum", (1, 8), "base B"),
+    ("base_sum", (2, 4000), "num_limbs"), ("u32_add_many", (70000, 1), "num_addends"), ("u32_add_many", (2, 0), "num_ops"),
+    ("u32_arithmetic", 100000, "num_ops"), ("u32_subtraction", 0, "num_ops"), ("u32_range_check", 5000, "num_input_limbs"),
+    ("comparison", (200, 4), "num_bits"), ("comparison", (32, 0), "num_chunks"), ("random_access", (20, 1, 0), "bits"),
+    ("random_access", (2, 100000, 0), "num_copies"), ("random_access", (2, 1, 100000), "num_extra_constants")])
+def test_parameters_out_of_range_are_invalid_arguments_not_wrapped_programs(kind, param, what):
+    """wire / constant indices are 16-bit instruction fields: parameters that would wrap them (or allocate without limit) come back as
+    GL_E_INVALID with the parameter's name, before anything is emitted"""
+    from plonky2_gpu_amd import _lib
+
+    spec = (_lib.GlGateSpec * 1)()
+    spec[0].kind = _lib.GATE_KINDS[kind]
+    for j, v in enumerate([param] if isinstance(param, int) else list(param)):
+        spec[0].params[j] = v
+    out = _lib.GlGatePrograms()
+    err = _lib.load().gl_gate_programs_emit(ctypes.byref(spec), 1, np.array([0, 1], dtype=np.uint32).ctypes.data, 1, ctypes.byref(out))
+    assert err.code == -1 and what.encode() in ctypes.string_at(err.message), ctypes.string_at(err.message)
+    assert not out.instrs and not out.gates and not out.immediates

@@ -56,12 +56,12 @@ def test_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path)
     a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
     for d in (a, b, c):
         d.mkdir()
-    out = run(a, PLONKY2_HIP_JIT_UNITS="3")
+    out = run(a, PLONKY2_HIP_JIT_UNITS="3", PLONKY2_HIP_JIT_FORK="1")  # forked children: opt-in (what build() uses)
     assert "built" in out or "loading the compiled gate kernel" in out, out  # no device here: the build ends at the module load
     assert len(objects(a)) == 3 and len([f for f in os.listdir(a) if f.endswith(".hip")]) == 3, os.listdir(a)
     assert not [f for f in os.listdir(a) if ".tmp." in f or f.count(".hip.")], os.listdir(a)  # nothing half-written left behind
     # the same units from this process alone, one after the other: same sources -> same names, same code objects
-    run(b, PLONKY2_HIP_JIT_UNITS="3", PLONKY2_HIP_JIT_FORK="0")
+    run(b, PLONKY2_HIP_JIT_UNITS="3")  # the default: no fork
     assert objects(a) == objects(b)
     for f in objects(a):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
