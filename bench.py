@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-commit", action="store_true", help="skip the configs[2] commit measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the configs[3]/[4]-shaped prove() measurement")
+    ap.add_argument("--no-reference", action="store_true", help="skip timing the reference's own kernels (oracle/_ref) on this GPU")
     ap.add_argument("--prove-degree-bits", type=int, default=18)
     ap.add_argument("--prove-wires", type=int, default=234)
     ap.add_argument("--prove-reps", type=int, default=3)
@@ -119,6 +120,121 @@ def cpu_baseline(log_n):
     }
 
 
+def cpu_baseline_commit(cols, log_n, rate_bits=3, cap_height=4, budget_s=25.0):
+    """configs[2]'s leg on the CPU: the C oracle's commit_from_values (restating PolynomialBatch::from_values, fri/oracle.rs:709-731,
+    and MerkleTree::new, hash/merkle_tree.rs:283-319: ifft per column, coset LDE per column, transpose + bit reversal, leaf hashing
+    and the cap subtrees, threaded per column / per subtree like the reference's rayon split) on every core the container may
+    use, at a REDUCED row count chosen to fit the budget (the work is linear in the rows up to the log factor of the transforms)."""
+    from oracle import oracle as o
+
+    hw, quota = o.hardware_threads(), o.cpu_quota()
+    cores = max(1, min(hw, int(quota))) if quota else hw
+    # about 1.5 M permutations/s/thread: rows so that leaves x ceil(cols/8) permutations take a few seconds
+    perms_per_row = ((cols + 7) // 8 + 1) << rate_bits
+    sample_log_n = min(log_n, max(10, int(np.log2(max(1.0, 0.25 * budget_s * 1.5e6 * cores / perms_per_row)))))
+    n = 1 << sample_log_n
+    vals = o.random_field((cols, n), seed=0x706C6F6E6B7932 + 7)
+    t = time.perf_counter()
+    o.commit_from_values(vals, rate_bits, cap_height, threads=cores, want_leaves=True)
+    dt = time.perf_counter() - t
+    leaves = n << rate_bits
+    return {"value": leaves / dt, "unit": "Merkle leaves/s (whole commit)", "cores": cores, "kind": "port", "seconds": dt,
+            "poseidon_permutations_per_s": leaves * ((cols + 7) // 8 + 1) / dt,
+            "projected_ms_at_full_size": dt * (1 << (log_n - sample_log_n)) * 1e3,
+            "sample": f"one from_values of {cols} columns x 2^{sample_log_n} rows (configs[2] has 2^{log_n}), rate {1 << rate_bits}, cap_height {cap_height}, "
+                      f"leaf-major copy included, on {cores} threads; C restatement (oracle/gl_oracle.c glo_commit_from_values)"}
+
+
+def cpu_baseline_prove(degree_bits, num_wires, rate_bits=3, cap_height=4):
+    """configs[3]'s leg on the CPU, as far as a compiled restatement exists: the THREE commitments of prove() at the ed25519
+    shape (wires 234 columns, Zs/partial products 20, quotient chunks 16; plonk/prover.rs:84, 125, 174 -> from_values /
+    from_coeffs) with the C oracle on every core the container may use. The quotient evaluation, the openings and FRI are
+    restated in Python only (oracle/plonk_ref.py, fri_ref.py: minutes per proof at 2^12 rows), so this is a LOWER bound of the
+    CPU prover's time, said so in `sample`; the reference's README quotes 45 s for its CPU prover on its authors' machine."""
+    from oracle import oracle as o
+
+    hw, quota = o.hardware_threads(), o.cpu_quota()
+    cores = max(1, min(hw, int(quota))) if quota else hw
+    n = 1 << degree_bits
+    parts = {}
+    total = 0.0
+    for name, cols in (("wires", num_wires), ("zs_partial_products", 20), ("quotient_chunks", 16)):
+        vals = o.random_field((cols, n), seed=0x706C6F6E6B7932 + cols)
+        t = time.perf_counter()
+        if name == "quotient_chunks":
+            o.commit_from_coeffs(vals, rate_bits, cap_height, threads=cores, want_leaves=False)
+        else:
+            o.commit_from_values(vals, rate_bits, cap_height, threads=cores, want_leaves=False)
+        parts[name] = time.perf_counter() - t
+        total += parts[name]
+    return {"value": total * 1e3, "unit": "ms per proof, the three commitments only (lower bound of prove())", "cores": cores, "kind": "port",
+            "commit_ms": {k: v * 1e3 for k, v in parts.items()},
+            "sample": f"the three PolynomialBatch commitments of one proof at n = 2^{degree_bits} ({num_wires} + 20 + 16 columns, rate {1 << rate_bits}) on "
+                      f"{cores} threads with the C oracle; quotient evaluation, openings and FRI have only Python restatements and are NOT "
+                      f"included, so the CPU prover takes longer than this"}
+
+
+def cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, log_n, batch, commit_cols, commit_log_n):
+    """Not a CPU figure but the same kind of leg (a stated baseline beside the product, rank 0 at N = 1, outside every timed
+    region): the REFERENCE'S OWN kernels (cuda/plonky2_gpu_impl.cuh compiled unmodified for gfx950, oracle/_ref, see
+    oracle/ref_harness.hip) timed on this very MI355X with the launch geometry of cuda/plonky2_gpu.cu. The only same-node
+    comparison with the reference this project can have; never the target."""
+    from oracle import oracle as o, ref_gpu
+
+    if not ref_gpu.available():
+        return {"absent_because": ref_gpu.why_absent()}
+    out = {"library": os.path.relpath(ref_gpu.PATH, ROOT), "what": "cuda/plonky2_gpu_impl.cuh, unmodified, hipcc --offload-arch=gfx950; durations by HIP events inside oracle/ref_harness.hip"}
+    n = 1 << log_n
+    # (1) the headline transform: fft_kernel / ifft_kernel, one 256-thread block per polynomial (plonky2_gpu.cu:81, 131)
+    x = pg.DeviceBuffer.from_host(ctx, o.random_field((batch, n), seed=11))
+    table = pg.DeviceBuffer.from_host(ctx, o.root_table_concat(n))
+    ctx.synchronize()
+    f = [ref_gpu.call("ref_fft", x.ptr, batch, n, log_n, table.ptr, 0)[0] for _ in range(3)]
+    i = [ref_gpu.call("ref_ifft", x.ptr, batch, n, log_n, table.ptr, ref_gpu.n_inv(log_n))[0] for _ in range(3)]
+    out["ntt"] = {"workload": f"{batch} columns x 2^{log_n}, fft_kernel then ifft_kernel", "fft_ms": min(f), "ifft_ms": min(i),
+                  "NTT_per_s": 2 * batch / ((min(f) + min(i)) * 1e-3)}
+    x.free()
+    table.free()
+    # (2) the commit of configs[2] = the launches of merkle_tree_from_values (plonky2_gpu.cu:218-433; body disabled by assert(0),
+    # its live twin is ifft + merkle_tree_from_coeffs :435-606): ifft, lde, init_lde, mul_shift, fft(r), reverse_index_bits,
+    # hash_leaves, reduce_digests, transpose
+    cols, cn = commit_cols, 1 << commit_log_n
+    rate_bits, h = 3, 4
+    n_ext = cn << rate_bits
+    pad = cols * n_ext
+    if pad >= 1 << 31:
+        out["commit"] = {"absent_because": "the reference indexes with int: (poly_num + salt) * n_ext must stay below 2^31"}
+        return out
+    region = pg.DeviceBuffer(ctx, 2 * pad + 4 * 2 * (n_ext - (1 << h)) + (4 << h))
+    seed_block = o.random_field((1 << 22,), seed=12)
+    for off in range(0, cols * cn, 1 << 22):  # values: one random block repeated (durations do not depend on the values)
+        region.upload(seed_block[:min(1 << 22, cols * cn - off)], off)
+    t1 = pg.DeviceBuffer.from_host(ctx, o.root_table_concat(cn))
+    t2 = pg.DeviceBuffer.from_host(ctx, o.root_table_concat(n_ext))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_circuit as sc
+
+    pw = np.ones(1, dtype=np.uint64)
+    while pw.size < cn:
+        pw = np.concatenate([pw, sc.np_mul(pw, np.uint64(pow(7, pw.size, sc.P)))])
+    shifts = pg.DeviceBuffer.from_host(ctx, pw[:cn])
+    ctx.synchronize()
+    ms = {}
+    ms["ifft_kernel"] = ref_gpu.call("ref_ifft", region.ptr, cols, cn, commit_log_n, t1.ptr, ref_gpu.n_inv(commit_log_n))[0]
+    lde = ref_gpu.call("ref_coset_lde", region.ptr, region.at(pad), cols, cn, commit_log_n, t2.ptr, shifts.ptr, rate_bits, n_ms=4)
+    ms.update({"lde_kernel": lde[0], "init_lde_kernel": lde[1], "mul_shift_kernel": lde[2], "fft_kernel": lde[3]})
+    ms["reverse_index_bits_kernel"] = ref_gpu.call("ref_reverse_index_bits", region.at(pad), cols, n_ext, commit_log_n + rate_bits)[0]
+    mk = ref_gpu.call("ref_merkle_tree", region.at(pad), cols, n_ext, h, n_ms=2)
+    ms.update({"hash_leaves_kernel": mk[0], "reduce_digests_kernel": mk[1]})
+    ms["transpose_kernel"] = ref_gpu.call("ref_transpose", region.at(pad), region.ptr, cols, n_ext)[0]
+    total = sum(ms.values())
+    out["commit"] = {"workload": f"configs[2]: {cols} columns x 2^{commit_log_n} rows, rate 8, cap_height {h}: every launch of ifft + merkle_tree_from_coeffs",
+                     "kernel_ms": ms, "commit_ms": total, "merkle_leaves_per_s": n_ext / (total * 1e-3)}
+    for b in (region, t1, t2, shifts):
+        b.free()
+    return out
+
+
 SPLITMIX_SEED = 0x706C6F6E6B7932  # "plonky2" (SURVEY.md 8d)
 P = 0xFFFFFFFF00000001
 
@@ -164,8 +280,7 @@ def dft_point(x, log_n, k):
     return int(terms[0])
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
-POSEIDON_RATE = os.path.join(ROOT, "profiles", "r03_poseidon_rate.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
 # the kernel sources whose counters the summary holds: tools/pmc_summary.py records their sha256 next to the counters
 PMC_SOURCES = ["plonky2_gpu_amd/csrc/ntt.hip", "plonky2_gpu_amd/csrc/ntt_direct.hip", "plonky2_gpu_amd/csrc/ntt_kernels.h",
                "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/poseidon_limb_constants.h", "plonky2_gpu_amd/csrc/gl_field.h"]
@@ -198,46 +313,103 @@ def pmc_summary(path=None, root=ROOT):
     return d, None
 
 
+def _kernel_key(name):
+    """'ntt_col_direct_kernel<2,true,false> grid=262144' -> ('ntt_col_direct_kernel', ['2', 'true', 'false'], 262144)"""
+    head, _, grid = name.partition(" grid=")
+    base, _, args = head.partition("<")
+    return base, [a.strip() for a in args.rstrip(">").split(",")] if args else [], int(grid) if grid.isdigit() else 0
+
+
+def forward_ntt_kernels(d):
+    """The two kernels of the forward natural-order batch transform in a counter summary: the natural-order, non-coset column
+    pass and the forward (non-inverse) natural row pass, each at the largest grid it was launched with (the 64-column batch;
+    smaller grids are the one-column parity check). (col_entry, row_entry, None) or (None, None, why): anything but exactly one
+    of each is an error, never a silent partial sum (a renamed template dropped the column pass unnoticed)."""
+    col, row = [], []
+    for name, e in d.get("kernels", {}).items():
+        base, args, grid = _kernel_key(name)
+        if base == "ntt_col_direct_kernel" and len(args) >= 3 and args[1] == "true" and args[2] == "false":
+            col.append((grid, name, e))
+        elif base == "ntt_row_natural_direct_kernel" and args[:1] == ["false"]:
+            row.append((grid, name, e))
+    picked = []
+    for what, found in (("column", col), ("row", row)):
+        if not found:
+            return None, None, f"the summary holds no forward {what}-pass kernel"
+        top = max(g for g, _, _ in found)
+        best = [x for x in found if x[0] == top]
+        if len(best) != 1:
+            return None, None, f"{len(best)} forward {what}-pass kernels at grid {top}: {[n for _, n, _ in best]}"
+        picked.append(best[0])
+    return picked[0], picked[1], None
+
+
+def traffic_of_summary(d, batch):
+    """HBM-side bytes per forward batch transform of `batch` columns: FETCH_SIZE x 2 (gfx950 note of MI355X_MICROARCH.md) +
+    WRITE_SIZE of the column pass and of the row pass, scaled from the columns per launch the passes were collected with."""
+    c, r, why = forward_ntt_kernels(d)
+    if why:
+        return None, why
+    total = 0.0
+    for _, name, e in (c, r):
+        rd, wr = e["derived"].get("read_bytes (FETCH_SIZE KiB x 1024 x 2)"), e["derived"].get("write_bytes (WRITE_SIZE KiB x 1024)")
+        if not rd or not wr:
+            return None, f"{name} has no FETCH_SIZE / WRITE_SIZE pass"
+        total += rd + wr
+    return total * (batch / float(d.get("ntt_columns_per_launch", 64))), None
+
+
+def int_alu_of_summary(d):
+    """The binding roof of the passes as a number: executed vector-ALU instructions x 4 cycles (the issue cost of a wave64
+    instruction on a SIMD-16) / (1024 SIMDs x the kernels' cycles), both kernels of the forward transform together."""
+    c, r, why = forward_ntt_kernels(d)
+    if why:
+        return None
+    insts = sum(e["counters"].get("SQ_INSTS_VALU", 0) for _, _, e in (c, r))
+    cycles = sum(e["derived"].get("kernel_cycles", 0) for _, _, e in (c, r))
+    if not insts or not cycles:
+        return None
+    return {"frac": insts * 4.0 / (1024 * cycles), "valu_insts_per_launch_pair": insts, "kernel_cycles_per_launch_pair": cycles,
+            "wave_parked_frac": {n.split(" ")[0]: e["derived"].get("wave_parked_frac (s_waitcnt / barrier)") for _, n, e in (c, r)},
+            "definition": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8), column pass + row pass"}
+
+
 def pmc_traffic(log_n, batch):
     """(bytes, source note): HBM-side bytes per forward batch transform from the committed counter summary (rocprofv3
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE x 2 as the gfx950 note of MI355X_MICROARCH.md prescribes),
-    per launch pair of `batch` columns; (None, why) when the summary is absent or stale."""
+    FETCH_SIZE and WRITE_SIZE in separate passes), per launch pair of `batch` columns; (None, why) when the summary is absent,
+    stale, or does not hold exactly one column and one row kernel."""
     d, why = pmc_summary()
     if not d:
         return None, why
     if log_n != 20:
         return None, "the counter passes were collected at 2^20"
-    total, per_launch_cols = 0.0, None
-    for name, e in d["kernels"].items():
-        if name.startswith(("ntt_col_direct_kernel<2,true>", "ntt_row_natural_direct_kernel<false>")):
-            total += e["derived"].get("read_bytes (FETCH_SIZE KiB x 1024 x 2)", 0) + e["derived"].get("write_bytes (WRITE_SIZE KiB x 1024)", 0)
-            per_launch_cols = d.get("ntt_columns_per_launch", 64)
-    if not total:
-        return None, "the summary holds no direct-pass kernels"
-    return total * (batch / float(per_launch_cols)), os.path.relpath(PMC_SUMMARY, ROOT)
+    total, why = traffic_of_summary(d, batch)
+    if total is None:
+        return None, why
+    return total, os.path.relpath(PMC_SUMMARY, ROOT)
 
 
-def poseidon_issue_bound():
-    """What the counters say bounds the leaf hashing: the permutation kernel issues VALU instructions back to back
-    (SQ_INSTS_VALU x 4 cycles = the kernel's cycles x 1024 SIMDs), so permutations/s <= 64 lanes x 1024 SIMDs x clock /
-    (VALU instructions per wavefront-permutation x 4). (bound, None) or (None, why not)."""
+def commit_hash_kernel_counters():
+    """Counters of the kernel that dominates a commit, taken on THAT kernel inside the commit (hash_leaves_chunk_kernel at the
+    configs[2] grid), not on a stand-alone permutation kernel: instructions per wavefront, the kernel's cycles and duration,
+    hence its clock, and the vector-ALU issue estimate (SQ_INSTS_VALU minus the matrix instructions, x 4 cycles, / SIMDs x cycles).
+    An ESTIMATE of how busy the issue port is, not a bound: not every vector instruction costs 4 cycles."""
     d, why = pmc_summary()
     if not d:
         return None, why
-    e = d["kernels"].get("permute_batch_kernel grid=4194304")
-    if not e or not os.path.exists(POSEIDON_RATE):
-        return None, "no permutation kernel in the summary"
-    insts = e["derived"]["valu_insts_per_wave"]
-    cycles = e["derived"]["kernel_cycles"]
-    rate = json.load(open(POSEIDON_RATE))
-    clock = cycles / (rate["ms"] * 1e-3)
-    return {"valu_insts_per_wavefront_permutation": insts, "issue_cycles_per_valu_inst": 4,
-            "matrix_insts_per_wavefront_permutation": e["derived"].get("matrix_insts_per_wave"),
-            "matrix_pipe_busy_frac": e["derived"].get("matrix_pipe_busy_frac (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / kernel cycles)"),
-            "valu_issue_frac_of_kernel_cycles": e["derived"]["valu_issue_frac_at_4_cycles_per_inst (lower bound of VALU busy)"],
-            "clock_GHz_during_kernel": clock / 1e9, "bound_permutations_per_s": 64 * 1024 * clock / (insts * 4.0),
-            "standalone_permutations_per_s": rate["permutations_per_s"],
-            "source": f"{os.path.relpath(PMC_SUMMARY, ROOT)} (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVES, GRBM_GUI_ACTIVE on tools/bench_poseidon.py), {os.path.relpath(POSEIDON_RATE, ROOT)}"}, None
+    found = [(_kernel_key(n)[2], n, e) for n, e in d["kernels"].items() if _kernel_key(n)[0] == "hash_leaves_chunk_kernel"]
+    if not found:
+        return None, "no hash_leaves_chunk_kernel in the summary"
+    grid, name, e = max(found)
+    c, dv = e["counters"], e["derived"]
+    valu, mfma, cyc = c.get("SQ_INSTS_VALU"), c.get("SQ_INSTS_MFMA", 0.0), dv.get("kernel_cycles")
+    out = {"kernel": name, "leaves": grid, "valu_insts_per_wavefront": dv.get("valu_insts_per_wave"), "matrix_insts_per_wavefront": mfma / c["SQ_WAVES"] if c.get("SQ_WAVES") else None,
+           "avg_us_per_launch": e.get("avg_us"), "kernel_cycles": cyc,
+           "clock_GHz_during_kernel": cyc / (e["avg_us"] * 1e3) if cyc and e.get("avg_us") else None,
+           "valu_issue_estimate_frac_of_cycles": (valu - mfma) * 4.0 / (1024 * cyc) if valu and cyc else None,
+           "wave_parked_frac": dv.get("wave_parked_frac (s_waitcnt / barrier)"),
+           "source": os.path.relpath(PMC_SUMMARY, ROOT)}
+    return out, None
 
 
 def launch_ranks(n, argv=None, script=None, extra_env=None):
@@ -382,6 +554,8 @@ def main():
     copy_gbs = 2 * 8.0 * batch * n / (min(copy_ms) * 1e-3) / 1e9
     mulmods = (n // 2) * log_n * batch  # (N/2) lg N butterflies per transform, one mulmod + add + sub each
     traffic, traffic_source = pmc_traffic(log_n, batch)
+    _d, _ = pmc_summary()
+    int_alu = int_alu_of_summary(_d) if (_d and log_n == 20) else None
 
     out = None
     if dist.rank == 0:
@@ -400,12 +574,14 @@ def main():
     extra = {}
     if not args.no_commit and dist.rank == 0:
         extra = bench_commit(pg, _lib, ctx, args.commit_cols, args.commit_log_n)
-        bound, why = poseidon_issue_bound()
-        if bound:
-            bound["commit_permutations_per_s_frac_of_bound"] = extra["poseidon_permutations_per_s"] / bound["bound_permutations_per_s"]
-        extra["poseidon_valu_issue_bound"] = bound
-        if not bound:
-            extra["poseidon_valu_issue_bound_absent_because"] = why
+        hk, why = commit_hash_kernel_counters()
+        extra["commit_hash_kernel_counters"] = hk
+        if not hk:
+            extra["commit_hash_kernel_counters_absent_because"] = why
+        elif hk.get("avg_us_per_launch"):
+            # the commit is serial in effect (every kernel here fills the register file): leaf hashing vs the whole
+            extra["commit_leaf_hashing_frac_of_commit_ms"] = hk["avg_us_per_launch"] * 1e-3 * ((args.commit_cols + 15) // 16) / extra["commit_ms"] \
+                if "chunk" in hk["kernel"] else None
 
     if not args.no_prove:
         pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
@@ -452,12 +628,14 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_source if traffic is not None else None,
                 "traffic_absent_because": None if traffic is not None else traffic_source,
-                "kernel": "forward batch NTT = ntt_col_direct_kernel<2,true> (column pass) + ntt_row_natural_direct_kernel<false> (row pass), "
+                "traffic_over_algorithmic": traffic / alg_bytes if traffic is not None else None,
+                "int_alu_frac": (int_alu or {}).get("frac"),
+                "int_alu": int_alu,
+                "kernel": "forward batch NTT = ntt_col_direct_kernel (column pass) + ntt_row_natural_direct_kernel (row pass), "
                           "one launch pair per 64-column batch",
-                "binding_roof": "two passes move 2x the algorithmic bytes (traffic). The passes are bound by vector-ALU issue: "
-                                "the same instruction stream with loads and stores served from L2 and without its workgroup "
-                                "barriers runs 12 % faster (profiles/r03_ntt_direct_diagnostic_variants.jsonl), counters in "
-                                "profiles/r03_pmc_summary.json, DESIGN.md 3.1",
+                "binding_roof": ("HBM-side traffic is %.2f x the algorithmic bytes: the second pass of a two-pass transform re-reads and "
+                                 "re-writes every element. " % (traffic / alg_bytes) if traffic is not None else "") +
+                                "The passes are bound by vector-ALU issue, not by HBM (int_alu_frac; DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
                 "ms": fwd,
                 "ms_min_max": [float(min(fwd_ms)), float(max(fwd_ms))],
@@ -471,6 +649,18 @@ def main():
             "cpu_baseline": None if (args.no_cpu or dist.world > 1) else cpu_baseline(log_n),
             "extra": extra,
         }
+        if not (args.no_cpu or dist.world > 1):
+            # the other two legs of the metric on this host's cores, and the reference's own kernels on this GPU
+            if not args.no_commit:
+                extra["commit_cpu_baseline"] = cpu_baseline_commit(args.commit_cols, args.commit_log_n)
+                extra["commit_speedup_vs_cpu_baseline_projected"] = extra["commit_cpu_baseline"]["projected_ms_at_full_size"] / extra["commit_ms"]
+            if not args.no_prove:
+                extra["prove_cpu_baseline"] = cpu_baseline_prove(args.prove_degree_bits, args.prove_wires)
+            if not args.no_reference:
+                try:
+                    extra["reference_gpu_kernels_on_this_mi355x"] = cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, log_n, batch, args.commit_cols, args.commit_log_n)
+                except Exception as e:  # noqa: BLE001  a baseline leg must not take the measurement down
+                    extra["reference_gpu_kernels_on_this_mi355x"] = {"absent_because": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     buf.free()
     ctx.close()
@@ -590,6 +780,24 @@ def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3)
         times_nl.append(e1.elapsed_ms_since(e0))
         assert d_cap.download().tobytes() == caps[0], "the cap must not depend on the leaf-major copy"
     ms_nl = float(np.median(times_nl))
+    # the stages of the same commit one at a time (HIP events around each entry point; inside the commit they overlap little:
+    # every kernel here fills the register file): values -> coefficients, coset LDE, leaf hashing + tree over the LDE's columns
+    def timed(fn):
+        ts = []
+        for _ in range(iters):
+            ctx.synchronize()
+            e0, e1 = pg.Event(), pg.Event()
+            e0.record(ctx)
+            fn()
+            e1.record(ctx)
+            ctx.synchronize()
+            ts.append(e1.elapsed_ms_since(e0))
+        return float(np.median(ts))
+
+    _lib.call("gl_memcpy_d2d", d_work.ptr, d_vals.ptr, cols * n * 8, ctx.ptr)
+    stage = {"ifft (values -> coefficients)": timed(lambda: _lib.call("gl_ntt_batch", d_work.ptr, cols, log_n, n, 1, 0, ctx.ptr)),
+             "coset LDE (bit-reversed)": timed(lambda: _lib.call("gl_coset_lde_batch", d_work.ptr, d_lde.ptr, cols, log_n, rate_bits, 7, n, n_ext, ctx.ptr)),
+             "leaf hashing + tree layers": timed(lambda: _lib.call("gl_merkle_tree_from_columns", d_lde.ptr, cols, n_ext, n_ext, cap_height, d_dig.ptr, d_cap.ptr, ctx.ptr))}
     alg = 8.0 * cols * n + 8.0 * cols * n_ext + 32.0 * (2 * (n_ext - (1 << cap_height)) + (1 << cap_height))
     perms = n_ext * ((cols + 7) // 8) + n_ext - (1 << cap_height)
     for b in (d_vals, d_work, d_lde, d_leaves, d_dig, d_cap):
@@ -599,6 +807,8 @@ def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3)
                            f"leaf-major copy included",
         "commit_ms": ms,
         "commit_ms_without_leaf_major_copy": ms_nl,
+        "commit_stage_ms_one_at_a_time": {k: round(v, 3) for k, v in stage.items()},
+        "commit_stage_ms_sum": round(sum(stage.values()), 3),
         "merkle_leaves_per_s": n_ext / (ms * 1e-3),
         "poseidon_permutations_per_s": perms / (ms * 1e-3),
         "commit_algorithmic_GBps": alg / (ms * 1e-3) / 1e9,

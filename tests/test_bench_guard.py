@@ -54,3 +54,35 @@ def test_the_committed_summary_if_any_matches_or_is_reported_stale():
     traffic, note = bench.pmc_traffic(20, 64)
     assert (traffic is None) or traffic > 0
     assert note
+
+
+def test_traffic_counts_exactly_the_column_and_the_row_pass():
+    """a renamed template argument dropped the column pass from the sum unnoticed. On the committed summaries the two
+    passes of the forward transform are found by template name + pinned arguments at the batch's grid, and their HBM-side bytes
+    are twice the algorithmic bytes (the second pass re-reads and re-writes everything)."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_pmc_summary.json")))
+    assert paths
+    for path in paths:
+        d = json.load(open(path))
+        c, r, why = bench.forward_ntt_kernels(d)
+        assert why is None, (path, why)
+        assert c[1].startswith("ntt_col_direct_kernel<") and r[1].startswith("ntt_row_natural_direct_kernel<false")
+        assert c[0] == r[0] == max(bench._kernel_key(n)[2] for n in d["kernels"] if n.startswith("ntt_col_direct_kernel"))
+        total, why = bench.traffic_of_summary(d, 64)
+        assert why is None
+        assert 1.9 <= total / (16.0 * (1 << 20) * 64) <= 2.2, (path, total)
+        alu = bench.int_alu_of_summary(d)
+        assert alu and 0.3 < alu["frac"] <= 1.0
+
+
+def test_a_summary_with_a_missing_or_duplicated_pass_is_an_error_not_a_partial_sum():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+    only_row = {"kernels": {k: v for k, v in d["kernels"].items() if not k.startswith("ntt_col_direct_kernel")}}
+    assert bench.traffic_of_summary(only_row, 64)[0] is None and "column" in bench.traffic_of_summary(only_row, 64)[1]
+    renamed = {"kernels": {k.replace("ntt_col_direct_kernel<2,true,false>", "ntt_col_direct_kernel<2,true>"): v for k, v in d["kernels"].items()}}
+    assert bench.traffic_of_summary(renamed, 64)[0] is None
+    twice = {"kernels": dict(d["kernels"])}
+    twice["kernels"]["ntt_col_direct_kernel<1,true,false> grid=262144"] = d["kernels"]["ntt_col_direct_kernel<2,true,false> grid=262144"]
+    assert bench.traffic_of_summary(twice, 64)[0] is None

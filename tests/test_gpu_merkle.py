@@ -306,7 +306,7 @@ def test_open_batch_from_the_column_major_lde(gpu):
 def test_commit_at_the_full_benchmark_size(gpu, oracle):
     """BASELINE.json configs[2], the shape bench.py's commit leg times: from_values of 135 columns x 2^20 rows, rate 8,
     cap height 4 — LDE 2^23 x 135 = 8.4 GiB, 2^23 leaves of 17 permutations each. Checked through properties that do not
-    need the whole answer on the host:
+    need the whole answer on the host, AND against the whole answer (the oracle's cap and all its digests):
       - three whole columns (first, middle, last): coefficients == the C oracle's ifft of the values, and the LDE
         column == its 2^23-point coset LDE in bit-reversed order;
       - from_coeffs on the coefficients builds the same tree (same cap, same sampled digests);
@@ -320,13 +320,28 @@ def test_commit_at_the_full_benchmark_size(gpu, oracle):
     watch = (0, 67, 134)
     d_vals = pg.DeviceBuffer(gpu, n_polys * n)
     values = {}
+    all_values = np.empty((n_polys, n), dtype=np.uint64)
     for c0 in range(0, n_polys, 15):
         v = oracle.random_field((15, n), seed=4200 + c0)
         d_vals.upload(v, c0 * n)
+        all_values[c0:c0 + 15] = v
         for c in watch:
             if c0 <= c < c0 + 15:
                 values[c] = v[c - c0].copy()
     a = pg.PolynomialBatch.from_values_device(gpu, d_vals, n_polys, log_n, rate_bits, False, h, leaf_major=False)
+    # THE WHOLE ANSWER: the C oracle's commit of the same 135 x 2^20 values on every core this process may use (151 M
+    # permutations, 135 transforms of 2^23 points: some tens of seconds) -> its cap and every one of its 2 (2^23 - 16) digests
+    import time
+
+    quota = oracle.cpu_quota()
+    threads = max(1, min(oracle.hardware_threads(), int(quota))) if quota else oracle.hardware_threads()
+    t0 = time.perf_counter()
+    exp = oracle.commit_from_values(all_values, rate_bits, h, threads=threads, want_leaves=False)
+    print("oracle commit of configs[2] on %d threads: %.1f s = %.2f M leaves/s" % (threads, time.perf_counter() - t0, n_ext / (time.perf_counter() - t0) / 1e6))
+    del all_values
+    assert (a.merkle_tree.cap == oracle.canon(exp["cap"])).all(), "cap of configs[2] at full size"
+    assert (a.merkle_tree.d_digests.download().reshape(-1, 4) == oracle.canon(exp["digests"])).all(), "digests of configs[2] at full size"
+    del exp
     perm = bitrev_perm(log_n + rate_bits)
     lde = {}
     for c in watch:
