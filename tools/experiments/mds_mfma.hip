@@ -7,10 +7,16 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <vector>
-#include "poseidon.h"
+#include "poseidon_blocked.h"
 
+#ifndef BLOCK_WAVES
+#define BLOCK_WAVES 2
+#endif
+#ifndef PLAIN_WAVES
+#define PLAIN_WAVES 4
+#endif
 template <int WHICH>
-__global__ __launch_bounds__(256) void permute_kernel(uint64_t *states, int reps) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WHICH == 2 ? BLOCK_WAVES : PLAIN_WAVES, WHICH == 2 ? BLOCK_WAVES : PLAIN_WAVES))) void permute_kernel(uint64_t *states, int reps) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t s[12];
@@ -19,7 +25,8 @@ __global__ __launch_bounds__(256) void permute_kernel(uint64_t *states, int reps
 #pragma unroll 1
     for (int l = 0; l < reps; l++) {
         if constexpr (WHICH == 0) poseidon_vector::permute(s);
-        else poseidon::permute(s, ops);
+        else if constexpr (WHICH == 1) poseidon::permute(s, ops);
+        else poseidon::permute_blocked(s, ops);  // the blocked partial rounds (poseidon_blocked.h)
     }
 #pragma unroll
     for (int k = 0; k < 12; k++) states[i * 12 + k] = gl::canon(s[k]);
@@ -166,7 +173,7 @@ int main() {
                 if (pass == 2) (void)hipEventRecord(e[0]);
                 if (w == 0) hipLaunchKernelGGL(permute_kernel<0>, dim3(n / 256), dim3(256), 0, 0, d[w], reps);
                 else if (w == 1) hipLaunchKernelGGL(permute_kernel<1>, dim3(n / 256), dim3(256), 0, 0, d[w], reps);
-                else hipLaunchKernelGGL(permute16_kernel, dim3(n / 256), dim3(256), 0, 0, d[w], reps);
+                else hipLaunchKernelGGL(permute_kernel<2>, dim3(n / 256), dim3(256), 0, 0, d[w], reps);
             }
             (void)hipEventRecord(e[1]);
             (void)hipDeviceSynchronize();
@@ -177,7 +184,7 @@ int main() {
         uint64_t bad = 0, bad16 = 0;
         for (uint64_t k = 0; k < n * 12; k++) bad += out[0][k] != out[1][k], bad16 += out[0][k] != out[2][k];
         printf("{\"permutations_per_state_and_launch\": %d, \"launches\": 8, \"states\": %llu, \"vector_ms\": %.3f, \"matrix_core_ms\": %.3f, "
-               "\"matrix_core_16x16x64_variant_ms\": %.3f, \"G_perm_per_s\": [%.3f, %.3f, %.3f], \"mismatching_words_after_32_permutations\": [%llu, %llu]}\n",
+               "\"matrix_core_blocked_partial_rounds_ms\": %.3f, \"G_perm_per_s\": [%.3f, %.3f, %.3f], \"mismatching_words_after_32_permutations\": [%llu, %llu]}\n",
                reps, (unsigned long long)n, t[0], t[1], t[2], n * reps / t[0] / 1e6, n * reps / t[1] / 1e6, n * reps / t[2] / 1e6, (unsigned long long)bad,
                (unsigned long long)bad16);
     }
