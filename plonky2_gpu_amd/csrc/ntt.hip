@@ -731,6 +731,9 @@ hipError_t launch_pass_wave(const PassParams &p, dim3 grid, hipStream_t stream) 
 template <bool TWIDDLE>
 hipError_t launch_pass_wave_split(const PassParams &p, dim3 grid, hipStream_t stream) {
     if (!(p.flags & F_WIDE) || (p.flags & (F_LOAD_ROWS | F_STORE_ROWS))) return hipErrorInvalidValue;
+    if constexpr (TWIDDLE)
+        if (direct_mode() && (p.flags & F_RAW_OUT) && !(p.flags & F_COSET) && p.scale == 1 && p.in_t == 1 && p.out_t == 1)
+            return nttk::launch_col_direct(3, p, grid, stream);   // the direct column pass with eight lane groups (tiles of 2048 rows x 8 columns)
     return launch_pass_wave_mode<LOGEW, TWIDDLE, false, false, 4, true>(p, grid, stream);
 }
 

@@ -807,6 +807,7 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
         case 0: return nat ? launch_col_direct_t<0, true>(p, grid, stream) : launch_col_direct_t<0, false>(p, grid, stream);
         case 1: return nat ? launch_col_direct_t<1, true>(p, grid, stream) : launch_col_direct_t<1, false>(p, grid, stream);
         case 2: return nat ? launch_col_direct_t<2, true>(p, grid, stream) : launch_col_direct_t<2, false>(p, grid, stream);
+        case 3: return nat ? launch_col_direct_t<3, true>(p, grid, stream) : launch_col_direct_t<3, false>(p, grid, stream);   // 2048-point columns, 64-byte segments
         default: return hipErrorInvalidValue;
     }
 }

@@ -73,7 +73,7 @@ def run(LOGG, natural, log_n=20, b=5, seed=1):
     print("LOGG", LOGG, "natural", natural, "mismatches", bad)
     return bad
 tot = 0
-for lg in (2, 1, 0):
+for lg in (3, 2, 1, 0):
     for nat in (True, False):
         tot += run(lg, nat)
 sys.exit(1 if tot else 0)
