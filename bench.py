@@ -583,6 +583,11 @@ def main():
             extra["commit_leaf_hashing_frac_of_commit_ms"] = hk["avg_us_per_launch"] * 1e-3 * ((args.commit_cols + 15) // 16) / extra["commit_ms"] \
                 if "chunk" in hk["kernel"] else None
 
+    if dist.world > 1 and not args.no_commit:
+        sc = bench_sharded_commit(pg, ctx, dist, args.commit_cols, args.commit_log_n)
+        if dist.rank == 0:
+            extra["sharded_commit"] = sc
+
     if not args.no_prove:
         pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
         if dist.rank == 0:
@@ -734,6 +739,63 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
         }
     d_wires.free()
     return res
+
+
+def bench_sharded_commit(pg, ctx, dist, cols, log_n, rate_bits=3, cap_height=4, iters=2):
+    """N > 1 only: ONE commit of configs[2] with its columns sharded over the ranks (second row; plonky2_gpu_amd/dist.py
+    ShardedCommitPlan): rank r transforms its slice of the columns, the path's one exchange regroups leaf ranges (every rank sends
+    each peer the peer's leaf range of its own columns, point to point: on an xGMI mesh every link carries one pair), each rank
+    hashes its leaves and its cap subtrees, the cap is gathered. Reported with the bytes that cross the links, so that the first run
+    on a node with a device per rank reads as xGMI GB/s without a code change; with ranks sharing a device (gloo, staged through
+    the host) the same figures describe the host path instead."""
+    from plonky2_gpu_amd.dist import ShardedCommitPlan
+
+    W = dist.world
+    if W & (W - 1) or W > (1 << cap_height):
+        return {"absent_because": f"{W} ranks: the sharded commit wants a power of two, at most 2^cap_height"}
+    n, n_ext = 1 << log_n, (1 << log_n) << rate_bits
+    plan = ShardedCommitPlan(dist, ctx, cols, log_n, rate_bits, cap_height)
+    mine = plan.mine
+    d_vals = pg.DeviceBuffer(ctx, max(mine, 1) * n)
+    d_work = pg.DeviceBuffer(ctx, max(mine, 1) * n)
+    for c0 in range(0, cols, 16):  # the very matrix of bench_commit (same chunks of the SplitMix64 stream), my columns of it
+        k = min(16, cols - c0)
+        lo, hi = max(c0, plan.col_lo), min(c0 + k, plan.col_hi)
+        if lo < hi:
+            block = splitmix64_field(k * n, start=(1 << 50) + c0 * n * 2).reshape(k, n)
+            d_vals.upload(block[lo - c0:hi - c0], (lo - plan.col_lo) * n)
+    from plonky2_gpu_amd import _lib
+
+    times, caps = [], []
+    for it in range(iters + 1):
+        _lib.call("gl_memcpy_d2d", d_work.ptr, d_vals.ptr, max(mine, 1) * n * 8, ctx.ptr)
+        ctx.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        res = plan.commit(d_work)
+        ctx.synchronize()
+        dist.barrier()
+        dt = dist.max(time.perf_counter() - t)
+        if it:
+            times.append(dt)
+        caps.append(np.asarray(res.cap).tobytes())
+    ms = float(np.median(times)) * 1e3
+    sent_per_rank = 8 * mine * plan.L * (W - 1)          # my columns, every peer's leaf range
+    per_link = 8 * mine * plan.L                          # what one (ordered) pair of ranks moves one way
+    out = {"workload": f"configs[2] as ONE commit over {W} ranks: {cols} columns x 2^{log_n} rows, rate 8, cap_height {cap_height}; columns {plan.bounds}",
+           "commit_ms": ms, "merkle_leaves_per_s": n_ext / (ms * 1e-3), "deterministic": all(c == caps[0] for c in caps),
+           "cap0": [hex(int(x)) for x in np.frombuffer(caps[0], dtype=np.uint64)[:4]],
+           "exchange": {"bytes_sent_per_rank": sent_per_rank, "bytes_per_link_one_way": per_link, "links_used_per_rank": W - 1,
+                        "bytes_all_ranks": sent_per_rank * W,
+                        "GBps_per_rank_if_it_took_the_whole_commit": sent_per_rank / (ms * 1e-3) / 1e9,
+                        "GBps_per_link_if_it_took_the_whole_commit": per_link / (ms * 1e-3) / 1e9,
+                        "xgmi_link_peak_GBps": 153.0, "note": "the exchange is posted per 16-column chunk under the remaining LDE; these rates divide "
+                        "by the WHOLE commit time and are lower bounds of what the links carried",
+                        "transport": "RCCL point to point between device buffers" if dist.backend == "nccl" else f"{dist.backend}: staged through host memory (ranks share a device)"}}
+    plan.free()
+    d_vals.free()
+    d_work.free()
+    return out
 
 
 def bench_commit(pg, _lib, ctx, cols, log_n, rate_bits=3, cap_height=4, iters=3):

@@ -77,6 +77,10 @@ def test_bench_with_two_ranks_prints_one_line_for_the_whole_job(gpu, launcher):
     assert d["extra"]["commit_ms"] > 0 and d["extra"]["prove"]["proofs_per_s_all_gpus"] > 0
     assert len(d["extra"]["prove"]["proofs_per_s_per_rank"]) == 2 and len(d["extra"]["prove"]["wires_cap0_per_rank"]) == 2
     assert d["config"]["pairs_per_step"] >= 1 and d["value_windows"]["count"] >= 1
+    # the column-sharded commit of configs[2] over the two ranks, with the bytes its one exchange moves
+    sc = d["extra"]["sharded_commit"]
+    assert sc["commit_ms"] > 0 and sc["deterministic"] and sc["cap0"] == d["extra"]["cap0"], sc  # same values, same cap as the one-GPU commit
+    assert sc["exchange"]["links_used_per_rank"] == 1 and sc["exchange"]["bytes_per_link_one_way"] == 8 * 68 * (1 << 22)
 
 
 def _device_count():

@@ -128,10 +128,10 @@ def test_full_size_round_trip_and_linearity(gpu, oracle):
     assert [int(v) for v in fz[idx]] == [(a * int(u) + int(v)) % P for u, v in zip(f0[0, idx], f0[1, idx])]
 
 
-@pytest.mark.parametrize("log_n", [21, 22, 23])
+@pytest.mark.parametrize("log_n", [21, 22, 23, 24])
 def test_ntt_three_pass_sizes(gpu, oracle, log_n):
-    """2^21..2^23 (the three-pass plan): oracle equality on one column, round trip and the
-    bit-reversed variant on a second one."""
+    """2^21 (two passes, 2048-point direct column pass) and 2^22..2^24 (the three-pass plan; 2^24 is the largest size
+    gl_ntt_batch accepts): oracle equality on both columns, round trip, and the bit-reversed variant on the second one."""
     import plonky2_gpu_amd as pg
 
     n = 1 << log_n
@@ -144,9 +144,9 @@ def test_ntt_three_pass_sizes(gpu, oracle, log_n):
     assert (b == exp[1][bitrev_perm(log_n)]).all()
 
 
-@pytest.mark.parametrize("log_n,rate_bits", [(21, 1), (22, 1), (23, 0)])
+@pytest.mark.parametrize("log_n,rate_bits", [(21, 1), (22, 1), (23, 0), (21, 3), (24, 0)])
 def test_coset_lde_three_pass(gpu, oracle, log_n, rate_bits):
-    """Coset LDE of the large sizes: 2^21 in two passes (split 2048-point columns), 2^22 and 2^23 in three."""
+    """Coset LDE of the large sizes: 2^21 in two passes (split 2048-point columns), 2^22 .. 2^24 points in three."""
     import plonky2_gpu_amd as pg
 
     c = oracle.random_field((2, 1 << log_n), seed=6000)
@@ -236,3 +236,18 @@ def test_ntt_argument_errors(gpu):
     with pytest.raises(ValueError):
         pg.fft_with_options(gpu, np.zeros(12, dtype=np.uint64))  # not a power of two
     _lib.call("gl_ntt_batch", buf.ptr, 0, 10, 1024, 0, 0, gpu.ptr)  # empty batch is a no-op
+
+
+def test_sizes_above_the_limit_are_rejected(gpu):
+    """log_n <= 24 is the documented limit of gl_ntt_batch / gl_coset_lde_batch (include/plonky2_hip.h): beyond it an error, not a wrong answer"""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    buf = pg.DeviceBuffer(gpu, 16)
+    with pytest.raises(pg.Plonky2HipError) as e:
+        _lib.call("gl_ntt_batch", buf.ptr, 1, 25, 1 << 25, 0, 0, gpu.ptr)
+    assert e.value.code == pg.GL_E_INVALID
+    with pytest.raises(pg.Plonky2HipError) as e:
+        _lib.call("gl_coset_lde_batch", buf.ptr, buf.ptr, 1, 25, 0, 7, 1 << 25, 1 << 25, gpu.ptr)
+    assert e.value.code == pg.GL_E_INVALID
+    buf.free()
