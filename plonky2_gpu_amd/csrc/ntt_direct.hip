@@ -30,25 +30,19 @@ namespace nttk {
 
 namespace {
 
-// Diagnostic builds (tools/gpu_runs/ntt_direct_variants.sh; never the product, their results are wrong by design):
-//   DIRECT_DIAG_SAME_LOADS   every tile loads tile 0's addresses (served by L2)     -> what the load latency costs
-//   DIRECT_DIAG_SAME_STORES  every tile stores to tile 0's addresses                 -> what the store traffic costs
-//   DIRECT_DIAG_NO_BARRIER   the two workgroup barriers of a tile are dropped        -> what waiting for the slowest wave costs
-//   DIRECT_DIAG_TAIL_FRONT   the sixteen tail steps run before the first rounds      -> what spreading the stores buys
-#ifdef DIRECT_DIAG_NO_BARRIER
-#define DIRECT_TILE_BARRIER() tile_sync<64>()
-#else
+// Hook points of the diagnostic builds: tools/experiments/ntt_direct_diag.hip sets them and then includes this file (its results
+// are wrong by design; tools/gpu_runs/ntt_direct_variants.sh). The product compiles this file as it stands: every hook is the
+// identity / false.
+#ifndef DIRECT_DIAG_HOOKS
 #define DIRECT_TILE_BARRIER() lds_barrier()
-#endif
-#ifdef DIRECT_DIAG_SAME_LOADS
-#define DIRECT_LOAD_TILE(t) 0u
-#else
 #define DIRECT_LOAD_TILE(t) (t)
-#endif
-#ifdef DIRECT_DIAG_SAME_STORES
-#define DIRECT_STORE_TILE(t) 0u
-#else
 #define DIRECT_STORE_TILE(t) (t)
+#define DIRECT_DIAG_TAIL_FRONT_ON 0
+#define DIRECT_DIAG_SAME_STORES_ON 0
+#define DIRECT_NT_LOAD_COL false
+#define DIRECT_NT_STORE_COL false
+#define DIRECT_NT_LOAD_ROW false
+#define DIRECT_NT_STORE_ROW false
 #endif
 
 __device__ __forceinline__ uint64_t lds_ld(const unsigned char *lds, uint32_t off) { return *reinterpret_cast<const uint64_t *>(lds + off); }
@@ -67,26 +61,7 @@ __device__ __forceinline__ void g_st(uint64_t *base, uint32_t byte_off, uint64_t
     else
         *q = v;
 }
-#ifdef DIRECT_DIAG_NT_LOAD_COL
-constexpr bool NT_LOAD_COL = true;
-#else
-constexpr bool NT_LOAD_COL = false;
-#endif
-#ifdef DIRECT_DIAG_NT_STORE_COL
-constexpr bool NT_STORE_COL = true;
-#else
-constexpr bool NT_STORE_COL = false;
-#endif
-#ifdef DIRECT_DIAG_NT_LOAD_ROW
-constexpr bool NT_LOAD_ROW = true;
-#else
-constexpr bool NT_LOAD_ROW = false;
-#endif
-#ifdef DIRECT_DIAG_NT_STORE_ROW
-constexpr bool NT_STORE_ROW = true;
-#else
-constexpr bool NT_STORE_ROW = false;
-#endif
+constexpr bool NT_LOAD_COL = DIRECT_NT_LOAD_COL, NT_STORE_COL = DIRECT_NT_STORE_COL, NT_LOAD_ROW = DIRECT_NT_LOAD_ROW, NT_STORE_ROW = DIRECT_NT_STORE_ROW;
 
 template <int LOGG>
 struct ColGeom {
@@ -253,9 +228,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 cstep8 = gl::mul(s4, s4);
             }
         }
-#ifdef DIRECT_DIAG_SAME_STORES
-        tile_of(0, b, a, z);
-#endif
+        if constexpr (DIRECT_DIAG_SAME_STORES_ON) tile_of(0, b, a, z);
         obase = p.dst + (a * p.out_sa + b * p.out_sb + (COSET ? brev_rt(z, p.rate_bits) : z) * p.out_sz);
         if constexpr (COSET) cc = gl::mul(cc0, lds_ld(CS, (z * C + (opaque_lane() & (C - 1))) * 8));
         else cc = cc0;
@@ -288,12 +261,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             uint32_t b_, a_;
             tile_of(t_in_a, b_, a_, zc);
         }
-#ifdef DIRECT_DIAG_TAIL_FRONT
-        if constexpr (with_tail) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
-#define TAIL(lo, hi) do { } while (0)
-#else
-#define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
-#endif
+        if constexpr (with_tail && DIRECT_DIAG_TAIL_FRONT_ON) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+#define TAIL(lo, hi) do { if constexpr (with_tail && !DIRECT_DIAG_TAIL_FRONT_ON) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
         TAIL(0, 4);   // four results leave before the butterflies need their temporaries
         if constexpr (COSET) {
             const uint32_t cu_base = (G > 1 ? (zc * G + (opaque_lane() >> LOGC)) * 16 : (zc * 16 + wave) * 16) * 8;
@@ -518,12 +487,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     auto first_rounds = [&](auto WITH_TAIL_) {
         constexpr bool with_tail = decltype(WITH_TAIL_)::value;
-#ifdef DIRECT_DIAG_TAIL_FRONT
-        if constexpr (with_tail) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
-#define TAIL(lo, hi) do { } while (0)
-#else
-#define TAIL(lo, hi) do { if constexpr (with_tail) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
-#endif
+        if constexpr (with_tail && DIRECT_DIAG_TAIL_FRONT_ON) tail_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 16>{});
+#define TAIL(lo, hi) do { if constexpr (with_tail && !DIRECT_DIAG_TAIL_FRONT_ON) tail_units(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{}); } while (0)
         TAIL(0, 3);
         radix_dif_stage<4, 0, 3>(A);
         TAIL(3, 5);

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
     for v in $VARIANTS; do
         mkdir -p $V/$v
         D=""; for f in ${v//+/ }; do D="$D -DDIRECT_DIAG_$f"; done
-        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $D -c plonky2_gpu_amd/csrc/ntt_direct.hip -o /tmp/ntt_direct_$v.o &&
+        /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 $D -I plonky2_gpu_amd/csrc -c tools/experiments/ntt_direct_diag.hip -o /tmp/ntt_direct_$v.o &&
             /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/ntt_direct_$v.o $(ls plonky2_gpu_amd/csrc/build/*.o | grep -v "ntt_direct\|debug_") -lhiprtc -o $V/$v/libplonky2_hip.so || exit 1
     done
     exit 0
