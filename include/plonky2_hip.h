@@ -368,6 +368,9 @@ typedef struct GlFriParams {
     uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
     uint32_t num_reductions;
     const uint32_t *reduction_arity_bits; /* host, num_reductions */
+    uint32_t hiding; /* FriParams::hiding = CircuitConfig::zero_knowledge (fri/mod.rs:64-65, plonk/circuit_data.rs:74): the wires, Zs /
+                      * partial products and quotient commitments carry SALT_SIZE = 4 random elements per leaf (fri/oracle.rs:41,
+                      * 985-1002); such a circuit is proved with gl_prove_zk */
 } GlFriParams;
 typedef struct GlCircuitDesc {
     uint32_t degree_bits, num_wires, num_routed_wires, num_constants, num_challenges, quotient_degree_factor;
@@ -396,6 +399,16 @@ GlError gl_circuit_trim(void *circuit);
 GlError gl_circuit_info(const void *circuit, uint64_t *h_digest, uint64_t *h_constants_sigmas_cap);
 GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
                  uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx);
+/* prove() of a circuit built with zero_knowledge = true (fri.hiding != 0): the three blinded commitments — wires, Zs / partial
+ * products, quotient chunks (plonk/prover.rs:84, 125, 174; PlonkOracle::*.blinding, plonk/plonk_common.rs:20-44) — get SALT_SIZE = 4
+ * extra elements per leaf, which the proof's initial-tree openings carry and the verifier strips (fri/proof.rs:45-52).
+ * The reference draws them from OsRng (F::rand_vec, fri/oracle.rs:998-1002); here the randomness is the CALLER's:
+ *   d_salts  [3][4][n_ext] uniform field elements (n_ext = 2^(degree_bits + rate_bits)): block 0 for the wires commitment, 1 for
+ *            Zs / partial products, 2 for the quotient; column k of a block is element k of the salt of every leaf, in LEAF order
+ *            (entry j belongs to leaf j, the leaf of the LDE point bitrev(j)).
+ * gl_prove on a hiding circuit and gl_prove_zk on a non-hiding one return GL_E_INVALID. */
+GlError gl_prove_zk(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                    const uint64_t *d_salts, uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx);
 void gl_bytes_free(uint8_t *p);
 
 /* ---------------------------------------------------------------------------------------------

@@ -37,8 +37,14 @@ def circuit_digest(constants_sigmas_cap, degree_bits, domain_separator=()):
     return pyref.hash_no_pad(parts)
 
 
-def commit_from_coeffs(coeffs, rate_bits, cap_height):
-    """PolynomialBatch::from_coeffs (fri/oracle.rs:911-977), no blinding."""
+SALT_SIZE = 4  # fri/oracle.rs:41
+
+
+def commit_from_coeffs(coeffs, rate_bits, cap_height, salt=None):
+    """PolynomialBatch::from_coeffs (fri/oracle.rs:911-977). `salt` (blinding, oracle.rs:985-1002: SALT_SIZE extra columns of
+    rate * n random elements appended to the LDE's columns before the transposition): SALT_SIZE columns given in LEAF order —
+    entry j is the element of leaf j, i.e. of the natural-order random vector at bitrev(j); the reference draws them from OsRng,
+    so any order of a uniform vector is the same distribution and the leaf order is what a device buffer holds."""
     n_ext = len(coeffs[0]) << rate_bits
     lde = []
     for c in coeffs:
@@ -46,11 +52,16 @@ def commit_from_coeffs(coeffs, rate_bits, cap_height):
         lde.append(pyref.fast_ntt(scaled))
     lg = pyref.log2_strict(n_ext)
     leaves = [[col[pyref.reverse_bits(i, lg)] for col in lde] for i in range(n_ext)]
+    if salt is not None:
+        assert len(salt) == SALT_SIZE and all(len(col) == n_ext for col in salt)
+        leaves = [row + [int(col[i]) % P for col in salt] for i, row in enumerate(leaves)]
     digests, cap = pyref.merkle_tree(leaves, cap_height)
     return dict(polynomials=[list(c) for c in coeffs], leaves=leaves, digests=digests, cap=cap)
 
 
-def commit_from_values(values, rate_bits, cap_height):
+def commit_from_values(values, rate_bits, cap_height, salt=None):
+    if salt is not None:  # from_values = ifft per column, then from_coeffs (oracle.rs:709-731)
+        return commit_from_coeffs([pyref.fast_ntt(list(v), inverse=True) for v in values], rate_bits, cap_height, salt)
     coeffs, leaves, digests, cap = pyref.commit_from_values(values, rate_bits, cap_height)
     return dict(polynomials=coeffs, leaves=leaves, digests=digests, cap=cap)
 
@@ -83,15 +94,20 @@ def fri_openings(openings):
             + openings["quotient_polys"], openings["plonk_zs_next"]]
 
 
-def prove(circuit, wires, public_inputs, trace=None):
+def prove(circuit, wires, public_inputs, trace=None, salts=None):
     """plonk/prover.rs:40-233 from the full witness (wire columns) on. `trace` (a dict) receives the intermediate objects
-    the reference can dump (prover.rs:829-877): commitments, Z / partial-product values, challenges, quotient polynomials."""
+    the reference can dump (prover.rs:829-877): commitments, Z / partial-product values, challenges, quotient polynomials.
+    With fri_params["hiding"] (CircuitConfig::zero_knowledge, circuit_data.rs:74) the wires, Zs / partial products and quotient
+    commitments are blinded (prover.rs:84, 125, 174): `salts` = [3][SALT_SIZE][n_ext] in leaf order (see commit_from_coeffs)."""
     fp = circuit["fri_params"]
+    hiding = bool(fp.get("hiding"))
+    assert hiding == (salts is not None), "salts are given exactly when the circuit is hiding"
+    salt_w, salt_z, salt_q = salts if hiding else (None, None, None)
     rate_bits, cap_height = fp["rate_bits"], fp["cap_height"]
     db, n = circuit["degree_bits"], 1 << circuit["degree_bits"]
     nch, qdf, num_routed = circuit["num_challenges"], circuit["quotient_degree_factor"], circuit["num_routed_wires"]
     pih = pyref.hash_no_pad(public_inputs)
-    wires_c = commit_from_values(wires, rate_bits, cap_height)
+    wires_c = commit_from_values(wires, rate_bits, cap_height, salt_w)
     ch = fri_ref.Challenger()
     ch.observe_elements(circuit["circuit_digest"])
     ch.observe_elements(pih)
@@ -100,7 +116,7 @@ def prove(circuit, wires, public_inputs, trace=None):
     assert qdf < num_routed
     subgroup = [pow(pyref.root_of_unity(db), i, P) for i in range(n)]
     zs_pp = plonk_ref.zs_partial_products(wires, circuit["sigmas"], circuit["k_is"], betas, gammas, qdf, subgroup)
-    zs_c = commit_from_values(zs_pp, rate_bits, cap_height)
+    zs_c = commit_from_values(zs_pp, rate_bits, cap_height, salt_z)
     ch.observe_cap(zs_c["cap"])
     alphas = ch.get_n_challenges(nch)
     cs = circuit["constants_sigmas"]
@@ -113,13 +129,14 @@ def prove(circuit, wires, public_inputs, trace=None):
         gate_terms.append(plonk_ref.evaluate_gate_constraints(gates, circuit["selector_indices"], circuit["groups"],
                                                               circuit["num_gate_constraints"], cs["leaves"][row][: circuit["num_constants"]],
                                                               wires_c["leaves"][row], pih))
-    quotient_polys = plonk_ref.compute_quotient_polys(wires_c["leaves"], cs["leaves"], zs_c["leaves"], circuit["num_constants"],
+    unsalted = lambda c: [row[: len(c["polynomials"])] for row in c["leaves"]] if hiding else c["leaves"]  # noqa: E731  get_lde_values, oracle.rs:1007-1018
+    quotient_polys = plonk_ref.compute_quotient_polys(unsalted(wires_c), cs["leaves"], unsalted(zs_c), circuit["num_constants"],
                                                       circuit["k_is"], betas, gammas, alphas, db, rate_bits, qdf, gate_terms)
     chunks = []
     for q in quotient_polys:
         assert all(c == 0 for c in q[n * qdf :]), "Quotient has failed, the vanishing polynomial is not divisible by Z_H"
         chunks += [q[k : k + n] for k in range(0, n * qdf, n)]
-    quot_c = commit_from_coeffs(chunks, rate_bits, cap_height)
+    quot_c = commit_from_coeffs(chunks, rate_bits, cap_height, salt_q)
     ch.observe_cap(quot_c["cap"])
     zeta = ch.get_extension_challenge()
     assert ext_pow(zeta, n) != (1, 0), "Opening point is in the subgroup."

@@ -80,6 +80,7 @@ class GlFriParams(ctypes.Structure):
         ("num_query_rounds", ctypes.c_uint32),
         ("num_reductions", ctypes.c_uint32),
         ("reduction_arity_bits", ctypes.c_void_p),
+        ("hiding", ctypes.c_uint32),
     ]
 
 
@@ -161,6 +162,7 @@ SIGNATURES = {
     "gl_circuit_trim": (GlError, [_vp]),
     "gl_circuit_info": (GlError, [_vp, _vp, _vp]),
     "gl_prove": (GlError, [_vp, _vp, _vp, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
+    "gl_prove_zk": (GlError, [_vp, _vp, _vp, _u32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
     "gl_bytes_free": (None, [_vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),
     "gl_eval_polys_ext2": (GlError, [_vp, _u64, _u32, _u64, _vp, _u32, _vp, _vp]),

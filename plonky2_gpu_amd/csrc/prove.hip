@@ -119,6 +119,7 @@ struct DevBuf {  // RAII device buffer of u64
 struct Batch {
     DevBuf coeffs, lde, digests, cap_d;
     uint32_t n_polys = 0;
+    uint32_t leaf_len = 0;  // n_polys + the salt of a blinded commitment (fri/oracle.rs:985-1002)
     std::vector<uint64_t> cap;  // host copy, 4 << cap_height
 };
 
@@ -190,6 +191,7 @@ GlError hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4], void *ctx) { 
 struct Circuit {
     uint32_t degree_bits, num_wires, num_routed, num_constants, num_challenges, qdf, num_gate_constraints;
     uint32_t rate_bits, cap_height, pow_bits, num_queries;
+    bool hiding = false;  // FriParams::hiding
     std::vector<uint32_t> arity_bits;
     uint64_t digest[4];
     DevBuf k_is, sigmas;
@@ -206,18 +208,25 @@ struct Circuit {
 
 uint32_t num_partial_products(uint32_t routed, uint32_t qdf) { return (routed + qdf - 1) / qdf - 1; }
 
-GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx) {
+constexpr uint32_t SALT_SIZE = 4;  // fri/oracle.rs:41
+
+// d_salt: SALT_SIZE columns of n_ext caller-provided random elements in leaf order (a blinded commitment, prover.rs:84, 125, 174), or null
+GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx, const uint64_t *d_salt = nullptr) {
     const uint64_t n_ext = 1ull << (c.degree_bits + c.rate_bits);
+    const uint32_t salt = d_salt ? SALT_SIZE : 0;
     b->coeffs = std::move(polys);
     b->n_polys = n_polys;
-    TRY(b->lde.alloc((uint64_t)n_polys * n_ext));
+    b->leaf_len = n_polys + salt;
+    TRY(b->lde.alloc((uint64_t)b->leaf_len * n_ext));
     TRY(b->digests.alloc(8 * (n_ext - (1ull << c.cap_height))));
     TRY(b->cap_d.alloc(4ull << c.cap_height));
+    // the salt columns sit behind the LDE's columns and are hashed with them (gl_commit_from_*: "read as given")
+    if (salt) TRY(gl_memcpy_d2d(b->lde.p + (uint64_t)n_polys * n_ext, d_salt, 8ull * salt * n_ext, ctx));
     if (from_values)
-        TRY(gl_commit_from_values(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, 0, 7, b->lde.p, nullptr, b->digests.p,
+        TRY(gl_commit_from_values(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, salt, 7, b->lde.p, nullptr, b->digests.p,
                                   b->cap_d.p, ctx));
     else
-        TRY(gl_commit_from_coeffs(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, 0, 7, b->lde.p, nullptr, b->digests.p,
+        TRY(gl_commit_from_coeffs(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, salt, 7, b->lde.p, nullptr, b->digests.p,
                                   b->cap_d.p, ctx));
     b->cap.resize(4ull << c.cap_height);
     return gl_memcpy_d2h(b->cap.data(), b->cap_d.p, b->cap.size() * 8, ctx);
@@ -271,6 +280,7 @@ GlError gl_circuit_create(const GlCircuitDesc *d, void **circuit, void *ctx) {
     c->num_gate_constraints = d->num_gate_constraints;
     c->rate_bits = d->fri.rate_bits, c->cap_height = d->fri.cap_height, c->pow_bits = d->fri.proof_of_work_bits;
     c->num_queries = d->fri.num_query_rounds;
+    c->hiding = d->fri.hiding != 0;
     c->arity_bits.assign(d->fri.reduction_arity_bits, d->fri.reduction_arity_bits + d->fri.num_reductions);
     const uint64_t n = 1ull << c->degree_bits;
     auto bail = [&](GlError e) {
@@ -359,10 +369,12 @@ GlError gl_circuit_info(const void *circuit, uint64_t h_digest[4], uint64_t *h_c
 
 void gl_bytes_free(uint8_t *p) { free(p); }
 
-GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
-                 uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
+static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                          const uint64_t *d_salts, uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
     if (!circuit || !d_wires || !proof || !proof_len || !ctx || (num_public_inputs && !h_public_inputs)) return fail("null pointer");
     const Circuit &c = *static_cast<const Circuit *>(circuit);
+    if (c.hiding && !d_salts) return fail("the circuit's FRI parameters are hiding (zero_knowledge): prove it with gl_prove_zk and salt columns");
+    if (!c.hiding && d_salts) return fail("gl_prove_zk on a circuit whose FRI parameters are not hiding");
     PoolScope pool_scope(&c.pool);  // every DevBuf below comes from / returns to the circuit's pool
     const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf;
     const uint64_t n = 1ull << db, n_ext = n << c.rate_bits;
@@ -378,7 +390,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
         DevBuf w;
         TRY(w.alloc((uint64_t)c.num_wires * n));
         TRY(gl_memcpy_d2d(w.p, d_wires, 8ull * c.num_wires * n, ctx));
-        TRY(commit(&wires, std::move(w), true, c.num_wires, c, ctx));
+        TRY(commit(&wires, std::move(w), true, c.num_wires, c, ctx, d_salts));
     }
     TRY(st.mark(0));
     Challenger ch(ctx);
@@ -396,7 +408,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
         TRY(gl_permutation_partial_products(d_wires, n, c.sigmas.p, n, c.k_is.p, betas.data(), gammas.data(), nch, c.num_routed, qdf, db, z.p,
                                             ctx));
         TRY(st.mark(1));
-        TRY(commit(&zs, std::move(z), true, nch * (1 + npp), c, ctx));
+        TRY(commit(&zs, std::move(z), true, nch * (1 + npp), c, ctx, d_salts ? d_salts + (uint64_t)SALT_SIZE * n_ext : nullptr));
     }
     TRY(st.mark(2));
     TRY(ch.observe(zs.cap));
@@ -450,7 +462,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
                 TRY(gl_memcpy_d2d(chunks.p + (uint64_t)k * qdf * n, quotient.p + ((uint64_t)k << (db + qdb)), 8ull * qdf * n, ctx));
             }
         }
-        TRY(commit(&quot, std::move(chunks), false, nch * qdf, c, ctx));
+        TRY(commit(&quot, std::move(chunks), false, nch * qdf, c, ctx, d_salts ? d_salts + 2ull * SALT_SIZE * n_ext : nullptr));
     }
     TRY(st.mark(4));
     TRY(ch.observe(quot.cap));
@@ -588,9 +600,9 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
     const uint32_t init_layers = lg_ext - c.cap_height;
     std::vector<uint64_t> init_leaves[4], init_sib[4];
     for (int o = 0; o < 4; o++) {
-        init_leaves[o].resize((uint64_t)c.num_queries * oracles[o]->n_polys);
+        init_leaves[o].resize((uint64_t)c.num_queries * oracles[o]->leaf_len);  // salted leaves go into the proof whole (fri/prover.rs:203-210)
         init_sib[o].resize((uint64_t)c.num_queries * init_layers * 4 + 4);
-        TRY(gl_merkle_open_batch(oracles[o]->lde.p, 1, n_ext, oracles[o]->n_polys, n_ext, c.cap_height, oracles[o]->digests.p, idx.data(),
+        TRY(gl_merkle_open_batch(oracles[o]->lde.p, 1, n_ext, oracles[o]->leaf_len, n_ext, c.cap_height, oracles[o]->digests.p, idx.data(),
                                  c.num_queries, init_leaves[o].data(), init_sib[o].data(), ctx));
     }
     std::vector<std::vector<uint64_t>> step_leaves(layers.size()), step_sib(layers.size());
@@ -624,7 +636,7 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
     for (auto &L : layers) out.fields(L.cap);
     for (uint32_t q = 0; q < c.num_queries; q++) {
         for (int o = 0; o < 4; o++) {
-            out.fields(init_leaves[o].data() + (uint64_t)q * oracles[o]->n_polys, oracles[o]->n_polys);
+            out.fields(init_leaves[o].data() + (uint64_t)q * oracles[o]->leaf_len, oracles[o]->leaf_len);
             out.merkle_proof(init_sib[o].data() + (uint64_t)q * init_layers * 4, init_layers);
         }
         for (size_t li = 0; li < layers.size(); li++) {
@@ -642,6 +654,17 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
     *proof = buf;
     *proof_len = out.v.size();
     return st.mark(10);
+}
+
+GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                 uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
+    return prove_impl(circuit, d_wires, h_public_inputs, num_public_inputs, nullptr, proof, proof_len, h_stage_ms, ctx);
+}
+
+GlError gl_prove_zk(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
+                    const uint64_t *d_salts, uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
+    if (!d_salts) return fail("gl_prove_zk: null salt columns");
+    return prove_impl(circuit, d_wires, h_public_inputs, num_public_inputs, d_salts, proof, proof_len, h_stage_ms, ctx);
 }
 
 }  // extern "C"

@@ -298,7 +298,7 @@ class NativeCircuit:
             circuit["degree_bits"], circuit["num_wires"], circuit["num_routed_wires"], circuit["num_constants"], circuit["num_challenges"],
             circuit["quotient_degree_factor"], circuit["num_gate_constraints"],
             _lib.GlFriParams(fp["rate_bits"], fp["cap_height"], fp["proof_of_work_bits"], fp["num_query_rounds"], arity.size,
-                             arity.ctypes.data),
+                             arity.ctypes.data, 1 if fp.get("hiding") else 0),
             k_is.ctypes.data, consts.ctypes.data, sigmas.ctypes.data,
             instrs.ctypes.data, instrs.size // 4, descs.ctypes.data, descs.size // 6,
             imms.ctypes.data if imms is not None else None, 0 if imms is None else imms.size, len(circuit["groups"]),
@@ -312,13 +312,19 @@ class NativeCircuit:
         self.circuit_digest = [int(x) for x in dg]
         self.constants_sigmas_cap = cap.reshape(-1, 4).tolist()
 
-    def prove_bytes(self, wires, public_inputs, timing=None):
-        """gl_prove: the proof in the reference's wire format. `wires`: host [num_wires][n] or a DeviceBuffer."""
+    def prove_bytes(self, wires, public_inputs, timing=None, salts=None):
+        """gl_prove: the proof in the reference's wire format. `wires`: host [num_wires][n] or a DeviceBuffer.
+        `salts` (a circuit with fri_params["hiding"], i.e. zero_knowledge): [3][4][n_ext] uniform field elements, host or DeviceBuffer —
+        the blinding of the wires, Zs / partial products and quotient commitments in leaf order (gl_prove_zk)."""
         d_w = wires if isinstance(wires, DeviceBuffer) else DeviceBuffer.from_host(self.ctx, _host_u64(wires))
         pis = _host_u64(public_inputs)
         out, ln = ctypes.c_void_p(), ctypes.c_uint64()
         ms = np.zeros(_lib.GL_PROVE_STAGES, dtype=np.float64) if timing is not None else None
-        _lib.call("gl_prove", self.ptr, d_w.ptr, pis, pis.size, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
+        if salts is not None:
+            d_s = salts if isinstance(salts, DeviceBuffer) else DeviceBuffer.from_host(self.ctx, _host_u64(salts))
+            _lib.call("gl_prove_zk", self.ptr, d_w.ptr, pis, pis.size, d_s.ptr, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
+        else:
+            _lib.call("gl_prove", self.ptr, d_w.ptr, pis, pis.size, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
         data = ctypes.string_at(out.value, ln.value)
         _lib.load().gl_bytes_free(out.value)
         if timing is not None:
@@ -326,10 +332,10 @@ class NativeCircuit:
                 timing[name] = timing.get(name, 0.0) + float(v)
         return data
 
-    def prove(self, wires, public_inputs, timing=None):
+    def prove(self, wires, public_inputs, timing=None, salts=None):
         from . import serialization
 
-        return serialization.proof_from_bytes(self.prove_bytes(wires, public_inputs, timing), self.circuit)
+        return serialization.proof_from_bytes(self.prove_bytes(wires, public_inputs, timing, salts), self.circuit)
 
     def trim(self):
         """release the working buffers gl_prove keeps attached to the circuit between proofs"""

@@ -110,7 +110,7 @@ def proof_to_bytes(proof):
 def proof_from_bytes(data, common):
     """read_proof_with_public_inputs (serialization.rs:306-348). `common` carries the shape fields of
     CommonCircuitData: num_constants, num_routed_wires, num_wires, num_challenges,
-    quotient_degree_factor, degree_bits, fri_params (no blinding: salt_size 0)."""
+    quotient_degree_factor, degree_bits, fri_params (with fri_params["hiding"]: salted leaves)."""
     get = (lambda k: common[k]) if isinstance(common, dict) else (lambda k: getattr(common, k))
     fp = get("fri_params")
     nch, qdf = get("num_challenges"), get("quotient_degree_factor")
@@ -123,7 +123,10 @@ def proof_from_bytes(data, common):
         wires=b.read_field_ext_vec(get("num_wires")), plonk_zs=b.read_field_ext_vec(nch), plonk_zs_next=b.read_field_ext_vec(nch),
         partial_products=b.read_field_ext_vec(npp * nch), quotient_polys=b.read_field_ext_vec(qdf * nch))
     caps = [b.read_merkle_cap(h) for _ in fp["reduction_arity_bits"]]
-    leaf_lens = [get("num_constants") + get("num_routed_wires"), get("num_wires"), nch * (1 + npp), nch * qdf]
+    # read_fri_initial_proof (serialization.rs:196-239): with fri_params.hiding the three blinded oracles' leaves end in SALT_SIZE = 4
+    # elements (salt_size, plonk/plonk_common.rs:46-52; constants/sigmas are never blinded)
+    salt = 4 if fp.get("hiding") else 0
+    leaf_lens = [get("num_constants") + get("num_routed_wires"), get("num_wires") + salt, nch * (1 + npp) + salt, nch * qdf + salt]
     rounds = []
     for _ in range(fp["num_query_rounds"]):
         initial = []

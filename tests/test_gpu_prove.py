@@ -1,10 +1,13 @@
 """prove() on the device vs oracle/prove_ref.py: the proof is identical element for element and the
 oracle's verifier (which recomputes all challenges from the proof) accepts it."""
+import numpy as np
 import pytest
 
 from gpu_util import gpu  # noqa: F401
 from oracle import prove_ref
 from plonk_instance import make_circuit
+
+P = 0xFFFFFFFF00000001
 
 pytestmark = pytest.mark.gpu
 
@@ -528,3 +531,46 @@ def test_device_memory_does_not_grow_over_proofs_circuits_and_commits(gpu):
 
     gc.collect()
     assert free_bytes() >= base, "commits leak device memory"
+
+
+@pytest.mark.parametrize("which,degree_bits,compile_gates", [("mini", 5, True), ("mini2", 4, False), ("full", 4, True), ("mini", 10, True)])
+def test_blinded_proof_bytes_equal_the_oracle(gpu, which, degree_bits, compile_gates):
+    """gl_prove_zk: a circuit with fri_params.hiding (CircuitConfig::zero_knowledge, plonk/circuit_data.rs:74) — the wires, Zs /
+    partial products and quotient commitments carry SALT_SIZE = 4 caller-supplied random elements per leaf (plonk/prover.rs:84, 125,
+    174; fri/oracle.rs:985-1002) — gives, with the same salts, the oracle's proof byte for byte; the oracle's verifier accepts it;
+    gl_prove refuses a hiding circuit and gl_prove_zk a plain one."""
+    import plonky2_gpu_amd as pg
+    from oracle import serialize_ref
+    from plonk_instance import make_full_circuit
+
+    if which == "full":
+        circuit, wires, pis = make_full_circuit(degree_bits, seed=5)
+    else:
+        circuit, wires, pis = make_circuit(degree_bits, seed=14, two_groups=which == "mini2", arity_bits=(2, 1) if degree_bits < 8 else (4, 4))
+    plain = circuit
+    circuit = dict(circuit, fri_params=dict(circuit["fri_params"], hiding=True))
+    n_ext = 1 << (circuit["degree_bits"] + circuit["fri_params"]["rate_bits"])
+    salts = np.random.default_rng(99 + degree_bits).integers(0, P, size=(3, 4, n_ext), dtype=np.uint64)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+    data = nc.prove_bytes(wires, pis, salts=salts)
+    if degree_bits <= 5:  # the pure-Python model; above it the C-accelerated one (same proofs, tests/test_oracle_prove.py)
+        exp = prove_ref.prove(circuit, wires, pis, salts=salts.tolist())
+    else:
+        from oracle import accel
+
+        with accel.c_backend():
+            exp = prove_ref.prove(circuit, wires, pis, salts=salts.tolist())
+    assert data == serialize_ref.proof_bytes(exp)
+    parsed = pg.serialization.proof_from_bytes(data, circuit)
+    assert prove_ref.verify(circuit, parsed)
+    assert len(parsed["opening_proof"]["query_round_proofs"][0]["initial_trees_proof"][1][0]) == circuit["num_wires"] + 4
+    # other salts, other commitments; the flag and the entry point go together
+    other = nc.prove_bytes(wires, pis, salts=(salts + np.uint64(1)) % np.uint64(P))
+    assert other[:32] != data[:32] and prove_ref.verify(circuit, pg.serialization.proof_from_bytes(other, circuit))
+    with pytest.raises(pg.Plonky2HipError, match="hiding"):
+        nc.prove_bytes(wires, pis)
+    nc.close()
+    nc2 = pg.NativeCircuit(gpu, dict(plain, circuit_digest=None), compile_gates=compile_gates)
+    with pytest.raises(pg.Plonky2HipError, match="not hiding"):
+        nc2.prove_bytes(wires, pis, salts=salts)
+    nc2.close()

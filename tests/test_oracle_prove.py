@@ -239,3 +239,45 @@ def test_the_2e14_row_all_gates_proof_fixture_is_what_its_generator_says():
         assert serialize_ref.proof_bytes(proof) == data
         assert prove_ref.verify(oc, proof)
 
+
+
+def _salts(circuit, seed):
+    import random
+
+    rng = random.Random(seed)
+    n_ext = 1 << (circuit["degree_bits"] + circuit["fri_params"]["rate_bits"])
+    return [[[rng.randrange(P) for _ in range(n_ext)] for _ in range(prove_ref.SALT_SIZE)] for _ in range(3)]
+
+
+@pytest.mark.parametrize("two_groups", [False, True])
+def test_blinded_proof_verifies_and_differs_only_through_the_salts(two_groups):
+    """CircuitConfig::zero_knowledge (plonk/circuit_data.rs:74): the wires, Zs / partial products and quotient commitments get
+    SALT_SIZE = 4 random elements per leaf (prover.rs:84, 125, 174; fri/oracle.rs:985-1002), the proof's initial-tree openings
+    carry them, the verifier strips them (fri/proof.rs:45-52). prove -> verify, serialise -> parse, other salts -> other caps,
+    the same openings at zeta only where the transcript allows (it does not: the caps feed the challenges)."""
+    from oracle import serialize_ref
+    from plonky2_gpu_amd import serialization
+
+    circuit, wires, pis = make_circuit(4, seed=77, two_groups=two_groups)
+    circuit = dict(circuit, fri_params=dict(circuit["fri_params"], hiding=True))
+    salts = _salts(circuit, 1)
+    proof = prove_ref.prove(circuit, wires, pis, salts=salts)
+    assert prove_ref.verify(circuit, proof)
+    nw = circuit["num_wires"]
+    for rnd in proof["opening_proof"]["query_round_proofs"]:
+        lens = [len(evals) for evals, _ in rnd["initial_trees_proof"]]
+        assert lens[0] == circuit["num_constants"] + circuit["num_routed_wires"] and lens[1] == nw + 4  # constants/sigmas are never blinded
+    data = serialize_ref.proof_bytes(proof)
+    parsed = serialization.proof_from_bytes(data, circuit)
+    assert serialization.proof_to_bytes(parsed) == data and prove_ref.verify(circuit, parsed)
+    other = prove_ref.prove(circuit, wires, pis, salts=_salts(circuit, 2))
+    assert other["wires_cap"] != proof["wires_cap"] and prove_ref.verify(circuit, other)
+    # a salt element changed in an opened leaf breaks its Merkle proof
+    bad = serialization.proof_from_bytes(data, circuit)
+    evals, sib = bad["opening_proof"]["query_round_proofs"][0]["initial_trees_proof"][1]
+    evals[-1] = (evals[-1] + 1) % P
+    with pytest.raises(AssertionError):
+        prove_ref.verify(circuit, bad)
+    # the flag and the salts go together
+    with pytest.raises(AssertionError):
+        prove_ref.prove(circuit, wires, pis)
