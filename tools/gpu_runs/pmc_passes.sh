@@ -1,7 +1,7 @@
 #!/bin/bash
 # counters + kernel stats of the final kernels -> gpurun_out/${TAG}pmc, summarised into profiles/${TAG}_pmc_summary.json by
 # tools/pmc_summary.py (which records the sha256 of the kernel sources: bench.py refuses a summary of other sources)
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -18,6 +18,8 @@ pmc sq3 SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VA
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc tcc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
+# the matrix instructions of the hashing kernels inside the commit (csrc/poseidon.h): bench.py subtracts them from the vector count
+pmc mfma SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES
 P="python3 $R/tools/bench_poseidon.py"
 pp() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/perm_$n -- $P > $O/perm_$n.log 2>&1; }
 pp sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
