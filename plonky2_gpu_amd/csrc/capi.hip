@@ -268,6 +268,34 @@ __device__ uint64_t pow2_case(uint64_t x, int k) {
     }
 }
 
+// The deferred-rare-path forms (gl_field.h add_f / sub_f / mul_f / mul_pow2_f) the way the NTT passes use them: a GROUP of three
+// independent operations on (x, y), (y, x), (x ^ y, x), one branch, the corrections behind it. `which` picks the member whose result is
+// returned, so that the tests see the flagged operation first, in the middle and last in its group, beside unflagged neighbours.
+template <int KIND>
+__device__ uint64_t deferred_group(uint64_t x, uint64_t y, int which) {
+    uint64_t a[3] = {x, y, x ^ y}, b[3] = {y, x, x}, r[3];
+    gl::rare_mask f[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = KIND == 0 ? gl::add_f(a[k], b[k], f[k]) : KIND == 1 ? gl::sub_f(a[k], b[k], f[k]) : gl::mul_f(a[k], b[k], f[k]);
+    if (gl::rare_any(f[0] | f[1] | f[2])) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) r[k] = KIND == 0 ? gl::add_fix(r[k], f[k]) : KIND == 1 ? gl::sub_fix(r[k], f[k]) : gl::mul_fix(r[k], f[k]);
+    }
+    return which == 0 ? r[0] : which == 1 ? r[1] : r[2];
+}
+template <int K>
+__device__ uint64_t pow2f_case(uint64_t x, int k, bool alone) {
+    if constexpr (K >= 96) {
+        return 0;
+    } else {
+        if (k != K) return pow2f_case<K + 1>(x, k, alone);
+        gl::rare_mask f0, f1;
+        uint64_t r0 = gl::mul_pow2_f<K>(x, f0), r1 = gl::mul_pow2_f<K>(~x, f1);
+        if (gl::rare_any(f0 | f1)) r0 = gl::mul_pow2_fix<K>(r0, f0), r1 = gl::mul_pow2_fix<K>(r1, f1);
+        return alone ? r0 : gl::add(r0, r1);  // x 2^K + ~x 2^K = (2^64 - 1) 2^K
+    }
+}
+
 // A lazy-dot-product accumulator built from two test words, so that the parity tests can reach the
 // reduction's rare wrap corrections directly (random Poseidon states hit them with probability ~2^-32).
 //   mode 0: every field wide (a0 = x, a1 = y, a2 = ~x + (y << 13), small counters from the top bits)
@@ -334,6 +362,10 @@ __global__ void field_op_kernel(int op, const uint64_t *a, const uint64_t *b, ui
         case 15: r = gl::dot_finish(dotacc_from(1, x, y)); break;
         case 16: r = gl::dot_finish_generic(dotacc_from(1, x, y)); break;
         case 17: r = gl::fold96(x, y & 0x7FFFFFFFFFFFFFFFull); break;  // x + (y mod 2^63) * 2^32: the ACC accumulators' fold
+        case 18: case 19: case 20: r = deferred_group<0>(x, y, op - 18); break;
+        case 21: case 22: case 23: r = deferred_group<1>(x, y, op - 21); break;
+        case 24: case 25: case 26: r = deferred_group<2>(x, y, op - 24); break;
+        case 27: r = pow2f_case<0>(x, (int)((uint32_t)y % 96), (y >> 32) != 0); break;
         default: r = x; break;
     }
     out[i] = (op >= 8 && op <= 12) ? r : gl::canon(r);  // canonical-domain ops must already be canonical

@@ -287,6 +287,140 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
 
 __device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
 
+// ---- the same three operations with their RARE PATH DEFERRED (round 4) -----------------------------------------------------
+// add, sub and mul above each end their fast path with `s_cbranch_vccz` around a correction that almost never runs (add / sub: both
+// operands >= p; mul: lo < hh + c1, probability 2^-32 per lane). The branch itself is what costs: the wave cannot issue anything
+// until the vector instruction that wrote VCC has left the pipeline, and a pass whose waves stall together (the NTT tiles: barriers,
+// LDS round trips) cannot hide it: the direct passes run 7 % (natural order) to 11 % (in place) faster with the branches removed, the
+// plain Poseidon kernel 13 % faster at two waves per SIMD and no faster at four (profiles/r04_rare_path_branches.jsonl).
+// The *_f variants run the fast path only and hand back, in a scalar register pair, the mask of lanes whose rare condition fired
+// (the carry- / borrow-out that the branch tested); the caller ORs the masks of a GROUP of independent operations, branches ONCE,
+// and applies *_fix to the flagged results. Every correction can be applied after the fact:
+//   add: the second wrap adds 2^64 = e once more; the wrapped sum is below e, so r + e cannot wrap again
+//   sub: the second borrow subtracts e once more; the wrapped difference is above 2^64 - e, so r - e cannot borrow again
+//   mul: the fast path reduces (t0 + 2^64) instead of t0, exactly (its own wrap correction is exact for what it is given):
+//        r_fast = r + e (mod p), so the true product is sub(r_fast, e)
+// Exactness is that of add / sub / mul: tools/ubench_field.hip and tests/test_gpu_field.py run the grouped forms over the same edge
+// operands (both >= p, 2^63 * 2^63, ...), with the flagged operation first, last and alone in its group.
+typedef uint64_t rare_mask;  // lanes whose result needs its correction; lives in an SGPR pair
+
+__device__ __forceinline__ uint64_t add_f(uint64_t a, uint64_t b, rare_mask &f) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t r;
+    asm("v_add_co_u32_e32 v32, vcc, %2, %4\n\t"
+        "v_addc_co_u32_e32 v33, vcc, %3, %5, vcc\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                  // overflow: 2^64 = 2^32 - 1
+        "v_mad_u64_u32 %0, %1, v42, 1, v[32:33]"                  // r = s + t, carry -> the mask
+        : "=&v"(r), "=&s"(f)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc", "v32", "v33", "v42");
+    return r;
+}
+__device__ __forceinline__ uint64_t add_fix(uint64_t r, rare_mask f) {
+    asm volatile("v_cndmask_b32_e64 v42, 0, -1, %1\n\t"
+                 "v_mad_u64_u32 %0, vcc, v42, 1, %0"
+                 : "+v"(r)
+                 : "s"(f)
+                 : "vcc", "v42");
+    return r;
+}
+
+__device__ __forceinline__ uint64_t sub_f(uint64_t a, uint64_t b, rare_mask &f) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint32_t rl, rh, t;
+    asm("v_sub_co_u32_e32 %0, vcc, %4, %6\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %5, %7, vcc\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"                    // borrow: -2^64 = -(2^32 - 1)
+        "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+        "v_subbrev_co_u32_e64 %1, %3, 0, %1, vcc"                  // borrow -> the mask
+        : "=&v"(rl), "=&v"(rh), "=&v"(t), "=&s"(f)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc");
+    return ((uint64_t)rh << 32) | rl;
+}
+__device__ __forceinline__ uint64_t sub_fix(uint64_t r, rare_mask f) {
+    uint32_t rl = (uint32_t)r, rh = (uint32_t)(r >> 32), t;
+    asm volatile("v_cndmask_b32_e64 %2, 0, -1, %3\n\t"
+                 "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"
+                 : "+v"(rl), "+v"(rh), "=&v"(t)
+                 : "s"(f)
+                 : "vcc");
+    return ((uint64_t)rh << 32) | rl;
+}
+
+__device__ __forceinline__ uint64_t mul_f(uint64_t a, uint64_t b, rare_mask &f) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t r, c1;
+    asm("v_mad_u64_u32 v[32:33], vcc, %3, %5, 0\n\t"          // T = al*bl
+        "v_mad_u64_u32 v[34:35], vcc, %3, %6, 0\n\t"          // U = al*bh
+        "v_mad_u64_u32 v[36:37], %1, %4, %5, v[34:35]\n\t"    // V = ah*bl + U, carry c1 (weight 2^96)
+        "v_mad_u64_u32 v[38:39], vcc, %4, %6, 0\n\t"          // W = ah*bh
+        "v_add_co_u32_e32 v33, vcc, v33, v36\n\t"            // lo.hi = T.hi + V.lo        lo = (v32, v33)
+        "v_addc_co_u32_e32 v38, vcc, v38, v37, vcc\n\t"      // hl = W.lo + V.hi + carry
+        "v_addc_co_u32_e32 v39, vcc, 0, v39, vcc\n\t"         // hh = W.hi + carry (+ c1, applied next)
+        "v_subb_co_u32_e64 v32, vcc, v32, v39, %1\n\t"       // t0 = lo - hh - c1
+        "v_subbrev_co_u32_e64 v33, %2, 0, v33, vcc\n\t"      // its borrow -> the mask (the fast path goes on with t0 + 2^64)
+        "v_mad_u64_u32 v[32:33], vcc, v38, -1, v[32:33]\n\t"  // r = t0 + hl*(2^32-1), carry -> vcc
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"                // carry: r += 2^32-1 (cannot carry again)
+        "v_mad_u64_u32 %0, vcc, v42, 1, v[32:33]"
+        : "=&v"(r), "=&s"(c1), "=&s"(f)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v42");
+    return r;
+}
+// r_fast = r + e (mod p) in the flagged lanes: subtract e there, with sub's own (exact, two-borrow) arithmetic
+__device__ __forceinline__ uint64_t mul_fix(uint64_t r, rare_mask f) {
+    uint32_t rl = (uint32_t)r, rh = (uint32_t)(r >> 32), t;
+    asm volatile("v_cndmask_b32_e64 %2, 0, -1, %3\n\t"          // e in the flagged lanes
+                 "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"         // r - e
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+                 "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"          // borrowed (r < e): -2^64 = -e
+                 "v_sub_co_u32_e32 %0, vcc, %0, %2\n\t"
+                 "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc"       // cannot borrow again: the wrapped r - e is above 2^64 - e
+                 : "+v"(rl), "+v"(rh), "=&v"(t)
+                 : "s"(f)
+                 : "vcc");
+    return ((uint64_t)rh << 32) | rl;
+}
+
+// One radix-2 butterfly, s = a + c and d = a - c (NEG: c - a), as ONE block with both rare paths deferred: the nine instructions of
+// add_f and sub_f without the wait state the compiler puts between two asm statements.
+template <bool NEG>
+__device__ __forceinline__ void bfly_f(uint64_t a, uint64_t c, uint64_t &s, uint64_t &d, rare_mask &fa, rare_mask &fs) {
+    const uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), cl = (uint32_t)c, ch = (uint32_t)(c >> 32);
+    uint32_t dl, dh, t;
+    uint64_t r;
+    asm("v_add_co_u32_e32 v32, vcc, %6, %8\n\t"
+        "v_addc_co_u32_e32 v33, vcc, %7, %9, vcc\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %0, %4, v42, 1, v[32:33]\n\t"             // s, second wrap -> fa
+        "v_sub_co_u32_e32 %1, vcc, %10, %12\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %11, %13, vcc\n\t"
+        "v_cndmask_b32_e64 %3, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 %1, vcc, %1, %3\n\t"
+        "v_subbrev_co_u32_e64 %2, %5, 0, %2, vcc"                   // d, second borrow -> fs
+        : "=&v"(r), "=&v"(dl), "=&v"(dh), "=&v"(t), "=&s"(fa), "=&s"(fs)
+        : "v"(al), "v"(ah), "v"(cl), "v"(ch), "v"(NEG ? cl : al), "v"(NEG ? ch : ah), "v"(NEG ? al : cl), "v"(NEG ? ah : ch)
+        : "vcc", "v32", "v33", "v42");
+    s = r;
+    d = ((uint64_t)dh << 32) | dl;
+}
+
+// x * 2^K with the rare borrow deferred (0 <= K < 96). The forms that have no rare path (K a multiple of 32, K < 32) return mask 0 — a
+// compile-time constant that the caller's OR folds away.
+template <int K>
+__device__ __forceinline__ uint64_t mul_pow2_f(uint64_t x, rare_mask &f);
+template <int K>
+__device__ __forceinline__ uint64_t mul_pow2_fix(uint64_t r, rare_mask f) {
+    constexpr int Q = K / 32, S = K % 32;
+    if constexpr (S != 0 && Q >= 1) return sub_fix(r, f);  // the deferred correction is "- e once more", as sub's
+    return r;
+}
+
+// did any lane of the wave flag any operation of the group? (uniform: the masks are scalar registers)
+__device__ __forceinline__ bool rare_any(rare_mask m) { return __builtin_expect(m != 0, 0); }
+
 // acc + x*y (goldilocks_field.rs:119-123): the multiplication followed by the addition, 16 VALU; the fused
 // arrangement this replaced (the addend riding on the first multiply-adds) took 22.
 __device__ __forceinline__ uint64_t mac(uint64_t acc, uint64_t x, uint64_t y) { return add(acc, mul(x, y)); }
@@ -413,6 +547,46 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
         }
     }
 }
+
+template <int K>
+__device__ __forceinline__ uint64_t mul_pow2_f(uint64_t x, rare_mask &f) {
+    static_assert(K >= 0 && K < 96, "shift out of range");
+    constexpr int Q = K / 32, S = K % 32;
+    if constexpr (S == 0 || Q == 0) {
+        f = 0;
+        return mul_pow2<K>(x);
+    } else {
+        const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+        uint32_t rl, rh, t;
+        if constexpr (Q == 1) {
+            asm("v_mov_b32_e32 v32, 0\n\t"
+                "v_lshlrev_b32_e32 v33, %[s], %[xl]\n\t"                  // (w0:0)
+                "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
+                "v_mad_u64_u32 v[32:33], vcc, %[t], -1, v[32:33]\n\t"  // + w1*e
+                "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
+                "v_mad_u64_u32 v[32:33], vcc, %[t], 1, v[32:33]\n\t"   // wrapped: + e
+                "v_lshrrev_b32_e32 %[t], %[r], %[xh]\n\t"                  // w2
+                "v_sub_co_u32_e32 %[rl], vcc, v32, %[t]\n\t"              // - w2
+                "v_subbrev_co_u32_e64 %[rh], %[f], 0, v33, vcc"              // borrow -> the mask
+                : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t), [f] "=&s"(f)
+                : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
+                : "vcc", "v32", "v33");
+        } else {
+            uint32_t u;
+            asm("v_lshlrev_b32_e32 %[t], %[s], %[xl]\n\t"                  // w0
+                "v_mad_u64_u32 v[32:33], vcc, %[t], -1, 0\n\t"           // w0*e
+                "v_alignbit_b32 %[t], %[xh], %[xl], %[r]\n\t"              // w1
+                "v_lshrrev_b32_e32 %[u], %[r], %[xh]\n\t"                  // w2
+                "v_sub_co_u32_e32 %[rl], vcc, v32, %[t]\n\t"              // - (w2:w1)
+                "v_subb_co_u32_e64 %[rh], %[f], v33, %[u], vcc"              // borrow -> the mask
+                : [rl] "=&v"(rl), [rh] "=&v"(rh), [t] "=&v"(t), [u] "=&v"(u), [f] "=&s"(f)
+                : [xl] "v"(xl), [xh] "v"(xh), [s] "n"(S), [r] "n"(32 - S)
+                : "vcc", "v32", "v33");
+        }
+        return pack64(rl, rh);
+    }
+}
+
 
 __device__ __forceinline__ uint64_t pow(uint64_t base, uint64_t e) {
     uint64_t cur = base, acc = 1;

@@ -33,6 +33,9 @@ namespace {
 // Hook points of the diagnostic builds: tools/experiments/ntt_direct_diag.hip sets them and then includes this file (its results
 // are wrong by design; tools/gpu_runs/ntt_direct_variants.sh). The product compiles this file as it stands: every hook is the
 // identity / false.
+#ifndef NTT_TAIL_GROUPED
+#define NTT_TAIL_GROUPED 1
+#endif
 #ifndef DIRECT_DIAG_HOOKS
 #define DIRECT_TILE_BARRIER() lds_barrier()
 #define DIRECT_LOAD_TILE(t) (t)
@@ -248,8 +251,38 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         g_st<NT_STORE_COL>(obase, so + row * st_row, B[s3]);   // unconditional: a branch here would make the compiler forget how many stores are pending
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the store of tail step j alone (its twiddle already applied)
+    auto tail_store = [&](auto J_) {
+        constexpr int j = decltype(J_)::value;
+        constexpr int s3 = brev_c(j, 4);
+        const uint32_t row = natural ? (uint32_t)(j << (4 + LOGG)) : (uint32_t)s3;
+        g_st<NT_STORE_COL>(obase, so + row * st_row, B[s3]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto tail_units = [&](auto LO_, auto HI_) {
-        static_for<decltype(LO_)::value, decltype(HI_)::value>([&](auto J_) { tail_unit(J_); });
+        constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value, N = HI - LO;
+        if constexpr (NTT_TAIL_GROUPED && kept_twiddles && N >= 1 && N <= 8) {
+            // the multiplications of the steps [LO, HI) as one group with deferred rare paths (gl_field.h): first the twiddles that are
+            // one multiplication away (steps 8-15: cw[j - 8] step^8), then the outputs; then the stores in order
+            uint64_t tw[N];
+            constexpr int N_HI = HI > 8 ? HI - (LO > 8 ? LO : 8) : 0;   // steps >= 8 in the range
+            if constexpr (N_HI > 0)
+                rare_group<N_HI>([&](auto I_, gl::rare_mask &f) { constexpr int j = (LO > 8 ? LO : 8) + decltype(I_)::value; tw[j - LO] = gl::mul_f(cw[j - 8], cstep8, f); },
+                                 [&](auto I_, gl::rare_mask f) { constexpr int j = (LO > 8 ? LO : 8) + decltype(I_)::value; tw[j - LO] = gl::mul_fix(tw[j - LO], f); });
+            rare_group<N>(
+                [&](auto I_, gl::rare_mask &f) {
+                    constexpr int j = LO + decltype(I_)::value, s3 = brev_c(j, 4);
+                    if constexpr (j < 8) B[s3] = gl::mul_f(B[s3], cw[j], f);
+                    else B[s3] = gl::mul_f(B[s3], tw[j - LO], f);
+                },
+                [&](auto I_, gl::rare_mask f) {
+                    constexpr int s3 = brev_c(LO + decltype(I_)::value, 4);
+                    B[s3] = gl::mul_fix(B[s3], f);
+                });
+            static_for<LO, HI>([&](auto J_) { tail_store(J_); });
+        } else {
+            static_for<LO, HI>([&](auto J_) { tail_unit(J_); });
+        }
     };
 
     // first rounds of the tile whose elements are in A: radix 16 over i, twiddle, exchange inside the wave, radix G over g,
@@ -266,10 +299,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TAIL(0, 4);   // four results leave before the butterflies need their temporaries
         if constexpr (COSET) {
             const uint32_t cu_base = (G > 1 ? (zc * G + (opaque_lane() >> LOGC)) * 16 : (zc * 16 + wave) * 16) * 8;
-            static_for<0, 16>([&](auto I_) {
-                constexpr int i = decltype(I_)::value;
-                A[i] = gl::mul(A[i], lds_ld(CU, cu_base + i * 8));
-            });
+            mul_run<0, 16>(A, [](auto I_) { return decltype(I_)::value; }, [&](auto I_) { return lds_ld(CU, cu_base + decltype(I_)::value * 8); }, [](auto) {});
         }
         radix_dif_stage<4, 0, 3>(A);
         TAIL(4, 6);
@@ -279,13 +309,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TAIL(8, 10);
         radix_dif_stage<4, 0, 0>(A);
         TAIL(10, 12);
-        static_for<1, 16>([&](auto S_) {
-            constexpr int s = decltype(S_)::value;
-            constexpr int ka = brev_c(s, 4);
-            A[s] = gl::mul(A[s], lds_ld(TW, tw_base + ka * 8));
-            if constexpr (s == 5) TAIL(12, 13);
-            if constexpr (s == 10) TAIL(13, 14);
-        });
+        mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW, tw_base + brev_c(decltype(S_)::value, 4) * 8); },
+                       [&](auto S_) {
+                           constexpr int s = decltype(S_)::value;
+                           if constexpr (s == 5) TAIL(12, 13);
+                           if constexpr (s == 10) TAIL(13, 14);
+                       });
         if constexpr (G > 1) {
             static_for<0, 16>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
@@ -303,15 +332,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             tile_sync<64>();
             static_for<0, 16 / G>([&](auto J_) { radix_dif<LOGG, decltype(J_)::value * G>(A); });
             TAIL(14, 15);
+            // register e = j G + s2 takes w_16G^(kB w), kB = bitrev(s2); without cosets the factor of kB = 0 is 1 and skipped
+            if constexpr (COSET)
+                mul_run<0, 16>(A, [](auto E_) { return decltype(E_)::value; },
+                               [&](auto E_) { return lds_ld(T2Z, ((zc * 16 + wave) * G + brev_c(decltype(E_)::value % G, LOGG)) * 8); }, [](auto) {});
+            else  // the (G - 1) 16 / G registers with kB != 0: k -> j = k / (G - 1), s2 = 1 + k % (G - 1)
+                mul_run<0, (G - 1) * (16 / G)>(A, [](auto K_) { return (decltype(K_)::value / (G - 1)) * G + 1 + decltype(K_)::value % (G - 1); },
+                                               [&](auto K_) { return t2[brev_c(1 + decltype(K_)::value % (G - 1), LOGG)]; }, [](auto) {});
             static_for<0, 16 / G>([&](auto J_) {
                 constexpr int j = decltype(J_)::value;
                 static_for<0, G>([&](auto S_) {
                     constexpr int s2 = decltype(S_)::value;
                     constexpr int kb = brev_c(s2, LOGG);
-                    uint64_t val = A[j * G + s2];
-                    if constexpr (COSET) val = gl::mul(val, lds_ld(T2Z, ((zc * 16 + wave) * G + kb) * 8));
-                    else if constexpr (kb != 0) val = gl::mul(val, t2[kb]);
-                    lds_st(X, pr_base + (G * j + 16 * kb) * SA, val);
+                    lds_st(X, pr_base + (G * j + 16 * kb) * SA, A[j * G + s2]);
                 });
             });
             TAIL(15, 16);
@@ -498,12 +531,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TAIL(6, 7);
         radix_dif_stage<4, 0, 0>(A);
         TAIL(7, 8);
-        static_for<1, 16>([&](auto S_) {
-            constexpr int s = decltype(S_)::value;
-            constexpr int ka = brev_c(s, 4);
-            A[s] = gl::mul(A[s], lds_ld(TW1, tw1_base + ka * 8));
-            if constexpr (s == 8) TAIL(8, 9);
-        });
+        mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW1, tw1_base + brev_c(decltype(S_)::value, 4) * 8); },
+                       [&](auto S_) {
+                           if constexpr (decltype(S_)::value == 8) TAIL(8, 9);
+                       });
         static_for<0, 16>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             constexpr int ka = brev_c(s, 4);
@@ -524,12 +555,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TAIL(12, 13);
         radix_dif_stage<4, 0, 0>(A);
         TAIL(13, 14);
+        // q = 0: the factor is 1, multiplied all the same (uniform code)
+        mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW2, tw2_base + brev_c(decltype(S_)::value, 4) * 8); }, [](auto) {});
         static_for<0, 16>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             constexpr int kb = brev_c(s, 4);
-            uint64_t val = A[s];
-            if constexpr (kb != 0) val = gl::mul(val, lds_ld(TW2, tw2_base + kb * 8));   // q = 0: the factor is 1, multiplied all the same (uniform code)
-            lds_st(X, pr_base + kb * SB, val);
+            lds_st(X, pr_base + kb * SB, A[s]);
             if constexpr (s == 7) TAIL(14, 15);
         });
         TAIL(15, 16);
@@ -646,11 +677,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // radix 16 over i on A, twiddle, E1 write
     auto first_round = [&]() {
         radix_dif<4, 0>(A);
-        static_for<1, 16>([&](auto S_) {
-            constexpr int s = decltype(S_)::value;
-            constexpr int ka = brev_c(s, 4);
-            A[s] = gl::mul(A[s], lds_ld(TW1, tw1_base + ka * 8));
-        });
+        mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW1, tw1_base + brev_c(decltype(S_)::value, 4) * 8); }, [](auto) {});
         static_for<0, 16>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             constexpr int ka = brev_c(s, 4);
@@ -666,12 +693,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         });
         tile_sync<64>();
         radix_dif<4, 0>(B);
+        mul_run<1, 16>(B, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW2, tw2_base + brev_c(decltype(S_)::value, 4) * 8); }, [](auto) {});
         static_for<0, 16>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             constexpr int kb = brev_c(s, 4);
-            uint64_t val = B[s];
-            if constexpr (kb != 0) val = gl::mul(val, lds_ld(TW2, tw2_base + kb * 8));
-            lds_st(X, e2w0 + kb * 512 + ((q ^ (uint32_t)(kb >> 2)) * 8), val);
+            lds_st(X, e2w0 + kb * 512 + ((q ^ (uint32_t)(kb >> 2)) * 8), B[s]);
         });
         tile_sync<64>();
         {

@@ -91,27 +91,91 @@ template <int D, int BASE, int s>
 __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
     constexpr int half = 1 << s;
     constexpr int NB = (1 << D) / 2;
-    if constexpr (NB >= 2) {
-        // butterflies in pairs through the interleaved carry-chain primitive (gl::bfly2)
-        static_for<0, NB / 2>([&](auto B_) {
-            constexpr int b0 = 2 * decltype(B_)::value, b1 = b0 + 1;
-            constexpr int i00 = BASE + (b0 / half) * 2 * half + (b0 % half), i01 = i00 + half;
-            constexpr int i10 = BASE + (b1 / half) * 2 * half + (b1 % half), i11 = i10 + half;
-            constexpr int K0 = (39 * (b0 % half) * (32 >> s)) % 192, K1 = (39 * (b1 % half) * (32 >> s)) % 192;
-            // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by
-            // swapping the operands of the subtraction instead of negating the product.
-            uint64_t s0, d0, s1, d1;
-            gl::bfly2<(K0 >= 96), (K1 >= 96)>(v[i00], v[i01], v[i10], v[i11], s0, d0, s1, d1);
-            v[i00] = s0;
-            v[i10] = s1;
-            v[i01] = gl::mul_pow2<(K0 >= 96 ? K0 - 96 : K0)>(d0);
-            v[i11] = gl::mul_pow2<(K1 >= 96 ? K1 - 96 : K1)>(d1);
+    // The rare paths of the field operations are DEFERRED (gl_field.h, add_f / sub_f / mul_pow2_f): the sums and differences of up to
+    // four butterflies run their fast paths back to back, the eight masks are OR-ed and ONE branch guards the corrections; then the
+    // shift twiddles of the stage the same way. A stage of a radix-16 butterfly has three or four branches instead of twenty-four.
+    constexpr int GB = NB >= 4 ? 4 : NB;  // butterflies per group
+    auto lo_of = [](int b) { return BASE + (b / half) * 2 * half + (b % half); };
+    static_for<0, NB / GB>([&](auto G_) {
+        constexpr int g0 = decltype(G_)::value * GB;
+        gl::rare_mask fa[GB], fs[GB];
+        static_for<0, GB>([&](auto B_) {
+            constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value;
+            constexpr int i0 = BASE + (b / half) * 2 * half + (b % half), i1 = i0 + half;
+            constexpr int K = (39 * (b % half) * (32 >> s)) % 192;
+            // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by swapping the operands of the subtraction
+            gl::bfly_f<(K >= 96)>(v[i0], v[i1], v[i0], v[i1], fa[k], fs[k]);
         });
-    } else {
-        uint64_t a = v[BASE], c = v[BASE + 1];
-        v[BASE] = gl::add(a, c);
-        v[BASE + 1] = gl::sub(a, c);
+        __builtin_amdgcn_sched_barrier(0);  // the ORs behind the last operation, see rare_group
+        gl::rare_mask any = 0;
+        static_for<0, GB>([&](auto B_) { any |= fa[decltype(B_)::value] | fs[decltype(B_)::value]; });
+        if (gl::rare_any(any)) {
+            static_for<0, GB>([&](auto B_) {
+                constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value;
+                constexpr int i0 = BASE + (b / half) * 2 * half + (b % half), i1 = i0 + half;
+                v[i0] = gl::add_fix(v[i0], fa[k]);
+                v[i1] = gl::sub_fix(v[i1], fs[k]);
+            });
+        }
+    });
+    (void)lo_of;
+    if constexpr (s > 0) {  // stage 0 has no twiddles (K = 0 for every butterfly)
+        gl::rare_mask fm[NB];
+        static_for<0, NB>([&](auto B_) {
+            constexpr int b = decltype(B_)::value;
+            constexpr int i1 = BASE + (b / half) * 2 * half + (b % half) + half;
+            constexpr int K = (39 * (b % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+            v[i1] = gl::mul_pow2_f<KK>(v[i1], fm[b]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        gl::rare_mask any = 0;
+        static_for<0, NB>([&](auto B_) { any |= fm[decltype(B_)::value]; });
+        if (gl::rare_any(any)) {
+            static_for<0, NB>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                constexpr int i1 = BASE + (b / half) * 2 * half + (b % half) + half;
+                constexpr int K = (39 * (b % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+                v[i1] = gl::mul_pow2_fix<KK>(v[i1], fm[b]);
+            });
+        }
     }
+}
+
+// N independent field operations with their rare paths deferred (gl_field.h): one(I, mask&) runs the fast path of operation I,
+// fix(I, mask) corrects its result; the corrections sit behind ONE branch. N <= 8 keeps the masks within sixteen scalar registers.
+template <int N, class One, class Fix>
+__device__ __forceinline__ void rare_group(One &&one, Fix &&fix) {
+    static_assert(N >= 1 && N <= 8, "a group's masks must fit the scalar registers a kernel has to spare");
+    gl::rare_mask f[N];
+    static_for<0, N>([&](auto I_) { one(I_, f[decltype(I_)::value]); });
+    // the scalar ORs wait for the vector instruction that wrote their mask: left to itself the scheduler puts each OR right behind
+    // its producer (N stalls); behind this fence they all come after the last operation (one)
+    __builtin_amdgcn_sched_barrier(0);
+    gl::rare_mask any = 0;
+    static_for<0, N>([&](auto I_) { any |= f[decltype(I_)::value]; });
+    if (gl::rare_any(any)) static_for<0, N>([&](auto I_) { fix(I_, f[decltype(I_)::value]); });
+}
+
+// v[idx(k)] *= w(k) for k = LO .. HI-1, eight multiplications per group; after(k) runs behind multiplication k (the passes put the
+// tail steps of the previous tile there)
+template <int LO, int HI, class Idx, class W, class After>
+__device__ __forceinline__ void mul_run(uint64_t (&v)[16], Idx &&idx, W &&w, After &&after) {
+    constexpr int N = HI - LO;
+    static_for<0, (N + 7) / 8>([&](auto G_) {
+        constexpr int k0 = LO + 8 * decltype(G_)::value, n = (HI - k0) < 8 ? (HI - k0) : 8;
+        rare_group<n>(
+            [&](auto I_, gl::rare_mask &f) {
+                constexpr int k = k0 + decltype(I_)::value;
+                auto K_ = std::integral_constant<int, k>{};
+                v[idx(K_)] = gl::mul_f(v[idx(K_)], w(K_), f);
+                after(K_);
+            },
+            [&](auto I_, gl::rare_mask f) {
+                constexpr int k = k0 + decltype(I_)::value;
+                auto K_ = std::integral_constant<int, k>{};
+                v[idx(K_)] = gl::mul_fix(v[idx(K_)], f);
+            });
+    });
 }
 
 template <int D, int BASE>

@@ -132,3 +132,29 @@ def test_fold96_over_its_whole_stated_domain(gpu):
     got = run_op(gpu, 17, a, b)
     for (x, y), g in zip(pairs, got):
         assert g == (x + (y << 32)) % P, (hex(x), hex(y))
+
+
+def test_deferred_rare_paths(gpu):
+    """add_f / sub_f / mul_f / mul_pow2_f + their *_fix (gl_field.h): the fast paths of a GROUP of operations, one branch, the
+    corrections behind it — the form the NTT passes use. Every member of a group of three over the edge operands (both >= p: add's
+    second wrap; b > p and a < 2^32: sub's second borrow; lo < hh + c1: mul's borrow, e.g. 2^63 * 2^63) and over random data."""
+    ops = edge_operands()
+    pairs = list(itertools.product(ops, ops))
+    rng = np.random.default_rng(11)
+    pairs += [(int(x), int(y)) for x, y in rng.integers(0, 2**64, size=(20000, 2), dtype=np.uint64).tolist()]
+    # products whose low 64 bits are tiny (mul's borrow): x * y with y = the inverse-like partner making lo small
+    pairs += [(1 << 63, 1 << 63), ((1 << 64) - 1, (1 << 64) - 1), ((1 << 32) + 1, (1 << 64) - (1 << 32)), (P - 1, P - 1), (1 << 32, 1 << 32)]
+    a = np.array([x for x, _ in pairs], dtype=np.uint64)
+    b = np.array([y for _, y in pairs], dtype=np.uint64)
+    members = [lambda x, y: (x, y), lambda x, y: (y, x), lambda x, y: (x ^ y, x)]
+    for which, m in enumerate(members):
+        assert run_op(gpu, 18 + which, a, b) == [sum(m(x, y)) % P for x, y in pairs], ("add", which)
+        assert run_op(gpu, 21 + which, a, b) == [(m(x, y)[0] - m(x, y)[1]) % P for x, y in pairs], ("sub", which)
+        assert run_op(gpu, 24 + which, a, b) == [(m(x, y)[0] * m(x, y)[1]) % P for x, y in pairs], ("mul", which)
+    xs = ops + rng.integers(0, 2**64, size=2000, dtype=np.uint64).tolist() + [0, (1 << 64) - 1, 1, (1 << 32) - 1, 1 << 32]
+    ax = np.array(xs, dtype=np.uint64)
+    M = (1 << 64) - 1
+    for k in range(96):  # x 2^k + (~x) 2^k = (2^64 - 1) 2^k
+        kk = np.full(len(xs), k, dtype=np.uint64)
+        assert run_op(gpu, 27, ax, kk) == [(M << k) % P] * len(xs), k
+        assert run_op(gpu, 27, ax, kk + np.uint64(1 << 32)) == [(x << k) % P for x in xs], k
