@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 });
             });
             tile_sync<64>();
-            static_for<0, 16 / G>([&](auto J_) { radix_dif<LOGG, decltype(J_)::value * G>(A); });
+            radix_dif_blocks<LOGG>(A);   // the 16 / G radix-G butterflies stage by stage together: larger groups for the deferred rare paths
             TAIL(14, 15);
             // register e = j G + s2 takes w_16G^(kB w), kB = bitrev(s2); without cosets the factor of kB = 0 is 1 and skipped
             if constexpr (COSET)
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             });
         }
         DIRECT_TILE_BARRIER();  // everyone has read it
-        static_for<0, 4>([&](auto J_) { radix_dif<2, decltype(J_)::value * 4>(B); });
+        radix_dif_blocks<2>(B);
         tail_begin(k);
         if (k < last) {
             first_rounds(std::true_type{});
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             });
         }
         tile_sync<64>();
-        static_for<0, 4>([&](auto J_) { radix_dif<2, decltype(J_)::value * 4>(B); });
+        radix_dif_blocks<2>(B);
         {
             // E3 write: position = bitrev4(kA) * 64 + bitrev2(kBlo) * 16 + bitrev2(kBhi) * 4 + s2, slot low bits ^ (position >> 8)
             const uint32_t l = opaque_lane();

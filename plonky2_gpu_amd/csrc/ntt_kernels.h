@@ -87,22 +87,24 @@ __device__ __forceinline__ void twiddle_chain(const PassParams &p, uint32_t tid,
 // In-register radix-2^D DIF butterfly on v[BASE .. BASE+2^D): output slot i holds frequency
 // bitrev_D(i). Stage twiddles w_{2^(s+1)}^j = 2^(39*j*(32>>s)) are multiply-free. radix_dif_stage is one of its D stages
 // (s = D-1 first), for callers that put other work between the stages.
-template <int D, int BASE, int s>
+// NBLK adjacent blocks of 2^D slots starting at BASE go through stage s TOGETHER (their butterflies are independent: larger groups)
+template <int D, int BASE, int s, int NBLK = 1>
 __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
     constexpr int half = 1 << s;
-    constexpr int NB = (1 << D) / 2;
-    // The rare paths of the field operations are DEFERRED (gl_field.h, add_f / sub_f / mul_pow2_f): the sums and differences of up to
+    constexpr int NBP = (1 << D) / 2;   // butterflies per block
+    constexpr int NB = NBP * NBLK;
+    // The rare paths of the field operations are DEFERRED (gl_field.h, bfly_f / mul_pow2_f): the sums and differences of up to
     // four butterflies run their fast paths back to back, the eight masks are OR-ed and ONE branch guards the corrections; then the
     // shift twiddles of the stage the same way. A stage of a radix-16 butterfly has three or four branches instead of twenty-four.
     constexpr int GB = NB >= 4 ? 4 : NB;  // butterflies per group
-    auto lo_of = [](int b) { return BASE + (b / half) * 2 * half + (b % half); };
+    static_assert(NB % GB == 0, "whole groups");
     static_for<0, NB / GB>([&](auto G_) {
         constexpr int g0 = decltype(G_)::value * GB;
         gl::rare_mask fa[GB], fs[GB];
         static_for<0, GB>([&](auto B_) {
-            constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value;
-            constexpr int i0 = BASE + (b / half) * 2 * half + (b % half), i1 = i0 + half;
-            constexpr int K = (39 * (b % half) * (32 >> s)) % 192;
+            constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value, bb = b % NBP;
+            constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
+            constexpr int K = (39 * (bb % half) * (32 >> s)) % 192;
             // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by swapping the operands of the subtraction
             gl::bfly_f<(K >= 96)>(v[i0], v[i1], v[i0], v[i1], fa[k], fs[k]);
         });
@@ -111,20 +113,20 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
         static_for<0, GB>([&](auto B_) { any |= fa[decltype(B_)::value] | fs[decltype(B_)::value]; });
         if (gl::rare_any(any)) {
             static_for<0, GB>([&](auto B_) {
-                constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value;
-                constexpr int i0 = BASE + (b / half) * 2 * half + (b % half), i1 = i0 + half;
+                constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value, bb = b % NBP;
+                constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
                 v[i0] = gl::add_fix(v[i0], fa[k]);
                 v[i1] = gl::sub_fix(v[i1], fs[k]);
             });
         }
     });
-    (void)lo_of;
     if constexpr (s > 0) {  // stage 0 has no twiddles (K = 0 for every butterfly)
+        static_assert(NB <= 8, "the shift twiddles of a stage form one group");
         gl::rare_mask fm[NB];
         static_for<0, NB>([&](auto B_) {
-            constexpr int b = decltype(B_)::value;
-            constexpr int i1 = BASE + (b / half) * 2 * half + (b % half) + half;
-            constexpr int K = (39 * (b % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+            constexpr int b = decltype(B_)::value, bb = b % NBP;
+            constexpr int i1 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half) + half;
+            constexpr int K = (39 * (bb % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
             v[i1] = gl::mul_pow2_f<KK>(v[i1], fm[b]);
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -132,9 +134,9 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
         static_for<0, NB>([&](auto B_) { any |= fm[decltype(B_)::value]; });
         if (gl::rare_any(any)) {
             static_for<0, NB>([&](auto B_) {
-                constexpr int b = decltype(B_)::value;
-                constexpr int i1 = BASE + (b / half) * 2 * half + (b % half) + half;
-                constexpr int K = (39 * (b % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+                constexpr int b = decltype(B_)::value, bb = b % NBP;
+                constexpr int i1 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half) + half;
+                constexpr int K = (39 * (bb % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
                 v[i1] = gl::mul_pow2_fix<KK>(v[i1], fm[b]);
             });
         }
@@ -181,6 +183,11 @@ __device__ __forceinline__ void mul_run(uint64_t (&v)[16], Idx &&idx, W &&w, Aft
 template <int D, int BASE>
 __device__ __forceinline__ void radix_dif(uint64_t (&v)[16]) {
     static_for<0, D>([&](auto S_) { radix_dif_stage<D, BASE, D - 1 - decltype(S_)::value>(v); });
+}
+// radix 2^D on all 16 >> D blocks of the sixteen registers at once, stage by stage
+template <int D>
+__device__ __forceinline__ void radix_dif_blocks(uint64_t (&v)[16]) {
+    static_for<0, D>([&](auto S_) { radix_dif_stage<D, 0, D - 1 - decltype(S_)::value, (16 >> D)>(v); });
 }
 
 // Synchronisation of the NT_ threads that share a tile: a wavefront (NT_ == 64) needs only program order.
