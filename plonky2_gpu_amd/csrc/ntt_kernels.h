@@ -87,6 +87,9 @@ __device__ __forceinline__ void twiddle_chain(const PassParams &p, uint32_t tid,
 // In-register radix-2^D DIF butterfly on v[BASE .. BASE+2^D): output slot i holds frequency
 // bitrev_D(i). Stage twiddles w_{2^(s+1)}^j = 2^(39*j*(32>>s)) are multiply-free. radix_dif_stage is one of its D stages
 // (s = D-1 first), for callers that put other work between the stages.
+#ifndef RARE_GB
+#define RARE_GB 4
+#endif
 // NBLK adjacent blocks of 2^D slots starting at BASE go through stage s TOGETHER (their butterflies are independent: larger groups)
 template <int D, int BASE, int s, int NBLK = 1>
 __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
@@ -96,7 +99,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
     // The rare paths of the field operations are DEFERRED (gl_field.h, bfly_f / mul_pow2_f): the sums and differences of up to
     // four butterflies run their fast paths back to back, the eight masks are OR-ed and ONE branch guards the corrections; then the
     // shift twiddles of the stage the same way. A stage of a radix-16 butterfly has three or four branches instead of twenty-four.
-    constexpr int GB = NB >= 4 ? 4 : NB;  // butterflies per group
+    constexpr int GB = NB >= RARE_GB ? RARE_GB : NB;  // butterflies per group
     static_assert(NB % GB == 0, "whole groups");
     static_for<0, NB / GB>([&](auto G_) {
         constexpr int g0 = decltype(G_)::value * GB;
