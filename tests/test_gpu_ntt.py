@@ -251,3 +251,31 @@ def test_sizes_above_the_limit_are_rejected(gpu):
         _lib.call("gl_coset_lde_batch", buf.ptr, buf.ptr, 1, 25, 0, 7, 1 << 25, 1 << 25, gpu.ptr)
     assert e.value.code == pg.GL_E_INVALID
     buf.free()
+
+
+@pytest.mark.parametrize("log_n", [12, 16, 20, 21])
+def test_representatives_that_fire_the_deferred_rare_paths(gpu, oracle, log_n):
+    """The passes' field operations defer their rare corrections (csrc/gl_field.h: add's second wrap needs both operands >= p, sub's
+    second borrow a subtrahend > p and a minuend below 2^32) — events of probability 2^-64 on canonical random data. Here they fire
+    in most lanes of the first radix stage: the same field elements given as NON-CANONICAL representatives (x + p wherever that fits
+    64 bits, i.e. for x < 2^32 - 1) mixed with tiny values. Every transform of them must equal the transform of the canonical
+    vector: natural, inverse, bit-reversed, and the coset LDE. (A build whose rare_any() always says "no" fails all four sizes of this
+    test and tests/test_gpu_field.py::test_deferred_rare_paths: checked once by hand, round 4.)"""
+    import plonky2_gpu_amd as pg
+
+    n = 1 << log_n
+    rng = np.random.default_rng(7000 + log_n)
+    small = rng.integers(0, (1 << 32) - 1, size=(2, n), dtype=np.uint64)        # all representable as x + p
+    tiny = rng.integers(0, 4, size=(2, n), dtype=np.uint64)
+    pick = rng.integers(0, 4, size=(2, n))
+    canonical = np.where(pick == 0, tiny, small).astype(np.uint64)
+    lifted = np.where(pick >= 2, canonical + np.uint64(P), canonical)            # half of the entries >= p, the rest < 2^32
+    assert (lifted >= np.uint64(P)).sum() > n // 2 and ((lifted % np.uint64(P)) == canonical).all()
+    exp = oracle.canon(oracle.fft_batch(canonical, threads=2))
+    assert (pg.fft_with_options(gpu, lifted) == exp).all()
+    assert (pg.fft_with_options(gpu, lifted[1], bit_reversed=True) == exp[1][bitrev_perm(log_n)]).all()
+    assert (pg.ifft_with_options(gpu, lifted) == pg.ifft_with_options(gpu, canonical)).all()
+    if log_n <= 20:
+        a = pg.coset_lde_bit_reversed(gpu, lifted, 3)
+        b = pg.coset_lde_bit_reversed(gpu, canonical, 3)
+        assert (a == b).all()
