@@ -82,17 +82,20 @@ __device__ __forceinline__ void radix_round(uint64_t *data, const uint64_t *tw, 
 
     if constexpr (SH > 0) {
         // inter-digit twiddle w_{2^(SH+D)}^(low * k1), k1 = bitrev_D(i), from the LDS table of w_R
+        // the G (RD - 1) multiplications as runs of eight with deferred rare paths (ntt_kernels.h mul_run)
+        uint32_t rest_lo[G];
         static_for<0, G>([&](auto G_) {
             constexpr int g = decltype(G_)::value;
-            uint32_t gid = tid + g * NT, rest = gid >> LOGT;
-            uint32_t rest_lo = rest & ((1u << SH) - 1);
-            static_for<1, RD>([&](auto I_) {
-                constexpr int i = decltype(I_)::value;
-                constexpr int k1 = brev_c(i, D);
-                uint32_t e = (rest_lo * k1) << (LOGR - SH - D);
-                v[g * RD + i] = gl::mul(v[g * RD + i], tw[e]);
-            });
+            rest_lo[g] = ((tid + g * NT) >> LOGT) & ((1u << SH) - 1);
         });
+        mul_run<0, G *(RD - 1)>(
+            v, [](auto K_) { return (decltype(K_)::value / (RD - 1)) * RD + 1 + decltype(K_)::value % (RD - 1); },
+            [&](auto K_) {
+                constexpr int g = decltype(K_)::value / (RD - 1), i = 1 + decltype(K_)::value % (RD - 1);
+                constexpr int k1 = brev_c(i, D);
+                return tw[(rest_lo[g] * k1) << (LOGR - SH - D)];
+            },
+            [](auto) {});
     } else if constexpr (TWIDDLE) {
         // inter-pass twiddle w_{2^tw_hi}^(L * k1), k1 = bitrev4(i)*(R/16) + kr  (G == 1, D == 4)
         static_assert(D == 4 || !TWIDDLE, "twiddled passes end with a radix-16 round");
