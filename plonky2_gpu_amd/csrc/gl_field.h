@@ -418,6 +418,27 @@ __device__ __forceinline__ uint64_t mul_pow2_fix(uint64_t r, rare_mask f) {
     return r;
 }
 
+// x in the flagged lanes, 0 in the others
+__device__ __forceinline__ uint64_t masked(uint64_t x, rare_mask f) {
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), rl, rh;
+    asm volatile("v_cndmask_b32_e64 %0, 0, %2, %4\n\t"
+                 "v_cndmask_b32_e64 %1, 0, %3, %4"
+                 : "=&v"(rl), "=&v"(rh)
+                 : "v"(xl), "v"(xh), "s"(f));
+    return ((uint64_t)rh << 32) | rl;
+}
+// (2^32 - 1) 2^k mod p, canonical, for 0 <= k < 96
+constexpr uint64_t eps_times_pow2(int k) {
+    uint64_t x = 0xFFFFFFFFull;
+    for (int i = 0; i < k; i++) {
+        const bool top = x >> 63;
+        x <<= 1;                       // 2 x mod 2^64; the lost 2^64 = 2^32 - 1 (mod p)
+        if (top) x += 0xFFFFFFFFull;   // x < 2^64 - 2^33 + 2 before, so no wrap (x was canonical: 2 x - 2^64 < p - 2^32)
+        if (x >= 0xFFFFFFFF00000001ull) x -= 0xFFFFFFFF00000001ull;
+    }
+    return x;
+}
+
 // did any lane of the wave flag any operation of the group? (uniform: the masks are scalar registers)
 __device__ __forceinline__ bool rare_any(rare_mask m) { return __builtin_expect(m != 0, 0); }
 

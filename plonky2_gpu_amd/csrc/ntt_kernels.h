@@ -90,6 +90,12 @@ __device__ __forceinline__ void twiddle_chain(const PassParams &p, uint32_t tid,
 #ifndef RARE_GB
 #define RARE_GB 4
 #endif
+#ifndef RARE_FENCE_MASK
+#define RARE_FENCE_MASK 0   // what may be scheduled across the fence in front of a group's mask ORs (0: nothing)
+#endif
+#ifndef RARE_STAGE_COMBINED
+#define RARE_STAGE_COMBINED 1
+#endif
 // NBLK adjacent blocks of 2^D slots starting at BASE go through stage s TOGETHER (their butterflies are independent: larger groups)
 template <int D, int BASE, int s, int NBLK = 1>
 __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
@@ -99,6 +105,44 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
     // The rare paths of the field operations are DEFERRED (gl_field.h, bfly_f / mul_pow2_f): the sums and differences of up to
     // four butterflies run their fast paths back to back, the eight masks are OR-ed and ONE branch guards the corrections; then the
     // shift twiddles of the stage the same way. A stage of a radix-16 butterfly has three or four branches instead of twenty-four.
+#if RARE_STAGE_COMBINED
+    // ONE group per stage: the butterflies and then the shift twiddles of their differences, all fast paths back to back. A
+    // difference whose second borrow is pending (true d = d_fast - e) goes through its shift as it is: the shift is linear and exact
+    // for any representative, so the true result is shift(d_fast) - e 2^K, a compile-time constant to subtract in the flagged lanes.
+    if constexpr (s > 0 && NB <= 8) {
+        gl::rare_mask fa[NB], fs[NB], fm[NB];
+        static_for<0, NB>([&](auto B_) {
+            constexpr int b = decltype(B_)::value, bb = b % NBP;
+            constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
+            constexpr int K = (39 * (bb % half) * (32 >> s)) % 192;
+            gl::bfly_f<(K >= 96)>(v[i0], v[i1], v[i0], v[i1], fa[b], fs[b]);
+        });
+        static_for<0, NB>([&](auto B_) {
+            constexpr int b = decltype(B_)::value, bb = b % NBP;
+            constexpr int i1 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half) + half;
+            constexpr int K = (39 * (bb % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+            v[i1] = gl::mul_pow2_f<KK>(v[i1], fm[b]);
+        });
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
+        gl::rare_mask any = 0;
+        static_for<0, NB>([&](auto B_) { constexpr int b = decltype(B_)::value; any |= fa[b] | fs[b] | fm[b]; });
+        if (gl::rare_any(any)) {
+            static_for<0, NB>([&](auto B_) {
+                constexpr int b = decltype(B_)::value, bb = b % NBP;
+                constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
+                constexpr int K = (39 * (bb % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
+                v[i0] = gl::add_fix(v[i0], fa[b]);
+                v[i1] = gl::mul_pow2_fix<KK>(v[i1], fm[b]);
+                #ifdef RARE_STAGE_WRONG_CONSTANT   // negative control of the tests only: the build must FAIL tests/test_gpu_ntt.py's rare-path test
+                v[i1] = gl::sub(v[i1], gl::masked(gl::eps_times_pow2(KK) + 1, fs[b]));
+#else
+                v[i1] = gl::sub(v[i1], gl::masked(gl::eps_times_pow2(KK), fs[b]));   // KK = 0: e itself
+#endif
+            });
+        }
+        return;
+    }
+#endif
     constexpr int GB = NB >= RARE_GB ? RARE_GB : NB;  // butterflies per group
     static_assert(NB % GB == 0, "whole groups");
     static_for<0, NB / GB>([&](auto G_) {
@@ -111,7 +155,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
             // 2^96 = -1: a twiddle 2^K with K >= 96 is -(2^(K-96)); the sign is absorbed by swapping the operands of the subtraction
             gl::bfly_f<(K >= 96)>(v[i0], v[i1], v[i0], v[i1], fa[k], fs[k]);
         });
-        __builtin_amdgcn_sched_barrier(0);  // the ORs behind the last operation, see rare_group
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);  // the ORs behind the last operation, see rare_group
         gl::rare_mask any = 0;
         static_for<0, GB>([&](auto B_) { any |= fa[decltype(B_)::value] | fs[decltype(B_)::value]; });
         if (gl::rare_any(any)) {
@@ -132,7 +176,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
             constexpr int K = (39 * (bb % half) * (32 >> s)) % 192, KK = K >= 96 ? K - 96 : K;
             v[i1] = gl::mul_pow2_f<KK>(v[i1], fm[b]);
         });
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
         gl::rare_mask any = 0;
         static_for<0, NB>([&](auto B_) { any |= fm[decltype(B_)::value]; });
         if (gl::rare_any(any)) {
@@ -155,7 +199,7 @@ __device__ __forceinline__ void rare_group(One &&one, Fix &&fix) {
     static_for<0, N>([&](auto I_) { one(I_, f[decltype(I_)::value]); });
     // the scalar ORs wait for the vector instruction that wrote their mask: left to itself the scheduler puts each OR right behind
     // its producer (N stalls); behind this fence they all come after the last operation (one)
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
     gl::rare_mask any = 0;
     static_for<0, N>([&](auto I_) { any |= f[decltype(I_)::value]; });
     if (gl::rare_any(any)) static_for<0, N>([&](auto I_) { fix(I_, f[decltype(I_)::value]); });
