@@ -417,8 +417,10 @@ hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t strea
 // ---------------------------------------------------------------------------------------------
 // Row pass with natural-order (transposed) output, rows of R = 1024 points; tile = 16 adjacent rows, one per wave.
 //   position j2 = 64 i + 4 h + q     i = register, (h, q) = lane: 8 bytes per lane, 512 contiguous bytes per load.
-//   radix 16 over i -> twiddle w_R^(kA lane) -> exchange inside the wave (h <-> kA) -> radix 16 over h -> twiddle
-//   w_64^(kB q) -> exchange ACROSS the waves: wave kA, lane (kBhi, row), registers (kBlo, q) -> radix 4 over q ->
+//   radix 16 over i -> twiddle w_R^(kA lane) -> exchange inside the wave (h <-> kA) -> radix 16 over h -> exchange ACROSS the
+//   waves: wave (kBhi, kAlo), lane (kAhi, row), registers (kBlo, q) -> twiddle w_64^(kB q) AS SHIFTS (every 64th root of unity is a
+//   power of two; kBlo and q are register indices and kBhi is wave-uniform, so the shift amounts are compile-time constants behind
+//   a four-way scalar switch: ntt_kernels.h, shift_twiddles_radix4) -> radix 4 over q ->
 //   stores of X[k1 + N1 k2], k2 = kA + 16 kB + 256 kC: sixteen lanes = sixteen adjacent rows k1 = one 128-byte segment.
 // The exchange image is [kA][kB][q][row] with pads chosen so that every access of both exchanges is conflict-free and the
 // slots a wave writes (its row's column of the image) are also the slots of its private exchange:
@@ -428,8 +430,8 @@ struct RowGeom {
     static constexpr uint32_t SQ = 136, SB = 544, SA = 8736;
     static constexpr uint32_t XBYTES = 16 * SA;
     static constexpr uint32_t TW1_STRIDE = 136, TW1_BYTES = 64 * TW1_STRIDE;   // [lane][kA]: w_1024^(kA lane)
-    static constexpr uint32_t TW2_STRIDE = 136, TW2_BYTES = 4 * TW2_STRIDE;    // [q][kB]:   w_64^(kB q)
-    static constexpr uint32_t LDS_BYTES = XBYTES + TW1_BYTES + TW2_BYTES;
+    static constexpr uint32_t TW2_STRIDE = 136, TW2_BYTES = 4 * TW2_STRIDE;    // [q][kB]:   w_64^(kB q), in-place pass only
+    static constexpr uint32_t LDS_BYTES = XBYTES + TW1_BYTES;   // the natural-order pass has no table for the second twiddle (shifts)
 };
 
 template <bool INVERSE>
@@ -439,7 +441,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char *X = ldsb;
     unsigned char *TW1 = ldsb + GEO::XBYTES;
-    unsigned char *TW2 = TW1 + GEO::TW1_BYTES;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -454,15 +455,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const uint32_t l = e >> 4, ka = e & 15;
         *reinterpret_cast<uint64_t *>(TW1 + l * GEO::TW1_STRIDE + ka * 8) = p.twh[(ka * l) << 2];
     }
-    if (tid < 64) {
-        const uint32_t q = tid >> 4, kb = tid & 15;
-        *reinterpret_cast<uint64_t *>(TW2 + q * GEO::TW2_STRIDE + kb * 8) = p.twh[(kb * q) << 6];
-    }
 
     // first rounds: lane = (h, q) before the private exchange, (kA', q) after it
     const uint32_t q = lane & 3, hi4 = lane >> 2;
     const uint32_t tw1_base = lane * GEO::TW1_STRIDE;
-    const uint32_t tw2_base = q * GEO::TW2_STRIDE;
     const uint32_t pw_base = hi4 * SB + q * SQ + wave * 8;      // + kA * SA
     const uint32_t pr_base = hi4 * SA + q * SQ + wave * 8;      // + h * SB; round 2 leaves (kA', kB, q) at + kB * SB
     auto opaque_lane = [&]() {
@@ -492,7 +488,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         });
     };
 
-    uint64_t B[16];   // registers (kBlo, q) of (kA = wave, kBhi, row) = lane
+    uint64_t B[16];   // registers (kBlo, q); wave = (kBhi, kAlo), lane = (kAhi, row)
+    const uint32_t kbhi = wave >> 2, kalo = wave & 3;
     uint64_t *obase = p.dst;
     uint32_t o_lane = 0;   // element index inside the polynomial of this lane's outputs, before the register part
     const uint32_t n_mask = (1u << p.log_n) - 1;
@@ -501,9 +498,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         tile_of(DIRECT_STORE_TILE(k), b, a, z);
         obase = p.dst + (a * p.out_sa + z * p.out_sz);
         const uint32_t l = opaque_lane();
-        const uint32_t r = l & 15, kbhi = l >> 4;
+        const uint32_t r = l & 15, ka = 4 * (l >> 4) + kalo;
         const uint32_t k1 = (b * 16 + r + p.row_shift) & (p.t_limit - 1);
-        o_lane = k1 + (uint32_t)p.out_m * (wave + 64 * kbhi);
+        o_lane = k1 + (uint32_t)p.out_m * (ka + 64 * kbhi);
     };
     // register slot s of B: kBlo = s >> 2, and after the radix 4 over q slot (s & 3) holds kC = bitrev2(s & 3)
     auto tail_unit = [&](auto J_) {
@@ -555,8 +552,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         TAIL(12, 13);
         radix_dif_stage<4, 0, 0>(A);
         TAIL(13, 14);
-        // q = 0: the factor is 1, multiplied all the same (uniform code)
-        mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW2, tw2_base + brev_c(decltype(S_)::value, 4) * 8); }, [](auto) {});
         static_for<0, 16>([&](auto S_) {
             constexpr int s = decltype(S_)::value;
             constexpr int kb = brev_c(s, 4);
@@ -577,14 +572,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         DIRECT_TILE_BARRIER();  // image of tile k complete
         {
             const uint32_t l = opaque_lane();
-            const uint32_t xr_base = wave * SA + (l >> 4) * (4 * SB) + (l & 15) * 8;
+            // conflict-free like the writes: the sixteen rows are 128 contiguous bytes, kAhi moves by 4 SA = 128 (mod 256) bytes
+            const uint32_t xr_base = (4 * (l >> 4) + kalo) * SA + kbhi * (4 * SB) + (l & 15) * 8;
             static_for<0, 16>([&](auto S_) {
                 constexpr int s = decltype(S_)::value;
                 B[s] = lds_ld(X, xr_base + (s >> 2) * SB + (s & 3) * SQ);
             });
         }
         DIRECT_TILE_BARRIER();  // everyone has read it
-        radix_dif_blocks<2>(B);
+        // twiddle w_64^(kB q) and the radix 4 over q; kbhi is wave-uniform: a scalar switch
+        if (kbhi == 0) shift_twiddles_radix4<0>(B);
+        else if (kbhi == 1) shift_twiddles_radix4<1>(B);
+        else if (kbhi == 2) shift_twiddles_radix4<2>(B);
+        else shift_twiddles_radix4<3>(B);
         tail_begin(k);
         if (k < last) {
             first_rounds(std::true_type{});

@@ -237,6 +237,102 @@ __device__ __forceinline__ void radix_dif_blocks(uint64_t (&v)[16]) {
     static_for<0, D>([&](auto S_) { radix_dif_stage<D, 0, D - 1 - decltype(S_)::value, (16 >> D)>(v); });
 }
 
+// The last radix 4 of a 1024-point row WITH the twiddles in front of it as shifts (row pass with natural-order output). Sixteen
+// registers v[4 kblo + q]: q = input index of the radix 4, kB = 4 KBHI + kblo = output index of the radix 16 before it; the twiddle
+// between them is w_64^(q kB), and every 64th root of unity of this field is a power of two (w_64 = 2^39, 2^96 = -1): a shift by
+// (39 q kB) mod 96 and a sign instead of a table look-up and a twelve-instruction multiplication. The signs cost nothing: a negated
+// subtrahend swaps the roles of a butterfly's two results, and the sign of x1 (the minuend of its pair) is handed on to the second
+// stage, where x1's sum and difference are the subtrahends. KBHI must be a compile-time constant: the caller switches on it
+// (it is wave-uniform there). Rare paths deferred, three groups; a pending correction of the value that goes through the stage's
+// own shift (2^48) is applied behind it as the constant e 2^48 (see radix_dif_stage).
+template <int KBHI>
+__device__ __forceinline__ void shift_twiddles_radix4(uint64_t (&v)[16]) {
+    constexpr auto KQ = [](int kblo, int q) { return (39 * q * (4 * KBHI + kblo)) % 192; };
+    constexpr auto NEGQ = [](int kblo, int q) { return (39 * q * (4 * KBHI + kblo)) % 192 >= 96; };
+    {   // the twiddles of q = 1, 2, 3 (their signs are NEGQ)
+        gl::rare_mask fm[12];
+        static_for<0, 12>([&](auto I_) {
+            constexpr int i = decltype(I_)::value, kblo = i / 3, q = 1 + i % 3, KK = KQ(kblo, q) % 96;
+            v[4 * kblo + q] = gl::mul_pow2_f<KK>(v[4 * kblo + q], fm[i]);
+        });
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
+        gl::rare_mask any = 0;
+        static_for<0, 12>([&](auto I_) { any |= fm[decltype(I_)::value]; });
+        if (gl::rare_any(any))
+            static_for<0, 12>([&](auto I_) {
+                constexpr int i = decltype(I_)::value, kblo = i / 3, q = 1 + i % 3, KK = KQ(kblo, q) % 96;
+                v[4 * kblo + q] = gl::mul_pow2_fix<KK>(v[4 * kblo + q], fm[i]);
+            });
+    }
+    // butterfly (a, c) -> (a + C, a - C) in slots (i0, i1), C = -c when CNEG: then slot i0 takes the difference and i1 the sum.
+    // f0 / f1: the masks of the values written to i0 / i1
+    auto bfly = [&](auto CNEG_, auto I0_, auto I1_, gl::rare_mask &f0, gl::rare_mask &f1) {
+        constexpr bool cneg = decltype(CNEG_)::value;
+        constexpr int i0 = decltype(I0_)::value, i1 = decltype(I1_)::value;
+        if constexpr (cneg) gl::bfly_f<false>(v[i0], v[i1], v[i1], v[i0], f1, f0);
+        else gl::bfly_f<false>(v[i0], v[i1], v[i0], v[i1], f0, f1);
+    };
+    // correction of slot I: it holds a sum (IS_SUM) or a difference, and went through a shift by SHIFT afterwards (0: none)
+    auto fix = [&](auto IS_SUM_, auto SHIFT_, auto I_, gl::rare_mask f, gl::rare_mask fshift) {
+        constexpr bool is_sum = decltype(IS_SUM_)::value;
+        constexpr int shift = decltype(SHIFT_)::value, i = decltype(I_)::value;
+        if constexpr (shift == 0) {
+            v[i] = is_sum ? gl::add_fix(v[i], f) : gl::sub_fix(v[i], f);
+        } else {
+            v[i] = gl::mul_pow2_fix<shift>(v[i], fshift);
+            const uint64_t c = gl::masked(gl::eps_times_pow2(shift), f);
+            v[i] = is_sum ? gl::add(v[i], c) : gl::sub(v[i], c);
+        }
+    };
+    using std::integral_constant;
+    using std::bool_constant;
+    {   // first stage: pairs (0, 2) and (1, 3) of every block, then 2^48 on slot 3
+        gl::rare_mask f0[8], f1[8], fm[4];
+        static_for<0, 4>([&](auto B_) {
+            constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
+            bfly(bool_constant<NEGQ(kblo, 2)>{}, integral_constant<int, b>{}, integral_constant<int, b + 2>{}, f0[2 * kblo], f1[2 * kblo]);
+            bfly(bool_constant<NEGQ(kblo, 1) != NEGQ(kblo, 3)>{}, integral_constant<int, b + 1>{}, integral_constant<int, b + 3>{}, f0[2 * kblo + 1], f1[2 * kblo + 1]);
+        });
+        static_for<0, 4>([&](auto B_) {
+            constexpr int kblo = decltype(B_)::value;
+            v[4 * kblo + 3] = gl::mul_pow2_f<48>(v[4 * kblo + 3], fm[kblo]);
+        });
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
+        gl::rare_mask any = 0;
+        static_for<0, 8>([&](auto I_) { any |= f0[decltype(I_)::value] | f1[decltype(I_)::value]; });
+        static_for<0, 4>([&](auto I_) { any |= fm[decltype(I_)::value]; });
+        if (gl::rare_any(any))
+            static_for<0, 4>([&](auto B_) {
+                constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
+                constexpr bool na = NEGQ(kblo, 2), nb = NEGQ(kblo, 1) != NEGQ(kblo, 3);
+                fix(bool_constant<!na>{}, integral_constant<int, 0>{}, integral_constant<int, b>{}, f0[2 * kblo], 0);
+                fix(bool_constant<na>{}, integral_constant<int, 0>{}, integral_constant<int, b + 2>{}, f1[2 * kblo], 0);
+                fix(bool_constant<!nb>{}, integral_constant<int, 0>{}, integral_constant<int, b + 1>{}, f0[2 * kblo + 1], 0);
+                fix(bool_constant<nb>{}, integral_constant<int, 48>{}, integral_constant<int, b + 3>{}, f1[2 * kblo + 1], fm[kblo]);
+            });
+    }
+    {   // second stage: pairs (0, 1) and (2, 3); their subtrahends carry the sign of x1
+        gl::rare_mask f0[8], f1[8];
+        static_for<0, 4>([&](auto B_) {
+            constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
+            bfly(bool_constant<NEGQ(kblo, 1)>{}, integral_constant<int, b>{}, integral_constant<int, b + 1>{}, f0[2 * kblo], f1[2 * kblo]);
+            bfly(bool_constant<NEGQ(kblo, 1)>{}, integral_constant<int, b + 2>{}, integral_constant<int, b + 3>{}, f0[2 * kblo + 1], f1[2 * kblo + 1]);
+        });
+        __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
+        gl::rare_mask any = 0;
+        static_for<0, 8>([&](auto I_) { any |= f0[decltype(I_)::value] | f1[decltype(I_)::value]; });
+        if (gl::rare_any(any))
+            static_for<0, 4>([&](auto B_) {
+                constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
+                constexpr bool n1 = NEGQ(kblo, 1);
+                fix(bool_constant<!n1>{}, integral_constant<int, 0>{}, integral_constant<int, b>{}, f0[2 * kblo], 0);
+                fix(bool_constant<n1>{}, integral_constant<int, 0>{}, integral_constant<int, b + 1>{}, f1[2 * kblo], 0);
+                fix(bool_constant<!n1>{}, integral_constant<int, 0>{}, integral_constant<int, b + 2>{}, f0[2 * kblo + 1], 0);
+                fix(bool_constant<n1>{}, integral_constant<int, 0>{}, integral_constant<int, b + 3>{}, f1[2 * kblo + 1], 0);
+            });
+    }
+}
+
 // Synchronisation of the NT_ threads that share a tile: a wavefront (NT_ == 64) needs only program order.
 template <int NT_>
 __device__ __forceinline__ void tile_sync() {
