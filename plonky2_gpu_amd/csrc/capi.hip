@@ -277,7 +277,7 @@ __device__ uint64_t deferred_group(uint64_t x, uint64_t y, int which) {
     gl::rare_mask f[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) r[k] = KIND == 0 ? gl::add_f(a[k], b[k], f[k]) : KIND == 1 ? gl::sub_f(a[k], b[k], f[k]) : gl::mul_f(a[k], b[k], f[k]);
-    if (gl::rare_any(f[0] | f[1] | f[2])) {
+    if (GL_RARE_ANY(f[0] | f[1] | f[2])) {
 #pragma unroll
         for (int k = 0; k < 3; k++) r[k] = KIND == 0 ? gl::add_fix(r[k], f[k]) : KIND == 1 ? gl::sub_fix(r[k], f[k]) : gl::mul_fix(r[k], f[k]);
     }
@@ -291,7 +291,7 @@ __device__ uint64_t pow2f_case(uint64_t x, int k, bool alone) {
         if (k != K) return pow2f_case<K + 1>(x, k, alone);
         gl::rare_mask f0, f1;
         uint64_t r0 = gl::mul_pow2_f<K>(x, f0), r1 = gl::mul_pow2_f<K>(~x, f1);
-        if (gl::rare_any(f0 | f1)) r0 = gl::mul_pow2_fix<K>(r0, f0), r1 = gl::mul_pow2_fix<K>(r1, f1);
+        if (GL_RARE_ANY(f0 | f1)) r0 = gl::mul_pow2_fix<K>(r0, f0), r1 = gl::mul_pow2_fix<K>(r1, f1);
         return alone ? r0 : gl::add(r0, r1);  // x 2^K + ~x 2^K = (2^64 - 1) 2^K
     }
 }

@@ -427,6 +427,20 @@ __device__ __forceinline__ uint64_t masked(uint64_t x, rare_mask f) {
                  : "v"(xl), "v"(xh), "s"(f));
     return ((uint64_t)rh << 32) | rl;
 }
+// the compile-time constant C in the flagged lanes, 0 in the others. The constant is materialised HERE, by the asm itself: a
+// constant the compiler sees is hoisted out of the (cold) block that uses it and out of the loop around it, and then occupies
+// vector registers through the hot path.
+template <uint64_t C>
+__device__ __forceinline__ uint64_t masked_const(rare_mask f) {
+    uint32_t rl, rh;
+    asm volatile("v_mov_b32_e32 %0, %2\n\t"
+                 "v_mov_b32_e32 %1, %3\n\t"
+                 "v_cndmask_b32_e64 %0, 0, %0, %4\n\t"
+                 "v_cndmask_b32_e64 %1, 0, %1, %4"
+                 : "=&v"(rl), "=&v"(rh)
+                 : "i"((uint32_t)C), "i"((uint32_t)(C >> 32)), "s"(f));
+    return ((uint64_t)rh << 32) | rl;
+}
 // (2^32 - 1) 2^k mod p, canonical, for 0 <= k < 96
 constexpr uint64_t eps_times_pow2(int k) {
     uint64_t x = 0xFFFFFFFFull;
@@ -440,7 +454,9 @@ constexpr uint64_t eps_times_pow2(int k) {
 }
 
 // did any lane of the wave flag any operation of the group? (uniform: the masks are scalar registers)
-__device__ __forceinline__ bool rare_any(rare_mask m) { return __builtin_expect(m != 0, 0); }
+// A MACRO, not a function: the hint must sit in the `if` itself. (Returned from an inline function it is dropped before inlining, the
+// compiler lays the correction block out as the fall-through, and the hot path pays a TAKEN branch over it at every group.)
+#define GL_RARE_ANY(m) __builtin_expect((m) != 0, 0)
 
 // acc + x*y (goldilocks_field.rs:119-123): the multiplication followed by the addition, 16 VALU; the fused
 // arrangement this replaced (the addend riding on the first multiply-adds) took 22.

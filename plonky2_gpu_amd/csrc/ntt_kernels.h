@@ -126,7 +126,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
         __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
         gl::rare_mask any = 0;
         static_for<0, NB>([&](auto B_) { constexpr int b = decltype(B_)::value; any |= fa[b] | fs[b] | fm[b]; });
-        if (gl::rare_any(any)) {
+        if (GL_RARE_ANY(any)) {
             static_for<0, NB>([&](auto B_) {
                 constexpr int b = decltype(B_)::value, bb = b % NBP;
                 constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
@@ -134,9 +134,9 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
                 v[i0] = gl::add_fix(v[i0], fa[b]);
                 v[i1] = gl::mul_pow2_fix<KK>(v[i1], fm[b]);
                 #ifdef RARE_STAGE_WRONG_CONSTANT   // negative control of the tests only: the build must FAIL tests/test_gpu_ntt.py's rare-path test
-                v[i1] = gl::sub(v[i1], gl::masked(gl::eps_times_pow2(KK) + 1, fs[b]));
+                v[i1] = gl::sub(v[i1], gl::masked_const<gl::eps_times_pow2(KK) + 1>(fs[b]));
 #else
-                v[i1] = gl::sub(v[i1], gl::masked(gl::eps_times_pow2(KK), fs[b]));   // KK = 0: e itself
+                v[i1] = gl::sub(v[i1], gl::masked_const<gl::eps_times_pow2(KK)>(fs[b]));   // KK = 0: e itself
 #endif
             });
         }
@@ -158,7 +158,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
         __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);  // the ORs behind the last operation, see rare_group
         gl::rare_mask any = 0;
         static_for<0, GB>([&](auto B_) { any |= fa[decltype(B_)::value] | fs[decltype(B_)::value]; });
-        if (gl::rare_any(any)) {
+        if (GL_RARE_ANY(any)) {
             static_for<0, GB>([&](auto B_) {
                 constexpr int b = g0 + decltype(B_)::value, k = decltype(B_)::value, bb = b % NBP;
                 constexpr int i0 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half), i1 = i0 + half;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void radix_dif_stage(uint64_t (&v)[16]) {
         __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
         gl::rare_mask any = 0;
         static_for<0, NB>([&](auto B_) { any |= fm[decltype(B_)::value]; });
-        if (gl::rare_any(any)) {
+        if (GL_RARE_ANY(any)) {
             static_for<0, NB>([&](auto B_) {
                 constexpr int b = decltype(B_)::value, bb = b % NBP;
                 constexpr int i1 = BASE + (b / NBP) * (1 << D) + (bb / half) * 2 * half + (bb % half) + half;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void rare_group(One &&one, Fix &&fix) {
     __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
     gl::rare_mask any = 0;
     static_for<0, N>([&](auto I_) { any |= f[decltype(I_)::value]; });
-    if (gl::rare_any(any)) static_for<0, N>([&](auto I_) { fix(I_, f[decltype(I_)::value]); });
+    if (GL_RARE_ANY(any)) static_for<0, N>([&](auto I_) { fix(I_, f[decltype(I_)::value]); });
 }
 
 // v[idx(k)] *= w(k) for k = LO .. HI-1, eight multiplications per group; after(k) runs behind multiplication k (the passes put the
@@ -258,7 +258,7 @@ __device__ __forceinline__ void shift_twiddles_radix4(uint64_t (&v)[16]) {
         __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
         gl::rare_mask any = 0;
         static_for<0, 12>([&](auto I_) { any |= fm[decltype(I_)::value]; });
-        if (gl::rare_any(any))
+        if (GL_RARE_ANY(any))
             static_for<0, 12>([&](auto I_) {
                 constexpr int i = decltype(I_)::value, kblo = i / 3, q = 1 + i % 3, KK = KQ(kblo, q) % 96;
                 v[4 * kblo + q] = gl::mul_pow2_fix<KK>(v[4 * kblo + q], fm[i]);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void shift_twiddles_radix4(uint64_t (&v)[16]) {
             v[i] = is_sum ? gl::add_fix(v[i], f) : gl::sub_fix(v[i], f);
         } else {
             v[i] = gl::mul_pow2_fix<shift>(v[i], fshift);
-            const uint64_t c = gl::masked(gl::eps_times_pow2(shift), f);
+            const uint64_t c = gl::masked_const<gl::eps_times_pow2(shift)>(f);
             v[i] = is_sum ? gl::add(v[i], c) : gl::sub(v[i], c);
         }
     };
@@ -301,7 +301,7 @@ __device__ __forceinline__ void shift_twiddles_radix4(uint64_t (&v)[16]) {
         gl::rare_mask any = 0;
         static_for<0, 8>([&](auto I_) { any |= f0[decltype(I_)::value] | f1[decltype(I_)::value]; });
         static_for<0, 4>([&](auto I_) { any |= fm[decltype(I_)::value]; });
-        if (gl::rare_any(any))
+        if (GL_RARE_ANY(any))
             static_for<0, 4>([&](auto B_) {
                 constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
                 constexpr bool na = NEGQ(kblo, 2), nb = NEGQ(kblo, 1) != NEGQ(kblo, 3);
@@ -321,7 +321,7 @@ __device__ __forceinline__ void shift_twiddles_radix4(uint64_t (&v)[16]) {
         __builtin_amdgcn_sched_barrier(RARE_FENCE_MASK);
         gl::rare_mask any = 0;
         static_for<0, 8>([&](auto I_) { any |= f0[decltype(I_)::value] | f1[decltype(I_)::value]; });
-        if (gl::rare_any(any))
+        if (GL_RARE_ANY(any))
             static_for<0, 4>([&](auto B_) {
                 constexpr int kblo = decltype(B_)::value, b = 4 * kblo;
                 constexpr bool n1 = NEGQ(kblo, 1);

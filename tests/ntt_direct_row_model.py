@@ -75,23 +75,28 @@ def run(inverse, seed=3):
             addrs = []
             for lane in range(64):
                 q, ka = lane & 3, lane >> 2
-                val = A2[lane][s] * pow(w64, kb * q, P) % P
+                val = A2[lane][s]   # the twiddle w_64^(kb q) is applied by the reader (as shifts: w_64 = 2^39)
                 a = ka * SA + q * SQ + w * 8 + kb * SB
                 X[a] = val; addrs.append(a)
             worst_w = max(worst_w, conflicts_write(addrs))
     assert len(X) == 16 * 1024
     out = {}
-    for wv in range(16):   # wave = kA
+    assert w64 == pow(2, 39, P)
+    for wv in range(16):   # wave = (kBhi, kAlo), lane = (kAhi, row)
+        kbhi, kalo = wv >> 2, wv & 3
         for s in range(16):
-            addrs = [wv * SA + (l >> 4) * 4 * SB + (l & 15) * 8 + (s >> 2) * SB + (s & 3) * SQ for l in range(64)]
+            addrs = [(4 * (l >> 4) + kalo) * SA + kbhi * 4 * SB + (l & 15) * 8 + (s >> 2) * SB + (s & 3) * SQ for l in range(64)]
             worst_r = max(worst_r, conflicts_read(addrs))
         for lane in range(64):
-            r, kbhi = lane & 15, lane >> 4
-            B = [X[wv * SA + kbhi * 4 * SB + r * 8 + (s >> 2) * SB + (s & 3) * SQ] for s in range(16)]
+            r, ka = lane & 15, 4 * (lane >> 4) + kalo
+            B = [X[ka * SA + kbhi * 4 * SB + r * 8 + (s >> 2) * SB + (s & 3) * SQ] for s in range(16)]
+            for s in range(16):   # a shift by (39 q kB) mod 96 and a sign (2^96 = -1)
+                K = (39 * (s & 3) * (4 * kbhi + (s >> 2))) % 192
+                B[s] = B[s] * pow(2, K % 96, P) * (P - 1 if K >= 96 else 1) % P
             for j in range(4):
                 B[4 * j:4 * j + 4] = dif(B[4 * j:4 * j + 4], w4)
             k1 = (b * 16 + r + row_shift) & (N1 - 1)
-            o_lane = k1 + N1 * (wv + 64 * kbhi)
+            o_lane = k1 + N1 * (ka + 64 * kbhi)
             for s in range(16):
                 kblo, kc = s >> 2, brev(s & 3, 2)
                 o = o_lane + N1 * (16 * kblo + 256 * kc)
