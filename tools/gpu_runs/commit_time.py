@@ -7,4 +7,4 @@ import bench
 ctx = pg.Context(0)
 r = bench.bench_commit(pg, _lib, ctx, int(os.environ.get("COLS", "135")), int(os.environ.get("LOG_N", "20")), iters=int(os.environ.get("ITERS", "5")))
 print(json.dumps({"tag": os.environ.get("TAG"), "commit_ms": round(r["commit_ms"], 3), "without_leaf_major_copy_ms": round(r["commit_ms_without_leaf_major_copy"], 3),
-                  "cap0": r["cap0"][0]}), flush=True)
+                  "stages_one_at_a_time_ms": r["commit_stage_ms_one_at_a_time"], "cap0": r["cap0"][0]}), flush=True)
