@@ -496,8 +496,9 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
 const char *cudaGetErrorString(int code);
 
 /* Test hook: element-wise field op on device arrays (op: 0 add, 1 sub, 2 mul, 3 neg, 4 x^7,
- * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b), 8-16 internal variants, 17 a + (b mod 2^63) * 2^32); output
- * canonical. d_b may be NULL for unary ops. */
+ * 5 a + b*b, 6 a * 2^(b mod 192), 7 a + canon(b), 8-16 internal variants, 17 a + (b mod 2^63) * 2^32, 18-27 the grouped
+ * forms with deferred corrections); output canonical. d_b may be NULL for unary ops. Ops 100-109: the register-level radix
+ * routines of the NTT passes on vectors of sixteen elements (n = 16 x vectors; d_b unused), see csrc/capi.hip. */
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx);
 /* Measurement hook: a plain streaming copy kernel (16 B per lane, asynchronous on ctx->stream) — the bandwidth a
  * kernel can actually reach on this device, which bench.py reports next to the 8 TB/s specification. */

@@ -14,6 +14,7 @@
 #include "knobs.h"
 #include "merkle.h"
 #include "ntt.h"
+#include "ntt_kernels.h"
 #include "plonk.h"
 #include "fri.h"
 #include "ed25519_gate_program.inc"
@@ -1043,10 +1044,46 @@ GlError gl_debug_copy(void *d_dst, const void *d_src, uint64_t bytes, void *ctx)
     return ok();
 }
 
+// ops 100 .. 109 of gl_debug_field_op: the register-level radix routines of the NTT passes (ntt_kernels.h) on vectors of sixteen
+// elements, one vector per lane — so that the tests can drive their DEFERRED CORRECTION paths with operands that flag (inside a
+// transform only the first stage of the first pass ever sees such operands):
+//   100 + s (s = 0..3): radix_dif_stage<4, 0, s>      104: radix_dif<4, 0>      105: radix_dif_blocks<2>
+//   106 + k (k = 0..3): shift_twiddles_radix4<k>
+__global__ void radix_probe_kernel(int which, const uint64_t *in, uint64_t *out, uint64_t n_vec) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = i < n_vec ? i : n_vec - 1;   // every lane computes (the masks are per wave); the store is predicated
+    uint64_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = in[j * 16 + k];
+    using namespace nttk;
+    switch (which) {
+        case 0: radix_dif_stage<4, 0, 0>(v); break;
+        case 1: radix_dif_stage<4, 0, 1>(v); break;
+        case 2: radix_dif_stage<4, 0, 2>(v); break;
+        case 3: radix_dif_stage<4, 0, 3>(v); break;
+        case 4: radix_dif<4, 0>(v); break;
+        case 5: radix_dif_blocks<2>(v); break;
+        case 6: shift_twiddles_radix4<0>(v); break;
+        case 7: shift_twiddles_radix4<1>(v); break;
+        case 8: shift_twiddles_radix4<2>(v); break;
+        default: shift_twiddles_radix4<3>(v); break;
+    }
+    if (i < n_vec)
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[i * 16 + k] = gl::canon(v[k]);
+}
+
 GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, uint64_t n, void *ctx) {
     DeviceCall device_call(ctx);
     if (!ctx || !d_a || !d_out) return fail(GL_E_INVALID, "null pointer");
     if (n == 0) return ok();
+    if (op >= 100 && op < 110) {
+        if (n % 16) return fail(GL_E_INVALID, "ops 100-109 take vectors of sixteen elements");
+        const uint64_t n_vec = n / 16;
+        hipLaunchKernelGGL(radix_probe_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, S(ctx)->stream, op - 100, d_a, d_out, n_vec);
+        HIP_TRY(hipGetLastError());
+        return ok();
+    }
     hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(ctx)->stream, op, d_a, d_b,
                        d_out, n);
     HIP_TRY(hipGetLastError());

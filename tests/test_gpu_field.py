@@ -158,3 +158,60 @@ def test_deferred_rare_paths(gpu):
         kk = np.full(len(xs), k, dtype=np.uint64)
         assert run_op(gpu, 27, ax, kk) == [(M << k) % P] * len(xs), k
         assert run_op(gpu, 27, ax, kk + np.uint64(1 << 32)) == [(x << k) % P for x in xs], k
+
+
+def _dif_stage(v, s, d=4):
+    """One radix-2 stage of the in-register DIF butterflies (ntt_kernels.h radix_dif_stage): blocks of 2^d slots, stage s."""
+    half = 1 << s
+    out = list(v)
+    for base in range(0, 16, 1 << d):
+        for bb in range((1 << d) // 2):
+            i0 = base + (bb // half) * 2 * half + (bb % half)
+            i1 = i0 + half
+            k = (39 * (bb % half) * (32 >> s)) % 192
+            a, c = v[i0], v[i1]
+            out[i0] = (a + c) % P
+            out[i1] = (a - c) * pow(2, k, P) % P
+    return out
+
+
+def test_radix_routines_with_operands_that_flag_their_deferred_corrections(gpu):
+    """radix_dif_stage / radix_dif / radix_dif_blocks / shift_twiddles_radix4 (ntt_kernels.h) one vector of sixteen per lane, through
+    gl_debug_field_op 100-109. Inside a transform only the first stage of the first pass sees operands that make add's second wrap or
+    sub's second borrow fire; here every stage does: the vectors mix 0, tiny values, values just below 2^64 (>= p) and random words, so
+    the correction blocks — also the constants e 2^K that settle a pending correction behind a shift, and the role-swapped butterflies
+    of the signed radix 4 — run in most wavefronts. (Checked once with two deliberately wrong builds: a correction constant off by
+    one fails the stage comparisons, sum and difference roles exchanged in the signed radix 4's correction fail the last ones.)"""
+    rng = np.random.default_rng(23)
+    n_vec = 4096
+    kinds = rng.integers(0, 5, size=(n_vec, 16))
+    rnd = rng.integers(0, 2**64, size=(n_vec, 16), dtype=np.uint64)
+    small = rng.integers(0, 4, size=(n_vec, 16), dtype=np.uint64)
+    top = np.uint64((1 << 64) - 1) - small
+    nearp = np.uint64(P) + small
+    vec = np.where(kinds == 0, rnd, np.where(kinds == 1, small, np.where(kinds == 2, top, np.where(kinds == 3, nearp, np.uint64(0)))))
+    vec[:64] = np.uint64((1 << 64) - 1)   # a whole wavefront of the extreme operand
+    vec[64:128, 0::2] = 0                 # 0 - (2^64 - 1) in every butterfly of every stage order
+    vec[64:128, 1::2] = np.uint64((1 << 64) - 1)
+    vec[128:192, :8] = np.uint64((1 << 64) - 1)
+    vec[128:192, 8:] = 0
+    flat = np.ascontiguousarray(vec.reshape(-1))
+    rows = [[int(x) for x in r] for r in vec.tolist()]
+
+    def run(which):
+        return np.array(run_op(gpu, 100 + which, flat), dtype=np.uint64).reshape(n_vec, 16).tolist()
+
+    for s in range(4):
+        assert run(s) == [_dif_stage(r, s) for r in rows], ("stage", s)
+    def dif16(r):
+        for s in (3, 2, 1, 0):
+            r = _dif_stage(r, s)
+        return r
+    assert run(4) == [dif16(r) for r in rows]
+    def dif4_blocks(r):
+        return _dif_stage(_dif_stage(r, 1, d=2), 0, d=2)
+    assert run(5) == [dif4_blocks(r) for r in rows]
+    for kbhi in range(4):
+        def twiddled(r):
+            return dif4_blocks([x * pow(2, 39 * (i & 3) * (4 * kbhi + (i >> 2)), P) % P for i, x in enumerate(r)])
+        assert run(6 + kbhi) == [twiddled(r) for r in rows], ("shift twiddles + radix 4", kbhi)
