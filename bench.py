@@ -503,14 +503,20 @@ def main():
         for _ in range(inner):
             pair()
 
+    region_events_ms = []   # the same regions between two HIP events on the launch stream (rank-local)
+
     def timed_window():
         ctx.synchronize()
         dist.barrier()
+        e0, e1 = pg.Event(), pg.Event()
         t = time.perf_counter()
+        e0.record(ctx)
         for _ in range(args.steps):
             step()
+        e1.record(ctx)
         ctx.synchronize()
         dist.barrier()
+        region_events_ms.append(e1.elapsed_ms_since(e0))
         return dist.max(time.perf_counter() - t)
 
     for _ in range(args.warmup):
@@ -524,7 +530,13 @@ def main():
     if not (back == host).all():
         raise SystemExit("bench: ifft(fft(x)) != x — results invalid")
 
-    # forward transform timed with HIP events on the launch stream (roofline numerator: 16 B/elt)
+    # The roofline's kernel = one batch transform = one launch pair (column pass + row pass; the forward and the inverse instance
+    # alternate in the timed region and differ by the inverse's index flip in the row pass's stores). Its average launch duration
+    # = the timed region between two HIP events on the launch stream / the launch pairs in it: what `rocprofv3 --kernel-trace
+    # --stats` of this command reports for the two kernels together (profiles/). Bracketing every pair with its own events is
+    # kept beside it: each event is a marker the queue drains for, so those figures run 3-6 % higher.
+    launches_in_region = 2 * inner * args.steps
+    pair_ms = region_events_ms[0] / launches_in_region
     reps = max(40, args.steps)
     ev = [pg.Event() for _ in range(2 * reps)]
     fwd_ms = []
@@ -538,7 +550,7 @@ def main():
         fwd_ms.append(ev[2 * r + 1].elapsed_ms_since(ev[2 * r]))
     fwd = float(np.median(fwd_ms))
     alg_bytes = 16.0 * n * batch
-    achieved = alg_bytes / (fwd * 1e-3) / 1e9
+    achieved = alg_bytes / (pair_ms * 1e-3) / 1e9
     # what a streaming kernel moves on this very device: a 16 B/lane copy of the same 512 MiB, read + write
     scratch = pg.DeviceBuffer(ctx, batch * n)
     cev = [pg.Event() for _ in range(2)]
@@ -636,19 +648,22 @@ def main():
                 "traffic_over_algorithmic": traffic / alg_bytes if traffic is not None else None,
                 "int_alu_frac": (int_alu or {}).get("frac"),
                 "int_alu": int_alu,
-                "kernel": "forward batch NTT = ntt_col_direct_kernel (column pass) + ntt_row_natural_direct_kernel (row pass), "
-                          "one launch pair per 64-column batch",
+                "kernel": "batch NTT = ntt_col_direct_kernel (column pass) + ntt_row_natural_direct_kernel (row pass), one launch pair per "
+                          "64-column batch; forward and inverse instances alternate in the timed region",
                 "binding_roof": ("HBM-side traffic is %.2f x the algorithmic bytes: the second pass of a two-pass transform re-reads and "
                                  "re-writes every element. " % (traffic / alg_bytes) if traffic is not None else "") +
                                 "The passes are bound by vector-ALU issue, not by HBM (int_alu_frac; DESIGN.md 3.1)",
                 "algorithmic_bytes_per_launch_pair": alg_bytes,
-                "ms": fwd,
-                "ms_min_max": [float(min(fwd_ms)), float(max(fwd_ms))],
-                "ms_launch_pairs_timed": reps,
+                "ms": pair_ms,
+                "ms_definition": "HIP events around the timed region on the launch stream / launch pairs in it",
+                "ms_launch_pairs_timed": launches_in_region,
+                "ms_all_windows": [w / launches_in_region for w in region_events_ms],
+                "ms_forward_pairs_bracketed_one_by_one": {"median": fwd, "min": float(min(fwd_ms)), "max": float(max(fwd_ms)), "pairs": reps,
+                                                          "note": "every event is a marker the queue drains for: 3-6 % above the region's average"},
                 "measured_copy_GBps": copy_gbs,
                 "frac_of_measured_copy": achieved / copy_gbs,
                 "algorithmic_butterflies_per_launch_pair": mulmods,
-                "butterflies_per_s": mulmods / (fwd * 1e-3),
+                "butterflies_per_s": mulmods / (pair_ms * 1e-3),
             },
             # rank 0 at N = 1 only: at N > 1 the host cores belong to the other ranks' transcripts
             "cpu_baseline": None if (args.no_cpu or dist.world > 1) else cpu_baseline(log_n),

@@ -9,8 +9,10 @@ O=$R/gpurun_out/${TAG}pmc
 mkdir -p $O
 cd /tmp
 B="python3 $R/bench.py --no-prove --no-cpu --steps 3 --warmup 1 --inner 1 --windows 0"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bench -- python3 $R/bench.py --no-cpu --steps 10 --warmup 2 --inner 1 --windows 0 > $O/stats_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ntt -- python3 $R/bench.py --no-prove --no-cpu --no-commit --steps 20 --warmup 3 --inner 1 --windows 0 > $O/stats_ntt.log 2>&1
+# kernel durations of the SAME commands bench.py is run with (steady state: back-to-back launches, default steps / inner / windows):
+# the batch transform's two kernels here must add up to the bench line's roofline.ms
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_bench -- python3 $R/bench.py --no-cpu --no-reference > $O/stats_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ntt -- python3 $R/bench.py --no-prove --no-cpu --no-commit --no-reference > $O/stats_ntt.log 2>&1
 pmc() { n=$1; shift; timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$n -- $B > $O/pmc_$n.log 2>&1; }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
