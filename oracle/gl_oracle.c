@@ -294,6 +294,35 @@ void glo_coset_ifft(uint64_t *v, size_t n, uint64_t shift) {
     }
 }
 
+/* The root table as an opaque object, so that a caller with many columns builds it once — fft_root_table is built once per
+ * circuit and handed to every transform (circuit_builder.rs:849-851, fri/oracle.rs:709-731). Used by prove_oracle.c. */
+void *glo_root_table_new(size_t n) {
+    root_table_t *t = (root_table_t *)malloc(sizeof *t);
+    *t = root_table_new(n);
+    return t;
+}
+void glo_root_table_free(void *t) {
+    if (!t) return;
+    root_table_free((root_table_t *)t);
+    free(t);
+}
+void glo_fft_with_table(uint64_t *v, size_t n, unsigned r, const void *t) { fft_with_table(v, n, r, (const root_table_t *)t); }
+void glo_ifft_with_table(uint64_t *v, size_t n, const void *t) {
+    if (n <= 1) return;
+    ifft_with_table(v, n, (const root_table_t *)t);
+}
+void glo_coset_lde_with_table(const uint64_t *coeffs, size_t n, unsigned rate_bits, uint64_t shift, uint64_t *out, const void *t_ext) {
+    coset_lde_with_table(coeffs, n, rate_bits, shift, out, (const root_table_t *)t_ext);
+}
+
+/* lde(rate_bits).coset_fft(shift) of several columns, one task per column (fri/oracle.rs:990-997) */
+void glo_coset_lde_batch(const uint64_t *coeffs, size_t n_polys, size_t n, unsigned rate_bits, uint64_t shift, uint64_t *out, int n_threads) {
+    root_table_t rt = root_table_new(n << rate_bits);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+    for (size_t p = 0; p < n_polys; p++) coset_lde_with_table(coeffs + p * n, n, rate_bits, shift, out + p * (n << rate_bits), &rt);
+    root_table_free(&rt);
+}
+
 void glo_fft_batch(uint64_t *v, size_t n_polys, size_t n, int inverse, int n_threads) {
     root_table_t rt = root_table_new(n);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
@@ -708,22 +737,36 @@ int glo_commit_from_coeffs(const uint64_t *coeffs, size_t n_polys, size_t n, uns
                            int n_threads) {
     size_t n_ext = n << rate_bits;
     if (cap_height > log2_strict(n_ext)) return -1;
-    uint64_t *lde = (uint64_t *)malloc(n_polys * n_ext * 8);
+    /* The reference materialises the whole LDE [P][n_ext], transposes it and permutes the rows (three full-size matrices in
+     * flight). Same values here with one: the LDE is produced a block of columns at a time (one column per task, as rayon
+     * does) and every block is transposed straight into its place in the bit-reversed leaf rows — so that the full-width
+     * 2^21..2^23-row commitments fit the host memory of a test box. */
+    int nt = n_threads > 0 ? n_threads : 1;
+    size_t blk = (size_t)nt * 2;
+    if (blk > n_polys) blk = n_polys ? n_polys : 1;
+    uint64_t *tmp = (uint64_t *)malloc(blk * n_ext * 8);
     uint64_t *lv = leaves ? leaves : (uint64_t *)malloc(n_polys * n_ext * 8);
-    if (!lde || !lv) return -2;
+    if (!tmp || !lv) {
+        free(tmp);
+        if (!leaves) free(lv);
+        return -2;
+    }
     root_table_t rt = root_table_new(n_ext);
     const uint64_t shift = 7; /* F::coset_shift() types.rs:431-433 */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
-    for (size_t p = 0; p < n_polys; p++) coset_lde_with_table(coeffs + p * n, n, rate_bits, shift, lde + p * n_ext, &rt);
-    root_table_free(&rt);
-    /* transpose [P][n_ext] -> [n_ext][P], then permute rows by bit reversal */
     unsigned lg = log2_strict(n_ext);
-#pragma omp parallel for schedule(static) num_threads(n_threads > 0 ? n_threads : 1)
-    for (size_t i = 0; i < n_ext; i++) {
-        size_t src = glo_reverse_bits(i, lg);
-        for (size_t p = 0; p < n_polys; p++) lv[i * n_polys + p] = lde[p * n_ext + src];
+    for (size_t p0 = 0; p0 < n_polys; p0 += blk) {
+        size_t nb = n_polys - p0 < blk ? n_polys - p0 : blk;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+        for (size_t q = 0; q < nb; q++) coset_lde_with_table(coeffs + (p0 + q) * n, n, rate_bits, shift, tmp + q * n_ext, &rt);
+        /* transpose [P][n_ext] -> [n_ext][P], rows permuted by bit reversal */
+#pragma omp parallel for schedule(static) num_threads(nt)
+        for (size_t i = 0; i < n_ext; i++) {
+            size_t src = glo_reverse_bits(i, lg);
+            for (size_t q = 0; q < nb; q++) lv[i * n_polys + p0 + q] = tmp[q * n_ext + src];
+        }
     }
-    free(lde);
+    root_table_free(&rt);
+    free(tmp);
     int rc = 0;
     if (digests && cap) rc = glo_merkle_tree(lv, n_ext, n_polys, cap_height, digests, cap, n_threads);
     if (!leaves) free(lv);

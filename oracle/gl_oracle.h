@@ -66,6 +66,13 @@ void glo_coset_fft(uint64_t *v, size_t n, uint64_t shift);
 /* PolynomialValues::coset_ifft (polynomial/mod.rs:64-77) */
 void glo_coset_ifft(uint64_t *v, size_t n, uint64_t shift);
 
+/* the same transforms with a root table built once (fft_root_table, fft.rs:15-34; built once per circuit in the reference) */
+void *glo_root_table_new(size_t n);
+void glo_root_table_free(void *table);
+void glo_fft_with_table(uint64_t *v, size_t n, unsigned r, const void *table);
+void glo_ifft_with_table(uint64_t *v, size_t n, const void *table);
+void glo_coset_lde_with_table(const uint64_t *coeffs, size_t n, unsigned rate_bits, uint64_t shift, uint64_t *out, const void *table_ext);
+
 /* ---- Poseidon (plonky2/src/hash/poseidon.rs, hashing.rs, plonk/config.rs) ---- */
 void glo_poseidon(uint64_t state[12]);        /* poseidon.rs:602-616 (fast partial rounds) */
 void glo_poseidon_naive(uint64_t state[12]);  /* poseidon.rs:631-640 */
@@ -101,6 +108,7 @@ int glo_commit_from_coeffs(const uint64_t *coeffs, size_t n_polys, size_t n, uns
 
 /* batch helpers used by the cpu_baseline timing (one task per column, like rayon par_iter) */
 void glo_fft_batch(uint64_t *v, size_t n_polys, size_t n, int inverse, int n_threads);
+void glo_coset_lde_batch(const uint64_t *coeffs, size_t n_polys, size_t n, unsigned rate_bits, uint64_t shift, uint64_t *out, int n_threads);
 /* timed inside C, root table prebuilt, thread-local first-touched columns: see gl_oracle.c */
 double glo_fft_bench(size_t n, int n_threads, int cols_per_thread, uint64_t seed, uint64_t *checksum);
 int glo_hardware_threads(void);

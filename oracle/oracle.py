@@ -16,7 +16,7 @@ P = 0xFFFFFFFF00000001
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("gl_oracle.c", "gl_oracle.h", "poseidon_constants.h")]
+    src = [os.path.join(_HERE, f) for f in ("gl_oracle.c", "gl_oracle.h", "prove_oracle.c", "prove_oracle.h", "poseidon_constants.h")]
     if (
         force
         or not os.path.exists(_LIB_PATH)
@@ -68,6 +68,7 @@ def lib():
             ("glo_commit_from_values", i, [_u64p, sz, sz, ui, ui, _u64p, _u64p, _u64p, _u64p, i]),
             ("glo_commit_from_coeffs", i, [_u64p, sz, sz, ui, ui, _u64p, _u64p, _u64p, i]),
             ("glo_fft_batch", None, [_u64p, sz, sz, i, i]),
+            ("glo_coset_lde_batch", None, [_u64p, sz, sz, ui, u64, _u64p, i]),
             ("glo_fft_bench", ctypes.c_double, [sz, i, i, ctypes.c_uint64, _u64p]),
             ("glo_hardware_threads", i, []),
         ]:
@@ -107,6 +108,14 @@ def coset_lde(coeffs, rate_bits, shift=7):
     c = _arr(coeffs)
     out = np.empty(c.size << rate_bits, dtype=np.uint64)
     lib().glo_coset_lde(_p(c), c.size, rate_bits, shift, _p(out))
+    return out
+
+
+def coset_lde_batch(coeffs, rate_bits, shift=7, threads=1):
+    """coeffs [n_polys, n] -> [n_polys, n << rate_bits] (natural order), one column per thread."""
+    c = _arr(coeffs)
+    out = np.empty((c.shape[0], c.shape[1] << rate_bits), dtype=np.uint64)
+    lib().glo_coset_lde_batch(_p(c), c.shape[0], c.shape[1], rate_bits, shift, _p(out), threads)
     return out
 
 
@@ -233,6 +242,12 @@ def commit_from_coeffs(coeffs, rate_bits, cap_height, threads=1, want_leaves=Tru
 
 def hardware_threads():
     return lib().glo_hardware_threads()
+
+
+def usable_threads():
+    """threads worth starting: the hardware threads this process may use, capped by the container's CPU quota"""
+    q = cpu_quota()
+    return max(1, min(hardware_threads(), int(q))) if q else hardware_threads()
 
 
 def cpu_quota():

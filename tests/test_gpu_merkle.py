@@ -372,6 +372,105 @@ def test_commit_at_the_full_benchmark_size(gpu, oracle):
         assert (a.merkle_tree.d_digests.download(4 * slot, 4) == b.merkle_tree.d_digests.download(4 * slot, 4)).all(), slot
 
 
+def _bitrev_take(col, log_n):
+    """col[bitrev(i)] for all i, without a 64-bit index array per call site (2^26 entries at the largest size)"""
+    perm = bitrev_perm(log_n)
+    out = col[perm]
+    del perm
+    return out
+
+
+@pytest.mark.parametrize("log_n", [21, 22, 23])
+def test_full_width_commit_of_large_traces(gpu, oracle, log_n):
+    """north_star's trace sizes at the FULL width of standard_recursion_config: from_values of 135 columns x 2^21, 2^22
+    and 2^23 rows at rate 8, cap height 4 (fri/oracle.rs:709-731, 911-977; hash/merkle_tree.rs:283-319). The LDE of the
+    last two has 4.5e9 and 9.1e9 elements — more than 2^32, 36 and 72 GB in HBM: every index of the path is 64-bit or
+    this fails. 2^21: the C oracle's WHOLE answer (cap and all 2 (2^24 - 16) digests). 2^22, 2^23: three whole columns
+    (coefficients and LDE) against the oracle, from_coeffs builds the same tree, 50 opened leaves verify against the cap
+    with the oracle's verifier and carry the LDE columns' values, a corrupted leaf is rejected."""
+    import time
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    n_polys, rate_bits, h = 135, 3, 4
+    n, n_ext = 1 << log_n, 1 << (log_n + rate_bits)
+    assert n_polys * n_ext > (1 << 32) or log_n == 21
+    watch = (0, 67, 134)
+    whole = log_n == 21
+    threads = oracle.usable_threads()
+    d_vals = pg.DeviceBuffer(gpu, n_polys * n)
+    values = np.empty((len(watch), n), dtype=np.uint64)
+    all_values = np.empty((n_polys, n), dtype=np.uint64) if whole else None
+    chunk = 5
+    for c0 in range(0, n_polys, chunk):
+        v = oracle.random_field((chunk, n), seed=9100 + 1000 * log_n + c0)
+        d_vals.upload(v, c0 * n)
+        if whole:
+            all_values[c0:c0 + chunk] = v
+        for k, c in enumerate(watch):
+            if c0 <= c < c0 + chunk:
+                values[k] = v[c - c0]
+        del v
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    a = pg.PolynomialBatch.from_values_device(gpu, d_vals, n_polys, log_n, rate_bits, False, h, leaf_major=False)
+    gpu.synchronize()
+    print("from_values 135 x 2^%d: %.1f ms (first call, tables included)" % (log_n, 1e3 * (time.perf_counter() - t0)))
+    cap = a.merkle_tree.cap
+    assert cap.shape == (16, 4)
+    if whole:
+        t0 = time.perf_counter()
+        exp = oracle.commit_from_values(all_values, rate_bits, h, threads=threads, want_leaves=False)
+        print("oracle commit of 135 x 2^21 on %d threads: %.1f s" % (threads, time.perf_counter() - t0))
+        del all_values
+        assert (cap == oracle.canon(exp["cap"])).all(), "cap"
+        assert (a.merkle_tree.d_digests.download().reshape(-1, 4) == oracle.canon(exp["digests"])).all(), "digests"
+        del exp
+    # three whole columns: coefficients == the oracle's ifft, LDE column == the oracle's coset LDE in leaf order
+    coeffs = oracle.canon(oracle.fft_batch(values, inverse=True, threads=len(watch)))
+    del values
+    for k, c in enumerate(watch):
+        assert (a.d_polynomials.download(c * n, n) == coeffs[k]).all(), ("coefficients", c)
+    lde_nat = oracle.canon(oracle.coset_lde_batch(coeffs, rate_bits, threads=len(watch)))
+    del coeffs
+    perm = bitrev_perm(log_n + rate_bits)
+    lde = []
+    for k, c in enumerate(watch):
+        want = lde_nat[k][perm]
+        got = a.d_lde.download(c * n_ext, n_ext)
+        assert (got == want).all(), ("LDE", c)
+        lde.append(got)
+        del want
+    del lde_nat, perm
+    rng = np.random.default_rng(770 + log_n)
+    idx = [0, n_ext - 1, n_ext // 2, n_ext // 2 - 1] + [int(i) for i in rng.integers(0, n_ext, size=46)]
+    leaves, sib = a.merkle_tree.open_batch(idx)
+    for q, i in enumerate(idx):
+        assert oracle.merkle_verify(leaves[q], i, cap, sib[q]), i
+        for k, c in enumerate(watch):
+            assert leaves[q][c] == lde[k][i], (i, c)
+    bad = leaves[7].copy()
+    bad[133] ^= np.uint64(1)
+    assert not oracle.merkle_verify(bad, idx[7], cap, sib[7])
+    del lde
+    # from_coeffs on the coefficients: the same tree. The LDE buffer of `a` is released first: two 72 GB LDEs and their
+    # trees do not fit beside each other at 2^23 rows.
+    digests_a = a.merkle_tree.d_digests
+    slots = [0, 1, 2 * (n_ext - 16) - 1] + [int(s) for s in rng.integers(0, 2 * (n_ext - 16), size=200)]
+    sampled = [digests_a.download(4 * s, 4) for s in slots]
+    d_coeffs = a.d_polynomials
+    a.d_lde.free()
+    digests_a.free()
+    b = pg.PolynomialBatch.from_coeffs_device(gpu, d_coeffs, n_polys, log_n, rate_bits, False, h, leaf_major=False)
+    assert (b.merkle_tree.cap == cap).all()
+    for s, want in zip(slots, sampled):
+        assert (b.merkle_tree.d_digests.download(4 * s, 4) == want).all(), s
+    b.d_lde.free()
+    b.merkle_tree.d_digests.free()
+    d_coeffs.free()
+
+
 @pytest.mark.parametrize("n_cols,n_rows", [(1, 64), (1, 10), (1, 65), (2, 10), (7, 1000), (64, 4096), (96, 640), (97, 641), (135, 8192), (234, 2048), (300, 129), (20, 1 << 16)])
 @pytest.mark.parametrize("kernel", ["strip", "tile"])
 def test_leaf_major_copy_and_back(gpu, n_cols, n_rows, kernel):

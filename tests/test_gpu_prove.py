@@ -281,20 +281,23 @@ def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
 
 
 @pytest.mark.parametrize("degree_bits,proof_bytes", [(18, 204544), (20, 219072)])
-def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu, degree_bits, proof_bytes):
+def test_full_size_proof_bytes_equal_the_c_oracle(gpu, degree_bits, proof_bytes):
     """The shape bench.py times (BASELINE.json configs[3]: n = 2^18, 234 wires / 80 routed, 88 preprocessed
-    polynomials, rate 8, cap height 4, FRI arities [4, 4, 4, 4], 28 queries, 16 proof-of-work bits) proven by
-    gl_prove and checked by the oracle's verifier, which recomputes every challenge from the bytes. bench.py
-    itself may not use the oracle for this (only its cpu_baseline leg may), so the validity of what it times is
-    established here; the witness comes from the same generator with the same seed as the bench's rank 0. The second
-    case, 2^20 rows (LDE 2^23: three-pass transforms, 15.7 GB of wire LDE), is the largest the verifier gets to see;
-    gl_prove itself has been run to 2^21 rows (473 ms)."""
+    polynomials, rate 8, cap height 4, FRI arities [4, 4, 4, 4], 28 queries, 16 proof-of-work bits; the whole 25-gate
+    ed25519 table evaluated at every point) proven by gl_prove and compared BYTE FOR BYTE with the C restatement of
+    prove() (oracle/prove_oracle.c: plonk/prover.rs:40-233 on the box's CPU cores — the same function that is bench.py's
+    prove() CPU baseline), then checked by the oracle's verifier, which recomputes every challenge from the bytes.
+    bench.py itself may not use the oracle for this (only its cpu_baseline leg may), so the validity of what it times is
+    established here; the witness comes from the same generator with the same seed as the bench's rank 0. The second case,
+    2^20 rows (LDE 2^23: three-pass transforms, 15.7 GB of wire LDE), is north_star's 2^20-row trace as a whole proof."""
     import os
     import sys
+    import time
 
     import numpy as np
 
     import plonky2_gpu_amd as pg
+    from oracle import accel, prove_c
     from plonky2_gpu_amd.challenger import hash_no_pad
 
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
@@ -308,9 +311,22 @@ def test_full_size_proof_is_accepted_by_the_oracle_verifier(gpu, degree_bits, pr
     d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))
     data = nc.prove_bytes(d_wires, pis)
     assert len(data) == proof_bytes
-    vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
-    assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
+    digest, cs_cap = nc.circuit_digest, nc.constants_sigmas_cap
     nc.close()
+    d_wires.free()
+    t0 = time.perf_counter()
+    oc = prove_c.Circuit(circuit)
+    assert oc.circuit_digest == [int(v) for v in digest]
+    tr = {}
+    want = oc.prove(wires, pis, trace=tr)
+    oc.close()
+    print("C oracle prove() at 2^%d rows on %d threads: %.1f s; stages %s" % (degree_bits, oc.threads, time.perf_counter() - t0,
+                                                                            {k: round(v, 1) for k, v in tr["stage_seconds"].items()}))
+    assert len(data) == len(want)
+    assert data == want, "first differing 8-byte word: %d" % next(i // 8 for i in range(0, len(want), 8) if data[i:i + 8] != want[i:i + 8])
+    vc = dict(circuit, circuit_digest=digest, constants_sigmas=dict(cap=cs_cap))
+    with accel.c_backend():
+        assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
 
 
 @pytest.mark.parametrize("compile_gates", [True, False])
@@ -362,11 +378,12 @@ def test_all_25_gates_proof_bytes_at_2e14_rows_equal_the_fixture(gpu):
         assert data == want, compile_gates
 
 
-def test_full_size_proof_with_all_25_gate_kinds_in_use_is_accepted_by_the_oracle_verifier(gpu):
+def test_full_size_proof_with_all_25_gate_kinds_in_use_bytes_equal_the_c_oracle(gpu):
     """BASELINE.json configs[3] at its full shape (2^18 rows, 234 wires / 80 routed, 88 preprocessed polynomials, rate 8,
     cap height 4, arities [4,4,4,4], 28 queries, 16 PoW bits) with EVERY one of the 25 gate kinds constraining rows
-    (10 485 rows each, honestly generated, tied by copy constraints): proven by gl_prove, accepted by the oracle's
-    verifier, which re-derives every challenge and evaluates all 25 gates' constraints at zeta over F_p^2 on its own."""
+    (10 485 rows each, honestly generated, tied by copy constraints): proven by gl_prove, BYTE-EQUAL to the C restatement of
+    prove() (oracle/prove_oracle.c), accepted by the oracle's verifier, which re-derives every challenge and evaluates all 25
+    gates' constraints at zeta over F_p^2 on its own."""
     import numpy as np
 
     import plonky2_gpu_amd as pg
@@ -381,6 +398,9 @@ def test_full_size_proof_with_all_25_gate_kinds_in_use_is_accepted_by_the_oracle
     d_wires = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(wires))
     data = nc.prove_bytes(d_wires, pis)
     assert len(data) == 204544
+    from oracle import prove_c
+
+    assert data == prove_c.prove(circuit, wires, pis), "gl_prove's bytes differ from the C restatement of prove() at 2^18 rows with all 25 gate kinds in use"
     vc = dict(circuit, circuit_digest=nc.circuit_digest, constants_sigmas=dict(cap=nc.constants_sigmas_cap))
     with accel.c_backend():
         assert prove_ref.verify(vc, pg.serialization.proof_from_bytes(data, circuit))
