@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the configs[3]/[4]-shaped prove() measurement")
     ap.add_argument("--no-reference", action="store_true", help="skip timing the reference's own kernels (oracle/_ref) on this GPU")
+    ap.add_argument("--reference-leg-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--prove-degree-bits", type=int, default=18)
     ap.add_argument("--prove-wires", type=int, default=234)
     ap.add_argument("--prove-reps", type=int, default=3)
@@ -120,58 +121,48 @@ def cpu_baseline(log_n):
     }
 
 
-def cpu_baseline_commit(cols, log_n, rate_bits=3, cap_height=4, budget_s=25.0):
-    """configs[2]'s leg on the CPU: the C oracle's commit_from_values (restating PolynomialBatch::from_values, fri/oracle.rs:709-731,
+def cpu_baseline_commit(cols, log_n, rate_bits=3, cap_height=4):
+    """configs[2]'s leg on the CPU, WHOLE: the C oracle's commit_from_values (restating PolynomialBatch::from_values, fri/oracle.rs:709-731,
     and MerkleTree::new, hash/merkle_tree.rs:283-319: ifft per column, coset LDE per column, transpose + bit reversal, leaf hashing
-    and the cap subtrees, threaded per column / per subtree like the reference's rayon split) on every core the container may
-    use, at a REDUCED row count chosen to fit the budget (the work is linear in the rows up to the log factor of the transforms)."""
+    and the cap subtrees, threaded per column / per subtree like the reference's rayon split) of the same shape as the GPU leg —
+    135 columns x 2^20 rows — on every core the container may use: half a minute on the pool's 16 CPUs (round 4 ran half the
+    rows and projected)."""
     from oracle import oracle as o
 
-    hw, quota = o.hardware_threads(), o.cpu_quota()
-    cores = max(1, min(hw, int(quota))) if quota else hw
-    # about 1.5 M permutations/s/thread: rows so that leaves x ceil(cols/8) permutations take a few seconds
-    perms_per_row = ((cols + 7) // 8 + 1) << rate_bits
-    sample_log_n = min(log_n, max(10, int(np.log2(max(1.0, 0.25 * budget_s * 1.5e6 * cores / perms_per_row)))))
-    n = 1 << sample_log_n
+    cores = o.usable_threads()
+    n = 1 << log_n
     vals = o.random_field((cols, n), seed=0x706C6F6E6B7932 + 7)
     t = time.perf_counter()
     o.commit_from_values(vals, rate_bits, cap_height, threads=cores, want_leaves=True)
     dt = time.perf_counter() - t
     leaves = n << rate_bits
-    return {"value": leaves / dt, "unit": "Merkle leaves/s (whole commit)", "cores": cores, "kind": "port", "seconds": dt,
+    return {"value": leaves / dt, "unit": "Merkle leaves/s (whole commit)", "cores": cores, "kind": "port", "seconds": dt, "ms": dt * 1e3,
             "poseidon_permutations_per_s": leaves * ((cols + 7) // 8 + 1) / dt,
-            "projected_ms_at_full_size": dt * (1 << (log_n - sample_log_n)) * 1e3,
-            "sample": f"one from_values of {cols} columns x 2^{sample_log_n} rows (configs[2] has 2^{log_n}), rate {1 << rate_bits}, cap_height {cap_height}, "
-                      f"leaf-major copy included, on {cores} threads; C restatement (oracle/gl_oracle.c glo_commit_from_values)"}
+            "sample": f"one from_values of {cols} columns x 2^{log_n} rows = configs[2] whole, rate {1 << rate_bits}, cap_height {cap_height}, "
+                      f"leaf-major matrix included, on {cores} threads; C restatement (oracle/gl_oracle.c glo_commit_from_values)"}
 
 
-def cpu_baseline_prove(degree_bits, num_wires, rate_bits=3, cap_height=4):
-    """configs[3]'s leg on the CPU, as far as a compiled restatement exists: the THREE commitments of prove() at the ed25519
-    shape (wires 234 columns, Zs/partial products 20, quotient chunks 16; plonk/prover.rs:84, 125, 174 -> from_values /
-    from_coeffs) with the C oracle on every core the container may use. The quotient evaluation, the openings and FRI are
-    restated in Python only (oracle/plonk_ref.py, fri_ref.py: minutes per proof at 2^12 rows), so this is a LOWER bound of the
-    CPU prover's time, said so in `sample`; the reference's README quotes 45 s for its CPU prover on its authors' machine."""
-    from oracle import oracle as o
+def cpu_baseline_prove(circuit, wires, pis, gpu_proof):
+    """configs[3]'s leg on the CPU: a REAL prove() — the C restatement of plonk/prover.rs:40-233 from the full witness on
+    (oracle/prove_oracle.c: the three commitments, the permutation argument, all 25 gates' constraints at every LDE point, the
+    quotient, the opening set, the FRI opening proof with the smallest proof-of-work witness, the wire format), threaded like
+    the reference's rayon loops, on every core the container may use — of the VERY circuit and witness rank 0's GPU leg proved.
+    As the checker it also says whether its bytes equal gl_prove's (they must: tests/test_gpu_prove.py asserts it). The
+    preprocessing (constants/sigmas commitment, circuit_builder.rs:849-960) is outside the clock on both sides. Until round 5
+    this leg timed the three commitments only. The reference's README quotes 45 s for its CPU prover on its authors' 8 cores."""
+    from oracle import prove_c
 
-    hw, quota = o.hardware_threads(), o.cpu_quota()
-    cores = max(1, min(hw, int(quota))) if quota else hw
-    n = 1 << degree_bits
-    parts = {}
-    total = 0.0
-    for name, cols in (("wires", num_wires), ("zs_partial_products", 20), ("quotient_chunks", 16)):
-        vals = o.random_field((cols, n), seed=0x706C6F6E6B7932 + cols)
-        t = time.perf_counter()
-        if name == "quotient_chunks":
-            o.commit_from_coeffs(vals, rate_bits, cap_height, threads=cores, want_leaves=False)
-        else:
-            o.commit_from_values(vals, rate_bits, cap_height, threads=cores, want_leaves=False)
-        parts[name] = time.perf_counter() - t
-        total += parts[name]
-    return {"value": total * 1e3, "unit": "ms per proof, the three commitments only (lower bound of prove())", "cores": cores, "kind": "port",
-            "commit_ms": {k: v * 1e3 for k, v in parts.items()},
-            "sample": f"the three PolynomialBatch commitments of one proof at n = 2^{degree_bits} ({num_wires} + 20 + 16 columns, rate {1 << rate_bits}) on "
-                      f"{cores} threads with the C oracle; quotient evaluation, openings and FRI have only Python restatements and are NOT "
-                      f"included, so the CPU prover takes longer than this"}
+    oc = prove_c.Circuit(circuit)
+    tr = {}
+    t = time.perf_counter()
+    data = oc.prove(wires, pis, trace=tr)
+    dt = time.perf_counter() - t
+    oc.close()
+    return {"value": dt * 1e3, "unit": "ms per proof (whole prove() from the full witness on)", "cores": oc.threads, "kind": "port",
+            "stage_ms": {k: round(v * 1e3, 1) for k, v in tr["stage_seconds"].items()},
+            "proof_bytes": len(data), "bytes_equal_gl_prove": (data == gpu_proof) if gpu_proof is not None else None,
+            "sample": f"one proof of the bench's own circuit and witness (n = 2^{circuit['degree_bits']}, {circuit['num_wires']} wires, "
+                      f"{len(circuit['gates'])} gates) on {oc.threads} threads with the C restatement of prove() (oracle/prove_oracle.c)"}
 
 
 def cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, log_n, batch, commit_cols, commit_log_n):
@@ -233,6 +224,43 @@ def cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, log_n, batch, commit_cols,
     for b in (region, t1, t2, shifts):
         b.free()
     return out
+
+
+def cpu_baseline_reference_gpu_kernels_in_child(log_n, batch, commit_cols, commit_log_n, timeout_s=420):
+    """The leg above in a FRESH CHILD PROCESS with a time limit: the reference's kernels are untrusted code (int indexing,
+    32-thread blocks, member-function-pointer stacks, the null stream) — a memory fault or a hang there must cost this leg,
+    not the measurements already taken. The child is this script with --reference-leg-child; it prints one JSON
+    object; anything else (non-zero exit, timeout, unparsable output) becomes `absent_because`."""
+    import subprocess
+
+    from oracle import ref_gpu
+
+    if not ref_gpu.available():
+        return {"absent_because": ref_gpu.why_absent()}
+    cmd = [sys.executable, os.path.abspath(__file__), "--reference-leg-child", "--log-n", str(log_n), "--batch", str(batch),
+           "--commit-cols", str(commit_cols), "--commit-log-n", str(commit_log_n)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"absent_because": f"the child running the reference's kernels did not finish within {timeout_s} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"absent_because": f"the child running the reference's kernels exited with {r.returncode}: {r.stderr[-300:]}"}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"absent_because": f"unparsable output of the child: {e}"}
+
+
+def cpu_baseline_reference_leg_child(args):
+    """entry of the child process started by cpu_baseline_reference_gpu_kernels_in_child"""
+    from oracle import ref_gpu  # noqa: F401  (this function is part of the baseline leg)
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    ctx = pg.Context(0)
+    print(json.dumps(cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, args.log_n, args.batch, args.commit_cols, args.commit_log_n)), flush=True)
+    ctx.close()
 
 
 SPLITMIX_SEED = 0x706C6F6E6B7932  # "plonky2" (SURVEY.md 8d)
@@ -456,6 +484,8 @@ def pick_backend(world, ndev):
 
 def main():
     args = parse()
+    if args.reference_leg_child:
+        return cpu_baseline_reference_leg_child(args)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -600,8 +630,9 @@ def main():
         if dist.rank == 0:
             extra["sharded_commit"] = sc
 
+    prove_inputs = None
     if not args.no_prove:
-        pr = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
+        pr, prove_inputs = bench_prove(pg, ctx, dist, args.prove_degree_bits, args.prove_wires, args.prove_reps)
         if dist.rank == 0:
             extra["prove"] = pr
 
@@ -673,15 +704,13 @@ def main():
             # the other two legs of the metric on this host's cores, and the reference's own kernels on this GPU
             if not args.no_commit:
                 extra["commit_cpu_baseline"] = cpu_baseline_commit(args.commit_cols, args.commit_log_n)
-                extra["commit_speedup_vs_cpu_baseline_projected"] = extra["commit_cpu_baseline"]["projected_ms_at_full_size"] / extra["commit_ms"]
-            if not args.no_prove:
-                extra["prove_cpu_baseline"] = cpu_baseline_prove(args.prove_degree_bits, args.prove_wires)
+                extra["commit_speedup_vs_cpu_baseline"] = extra["commit_cpu_baseline"]["ms"] / extra["commit_ms"]
+            if not args.no_prove and prove_inputs is not None:
+                extra["prove_cpu_baseline"] = cpu_baseline_prove(*prove_inputs)
+                extra["prove_speedup_vs_cpu_baseline"] = extra["prove_cpu_baseline"]["value"] / extra["prove"]["prove_ms"]
             if not args.no_reference:
-                try:
-                    extra["reference_gpu_kernels_on_this_mi355x"] = cpu_baseline_reference_gpu_kernels(pg, _lib, ctx, log_n, batch, args.commit_cols, args.commit_log_n)
-                except Exception as e:  # noqa: BLE001  a baseline leg must not take the measurement down
-                    extra["reference_gpu_kernels_on_this_mi355x"] = {"absent_because": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out))
+                extra["reference_gpu_kernels_on_this_mi355x"] = cpu_baseline_reference_gpu_kernels_in_child(log_n, batch, args.commit_cols, args.commit_log_n)
+        print(json.dumps(out), flush=True)
     buf.free()
     ctx.close()
     dist.barrier()  # rank 0 runs the extra legs; leave the group together
@@ -730,7 +759,7 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
         # Self-checks that need no oracle (only the cpu_baseline leg may touch it): the proof parses with the
         # product's reader into the shape the circuit dictates, re-serialises to the same bytes, and is
         # identical from run to run. Its VALIDITY at this very shape is established where the oracle is allowed:
-        # tests/test_gpu_prove.py::test_full_size_proof_is_accepted_by_the_oracle_verifier (run with -m gpu).
+        # tests/test_gpu_prove.py::test_full_size_proof_bytes_equal_the_c_oracle (run with -m gpu).
         parsed = pg.serialization.proof_from_bytes(data, circuit)
         if pg.serialization.proof_to_bytes(parsed) != data or again != data:
             raise SystemExit("bench: the proof does not round-trip through the wire format or is not deterministic")
@@ -750,10 +779,11 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
             "prover": "gl_prove (native host logic, csrc/prove.hip)",
             "stage_ms": {k: round(v, 3) for k, v in timing.items()},
             "self_checks": "parses, re-serialises identically, deterministic across runs",
-            "validity_checked_by": "tests/test_gpu_prove.py::test_full_size_proof_is_accepted_by_the_oracle_verifier",
+            "validity_checked_by": "tests/test_gpu_prove.py::test_full_size_proof_bytes_equal_the_c_oracle",
         }
     d_wires.free()
-    return res
+    # rank 0 at N = 1 hands its circuit, witness and proof to the CPU leg (cpu_baseline_prove), which proves the same thing
+    return res, ((circuit, wires, pis, data) if dist.rank == 0 and dist.world == 1 else None)
 
 
 def bench_sharded_commit(pg, ctx, dist, cols, log_n, rate_bits=3, cap_height=4, iters=2):

@@ -194,6 +194,10 @@ typedef struct GlGateProgram {
  *   BASE_SUM {B, num_limbs}                   U32_ADD_MANY {num_addends, num_ops}
  *   U32_ARITHMETIC / U32_SUBTRACTION {num_ops}  U32_RANGE_CHECK {num_input_limbs}
  *   COMPARISON {num_bits, num_chunks} (chunks of at most 4 bits)   RANDOM_ACCESS {bits, num_copies, num_extra_constants}
+ *   ARITHMETIC_EXTENSION / MUL_EXTENSION {num_ops}   REDUCING / REDUCING_EXTENSION {num_coeffs}   EXPONENTIATION {num_power_bits}
+ *   POSEIDON_MDS: none   LOW_DEGREE_INTERPOLATION / HIGH_DEGREE_INTERPOLATION {subgroup_bits <= 4}
+ *   (plonky2/src/gates/{arithmetic_extension,multiplication_extension,reducing,reducing_extension,exponentiation,poseidon_mds,
+ *   low_degree_interpolation,high_degree_interpolation}.rs; pairs of wires are elements of F_p[X]/(X^2 - 7), plonk/vars.rs:122-129)
  * gl_gate_programs_emit builds the programs of a whole gate list in circuit order (gate i has selector index
  * gates[i].selector_index; group_bounds[2 s], group_bounds[2 s + 1] = selectors_info.groups[s], gates/selectors.rs): host arrays
  * in exactly the form GlCircuitDesc / gl_gate_kernel_build take, immediates deduplicated across the list, num_gate_constraints =
@@ -202,7 +206,10 @@ typedef struct GlGateProgram {
 enum GlGateKind {
     GL_GATE_NOOP = 0, GL_GATE_CONSTANT = 1, GL_GATE_PUBLIC_INPUT = 2, GL_GATE_ARITHMETIC = 3, GL_GATE_BASE_SUM = 4,
     GL_GATE_U32_ADD_MANY = 5, GL_GATE_U32_ARITHMETIC = 6, GL_GATE_U32_SUBTRACTION = 7, GL_GATE_U32_RANGE_CHECK = 8,
-    GL_GATE_COMPARISON = 9, GL_GATE_RANDOM_ACCESS = 10, GL_GATE_POSEIDON = 11
+    GL_GATE_COMPARISON = 9, GL_GATE_RANDOM_ACCESS = 10, GL_GATE_POSEIDON = 11,
+    /* the other gates of upstream plonky2 (what standard_recursion_config circuits are made of), extension degree D = 2 */
+    GL_GATE_ARITHMETIC_EXTENSION = 12, GL_GATE_MUL_EXTENSION = 13, GL_GATE_REDUCING = 14, GL_GATE_REDUCING_EXTENSION = 15,
+    GL_GATE_EXPONENTIATION = 16, GL_GATE_POSEIDON_MDS = 17, GL_GATE_LOW_DEGREE_INTERPOLATION = 18, GL_GATE_HIGH_DEGREE_INTERPOLATION = 19
 };
 typedef struct GlGateSpec {
     uint32_t kind;      /* GlGateKind */

@@ -95,6 +95,23 @@ def num_wires(kind, param):
         return (2 + (1 << bits)) * copies + extra + copies * bits
     if kind == "poseidon":
         return 25 + 4 + 12 * 3 + 22 + 12 * 4
+    if kind == "arithmetic_extension":
+        return 4 * D * param
+    if kind == "mul_extension":
+        return 3 * D * param
+    if kind == "reducing":
+        return 3 * D + param + D * (param - 1)
+    if kind == "reducing_extension":
+        return 3 * D + D * param + D * (param - 1)
+    if kind == "exponentiation":
+        return 2 + 2 * param
+    if kind == "poseidon_mds":
+        return 2 * SW * D
+    if kind == "high_degree_interpolation":
+        return 1 + (1 << param) * D + 2 * D + (1 << param) * D
+    if kind == "low_degree_interpolation":
+        np_ = 1 << param
+        return 1 + np_ * D + 2 * D + np_ * D + (np_ - 2) + (np_ - 2) * D
     return {"noop": 0, "constant": param, "public_input": 4, "arithmetic": 4 * (param or 0)}[kind]
 
 
@@ -117,6 +134,16 @@ def num_constraints(kind, param):
         return copies * (bits + 2) + extra
     if kind == "poseidon":
         return 12 * 7 + 22 + 12 + 1 + 4
+    if kind in ("arithmetic_extension", "mul_extension", "reducing", "reducing_extension"):
+        return D * param  # arithmetic_extension.rs:205, multiplication_extension.rs:191, reducing.rs:235, reducing_extension.rs:233
+    if kind == "exponentiation":
+        return param + 1  # exponentiation.rs:258
+    if kind == "poseidon_mds":
+        return SW * D  # poseidon_mds.rs:246
+    if kind == "high_degree_interpolation":
+        return (1 << param) * D + D  # high_degree_interpolation.rs:207-211
+    if kind == "low_degree_interpolation":
+        return (1 << param) * D + D + (D + 1) * ((1 << param) - 2)  # low_degree_interpolation.rs:505-510
     return {"noop": 0, "constant": param, "public_input": 4, "arithmetic": param}[kind]
 
 
@@ -246,7 +273,129 @@ def constraints(kind, param, consts, w, pih, F):
         return out
     if kind == "poseidon":  # gates/poseidon.rs:485-564
         return _poseidon_gate(F, w)
+    A = Algebra(F)
+    if kind == "arithmetic_extension":  # gates/arithmetic_extension.rs:110-147; wires 4*D*i + {0, D, 2D, 3D}
+        for i in range(param):
+            m0, m1, ad, o = (A.get(w, 4 * D * i + D * k) for k in range(4))
+            computed = A.add(A.scalar(A.mul(m0, m1), consts[0]), A.scalar(ad, consts[1]))
+            out += A.sub(o, computed)
+        return out
+    if kind == "mul_extension":  # gates/multiplication_extension.rs:103-137; wires 3*D*i + {0, D, 2D}
+        for i in range(param):
+            m0, m1, o = (A.get(w, 3 * D * i + D * k) for k in range(3))
+            out += A.sub(o, A.scalar(A.mul(m0, m1), consts[0]))
+        return out
+    if kind in ("reducing", "reducing_extension"):  # gates/reducing.rs:160-181, reducing_extension.rs:157-178
+        nc = param
+        ext_coeffs = kind == "reducing_extension"
+        alpha, acc = A.get(w, D), A.get(w, 2 * D)
+        start_coeffs = 3 * D
+        start_accs = start_coeffs + (D * nc if ext_coeffs else nc)
+        for i in range(nc):
+            nxt = A.get(w, 0) if i == nc - 1 else A.get(w, start_accs + D * i)  # the last accumulator is the output
+            coeff = A.get(w, start_coeffs + D * i) if ext_coeffs else A.from_base(w[start_coeffs + i])
+            out += A.sub(A.add(A.mul(acc, alpha), coeff), nxt)
+            acc = nxt
+        return out
+    if kind == "exponentiation":  # gates/exponentiation.rs:266-298
+        n = param
+        base, output = w[0], w[1 + n]
+        bits, inter = [w[1 + i] for i in range(n)], [w[2 + n + i] for i in range(n)]
+        for i in range(n):
+            prev = F.one if i == 0 else F.mul(inter[i - 1], inter[i - 1])
+            cur_bit = bits[n - 1 - i]  # power_bits is in LE order, but we accumulate in BE order
+            computed = F.mul(prev, F.add(F.mul(cur_bit, base), F.sub(F.one, cur_bit)))
+            out.append(F.sub(computed, inter[i]))
+        out.append(F.sub(output, inter[n - 1]))
+        return out
+    if kind == "poseidon_mds":  # gates/poseidon_mds.rs:184-204 with mds_layer_field / mds_layer_algebra (:49-110)
+        inputs = [A.get(w, D * i) for i in range(SW)]
+        for r in range(SW):
+            acc = A.scalar(inputs[r], F.c(_C["POSEIDON_MDS_DIAG"][r]))
+            for i in range(SW):
+                acc = A.add(acc, A.scalar(inputs[(i + r) % SW], F.c(_C["POSEIDON_MDS_CIRC"][i])))
+            out += A.sub(A.get(w, D * (SW + r)), acc)
+        return out
+    if kind in ("high_degree_interpolation", "low_degree_interpolation"):
+        return _interpolation_gate(F, A, kind == "low_degree_interpolation", param, w)
     raise ValueError(kind)
+
+
+D = 2  # the extension degree the gates are instantiated with (GoldilocksField: Extendable<2>)
+
+
+class Algebra:
+    """D = 2 "extension algebra" over F (field/src/extension/algebra.rs): pairs [a0, a1] of F elements meaning a0 + a1 X with
+    X^2 = W. With F = Base this is F_p^2 itself (EvaluationVarsBase::get_local_ext, plonk/vars.rs:122-129); with F = Ext it is
+    ExtensionAlgebra<F_p^2, 2>, what eval_unfiltered uses for the same wires (get_local_ext_algebra)."""
+
+    def __init__(self, F):
+        self.F = F
+        self.W = F.c(W)
+
+    def get(self, w, at):
+        return [w[at], w[at + 1]]
+
+    def from_base(self, x):
+        return [x, self.F.zero]
+
+    def add(self, x, y):
+        return [self.F.add(x[0], y[0]), self.F.add(x[1], y[1])]
+
+    def sub(self, x, y):
+        return [self.F.sub(x[0], y[0]), self.F.sub(x[1], y[1])]
+
+    def mul(self, x, y):
+        F = self.F
+        return [F.add(F.mul(x[0], y[0]), F.mul(self.W, F.mul(x[1], y[1]))), F.add(F.mul(x[0], y[1]), F.mul(x[1], y[0]))]
+
+    def scalar(self, x, k):
+        return [self.F.mul(x[0], k), self.F.mul(x[1], k)]
+
+
+def _interpolation_gate(F, A, low_degree, subgroup_bits, w):
+    """gates/high_degree_interpolation.rs:119-147 and gates/low_degree_interpolation.rs:356-404 (wire layout gates/interpolation.rs:19-76):
+    shift at 0, the values at the 2^bits points from 1, evaluation point, evaluation value, coefficients; the low-degree gate appends the
+    powers of the shift (i = 2..np-1, base wires) and of the evaluation point (i = 2..np-1)."""
+    np_ = 1 << subgroup_bits
+    out = []
+    shift = w[0]
+    start_values, eval_point, eval_value = 1, 1 + np_ * D, 1 + np_ * D + D
+    start_coeffs = eval_value + D
+    end_coeffs = start_coeffs + np_ * D
+    coeffs = [A.get(w, start_coeffs + D * i) for i in range(np_)]
+    g = pyref.root_of_unity(subgroup_bits)
+
+    def eval_at_base(cs, x):  # PolynomialCoeffs<ext>::eval_base: Horner with a base-field point
+        acc = [F.zero, F.zero]
+        for c in reversed(cs):
+            acc = A.add(A.scalar(acc, x), c)
+        return acc
+
+    if not low_degree:
+        for i in range(np_):
+            point = F.mul(F.c(pow(g, i, P)), shift)  # coset(shift) = g^i * shift
+            out += A.sub(A.get(w, start_values + D * i), eval_at_base(coeffs, point))
+        acc = [F.zero, F.zero]  # interpolant.eval(evaluation_point): Horner over the algebra
+        ep = A.get(w, eval_point)
+        for c in reversed(coeffs):
+            acc = A.add(A.mul(acc, ep), c)
+        out += A.sub(A.get(w, eval_value), acc)
+        return out
+    powers_shift = [F.one, shift] + [w[end_coeffs + i - 2] for i in range(2, np_)]
+    for i in range(1, np_ - 1):
+        out.append(F.sub(F.mul(powers_shift[i], shift), powers_shift[i + 1]))
+    altered = [A.scalar(c, p) for c, p in zip(coeffs, powers_shift)]
+    for i in range(np_):
+        out += A.sub(A.get(w, start_values + D * i), eval_at_base(altered, F.c(pow(g, i, P))))
+    epp = [None, A.get(w, eval_point)] + [A.get(w, end_coeffs + np_ - 2 + (i - 2) * D) for i in range(2, np_)]
+    for i in range(1, np_ - 1):
+        out += A.sub(A.mul(epp[i], epp[1]), epp[i + 1])
+    acc = coeffs[0]  # eval_with_powers (field/src/polynomial/mod.rs:169-176): the ORIGINAL coefficients
+    for i in range(1, np_):
+        acc = A.add(acc, A.mul(epp[i], coeffs[i]))
+    out += A.sub(A.get(w, eval_value), acc)
+    return out
 
 
 # ---- Poseidon gate -----------------------------------------------------------------------------
@@ -470,5 +619,72 @@ def fill_row(kind, param, rng, consts, pih):
             rc += 1
         w[SW : 2 * SW] = s
         assert s == expected, "the gate's fast partial rounds must equal the textbook permutation"
+        return w
+    A = Algebra(Base)
+    rext = lambda: [rng.randrange(P), rng.randrange(P)]  # noqa: E731
+    if kind == "arithmetic_extension":  # ArithmeticExtensionGenerator (arithmetic_extension.rs:216-262)
+        w = []
+        for _ in range(param):
+            m0, m1, ad = rext(), rext(), rext()
+            w += m0 + m1 + ad + A.add(A.scalar(A.mul(m0, m1), consts[0]), A.scalar(ad, consts[1]))
+        return w
+    if kind == "mul_extension":  # MulExtensionGenerator (multiplication_extension.rs:202-240)
+        w = []
+        for _ in range(param):
+            m0, m1 = rext(), rext()
+            w += m0 + m1 + A.scalar(A.mul(m0, m1), consts[0])
+        return w
+    if kind in ("reducing", "reducing_extension"):  # ReducingGenerator (reducing.rs:246-300, reducing_extension.rs:243-292)
+        nc = param
+        ext_coeffs = kind == "reducing_extension"
+        alpha, acc = rext(), rext()
+        coeffs = [rext() if ext_coeffs else [rng.randrange(P), 0] for _ in range(nc)]
+        accs = []
+        old = acc
+        for c in coeffs:
+            acc = A.add(A.mul(acc, alpha), c)
+            accs.append(acc)
+        flat_coeffs = [x for c in coeffs for x in (c if ext_coeffs else c[:1])]
+        return accs[-1] + alpha + old + flat_coeffs + [x for a in accs[:-1] for x in a]
+    if kind == "exponentiation":  # ExponentiationGenerator (exponentiation.rs:303-360)
+        n = param
+        base = rng.randrange(P)
+        bits = [rng.randrange(2) for _ in range(n)]
+        inter, cur = [], 1
+        for i in range(n):
+            prev = 1 if i == 0 else inter[i - 1] * inter[i - 1] % P
+            cur = prev * (base if bits[n - 1 - i] else 1) % P
+            inter.append(cur)
+        return [base] + bits + [inter[-1]] + inter
+    if kind == "poseidon_mds":  # PoseidonMdsGenerator (poseidon_mds.rs:253-300)
+        inputs = [rext() for _ in range(SW)]
+        outs = []
+        for r in range(SW):
+            acc = A.scalar(inputs[r], _C["POSEIDON_MDS_DIAG"][r])
+            for i in range(SW):
+                acc = A.add(acc, A.scalar(inputs[(i + r) % SW], _C["POSEIDON_MDS_CIRC"][i]))
+            outs.append(acc)
+        return [x for e in inputs + outs for x in e]
+    if kind in ("high_degree_interpolation", "low_degree_interpolation"):  # InterpolationGenerator (both files)
+        np_ = 1 << param
+        g = pyref.root_of_unity(param)
+        shift = rng.randrange(1, P)
+        coeffs = [rext() for _ in range(np_)]
+
+        def ev(x):  # x in the algebra
+            acc = [0, 0]
+            for c in reversed(coeffs):
+                acc = A.add(A.mul(acc, x), c)
+            return acc
+
+        values = [ev([shift * pow(g, i, P) % P, 0]) for i in range(np_)]
+        ep = rext()
+        w = [shift] + [x for v in values for x in v] + ep + ev(ep) + [x for c in coeffs for x in c]
+        if kind == "low_degree_interpolation":
+            w += [pow(shift, i, P) for i in range(2, np_)]
+            pw = ep
+            for _ in range(2, np_):
+                pw = A.mul(pw, ep)
+                w += pw
         return w
     raise ValueError(kind)

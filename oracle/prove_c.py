@@ -109,7 +109,7 @@ class Circuit:
     its "constants_sigmas" / "circuit_digest" entries are not needed (pass derive_digest=False to take the dict's digest)."""
 
     def __init__(self, circuit, threads=None, derive_digest=True):
-        self.threads = threads or o.hardware_threads()
+        self.threads = threads or o.usable_threads()  # the CPUs the container's quota grants, not the host's hardware threads
         fp = circuit["fri_params"]
         d = CircuitDesc()
         for k in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges", "quotient_degree_factor", "num_gate_constraints"):

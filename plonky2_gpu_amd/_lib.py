@@ -69,7 +69,9 @@ class GlGatePrograms(ctypes.Structure):
 
 # include/plonky2_hip.h enum GlGateKind, by the names plonky2_gpu_amd/gate_program.py uses
 GATE_KINDS = {"noop": 0, "constant": 1, "public_input": 2, "arithmetic": 3, "base_sum": 4, "u32_add_many": 5, "u32_arithmetic": 6,
-              "u32_subtraction": 7, "u32_range_check": 8, "comparison": 9, "random_access": 10, "poseidon": 11}
+              "u32_subtraction": 7, "u32_range_check": 8, "comparison": 9, "random_access": 10, "poseidon": 11,
+              "arithmetic_extension": 12, "mul_extension": 13, "reducing": 14, "reducing_extension": 15, "exponentiation": 16,
+              "poseidon_mds": 17, "low_degree_interpolation": 18, "high_degree_interpolation": 19}
 
 
 class GlFriParams(ctypes.Structure):

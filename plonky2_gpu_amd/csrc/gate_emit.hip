@@ -3,11 +3,15 @@
 // The device evaluates evaluate_gate_constraints_base_batch (plonky2/src/plonk/vanishing_poly.rs:267-306) for any circuit from
 // one register program per gate (include/plonky2_hip.h, GlGateInstr). Until round 3 the only producer of such programs was
 // the Python host (plonky2_gpu_amd/gate_program.py): a Rust or C++ host could prove exactly one circuit, the compiled-in
-// ed25519 table. gl_gate_programs_emit builds the programs of a gate list natively, for the twelve gate kinds of that list —
-// what a Rust host would otherwise have to port from each gate's eval_unfiltered_base_one:
+// ed25519 table. gl_gate_programs_emit builds the programs of a gate list natively, for the twelve gate kinds of that list and
+// (round 5) the eight other gates of upstream plonky2 — what a Rust host would otherwise have to port from each gate's
+// eval_unfiltered_base_one:
 //   Noop, Constant, PublicInput, Arithmetic        plonky2/src/gates/{noop,constant,public_input,arithmetic_base}.rs
 //   BaseSum<B>, RandomAccess, Poseidon             plonky2/src/gates/{base_sum,random_access,poseidon}.rs
 //   U32AddMany, U32Arithmetic, U32Subtraction, U32RangeCheck, Comparison        u32/src/gates/*.rs
+//   ArithmeticExtension, MulExtension, Reducing, ReducingExtension, Exponentiation, PoseidonMds, Low/HighDegreeInterpolation
+//                                                  plonky2/src/gates/{arithmetic_extension,multiplication_extension,reducing,
+//                                                  reducing_extension,exponentiation,poseidon_mds,low_degree_interpolation,high_degree_interpolation}.rs
 // The output is identical, instruction for instruction and immediate for immediate, to gate_program.py's
 // (tests/test_gate_emit.py), which the oracle's gate restatements check (tests/test_gate_programs_cpu.py).
 #include <stdint.h>
@@ -617,6 +621,246 @@ Program poseidon_gate(ImmediatePool &pool) {
     return g.instrs;
 }
 
+// ---- the gates of upstream plonky2 beyond the ed25519 list (round 5) -------------------------------------------------------------------
+// Extension-field gates see pairs of wires as elements of F_p[X]/(X^2 - 7) (EvaluationVarsBase::get_local_ext, plonk/vars.rs:122-129;
+// field/src/extension/quadratic.rs:173-185). A pair = (register of c0, register of c1). Every helper allocates its registers in the
+// same order as its twin in gate_program.py: the two emitters must agree instruction for instruction.
+struct Ext {
+    int c0, c1;
+    int operator[](int k) const { return k ? c1 : c0; }
+};
+Ext ext_wire(GateAsm &g, unsigned at) {
+    const int a = g.wire((int)at);
+    const int b = g.wire((int)at + 1);
+    return Ext{a, b};
+}
+// (x0 + x1 X)(y0 + y1 X): c0 = x0 y0 + 7 x1 y1 through an accumulator (weights 1 and 7, one fold), c1 = x0 y1 + x1 y0
+Ext ext_mul(GateAsm &g, Ext x, Ext y) {
+    const int t00 = g.mul(x.c0, y.c0);
+    const int t11 = g.mul(x.c1, y.c1);
+    const int c0 = g.weighted_sum({{t00, 1}, {t11, 7}});
+    g.free({t00, t11});
+    const int t01 = g.mul(x.c0, y.c1);
+    const int t10 = g.mul(x.c1, y.c0);
+    const int c1 = g.add(t01, t10, t01);
+    g.free1(t10);
+    return Ext{c0, c1};
+}
+void ext_free(GateAsm &g, Ext x) { g.free({x.c0, x.c1}); }
+// emit a - b component by component (to_basefield_array); `a` is overwritten
+void ext_emit_diff(GateAsm &g, Ext a, Ext b) {
+    g.emit(g.sub(a.c0, b.c0, a.c0));
+    g.emit(g.sub(a.c1, b.c1, a.c1));
+}
+
+// ArithmeticExtensionGate { num_ops } (plonky2/src/gates/arithmetic_extension.rs:129-147)
+Program arithmetic_extension_gate(unsigned num_ops, ImmediatePool &pool) {
+    GateAsm g(&pool);
+    for (unsigned i = 0; i < num_ops; i++) {
+        g.release();
+        const int c0 = g.constant(0), c1 = g.constant(1);
+        const Ext m0 = ext_wire(g, 8 * i), m1 = ext_wire(g, 8 * i + 2), ad = ext_wire(g, 8 * i + 4), out = ext_wire(g, 8 * i + 6);
+        const Ext m = ext_mul(g, m0, m1);
+        for (int k = 0; k < 2; k++) {  // computed = m * c0 + addend * c1
+            g.mul(m[k], c0, m[k]);
+            g.mul(ad[k], c1, ad[k]);
+            g.add(m[k], ad[k], m[k]);
+        }
+        ext_emit_diff(g, out, m);
+    }
+    return g.instrs;
+}
+
+// MulExtensionGate { num_ops } (plonky2/src/gates/multiplication_extension.rs:122-137)
+Program mul_extension_gate(unsigned num_ops, ImmediatePool &pool) {
+    GateAsm g(&pool);
+    for (unsigned i = 0; i < num_ops; i++) {
+        g.release();
+        const int c0 = g.constant(0);
+        const Ext m0 = ext_wire(g, 6 * i), m1 = ext_wire(g, 6 * i + 2), out = ext_wire(g, 6 * i + 4);
+        const Ext m = ext_mul(g, m0, m1);
+        for (int k = 0; k < 2; k++) g.mul(m[k], c0, m[k]);
+        ext_emit_diff(g, out, m);
+    }
+    return g.instrs;
+}
+
+// ReducingGate { num_coeffs } (plonky2/src/gates/reducing.rs:160-181) and, with extension_coeffs, ReducingExtensionGate
+// (reducing_extension.rs:157-178): acc_i = acc_{i-1} * alpha + coeff_i, the last accumulator being the output wires
+Program reducing_gate(unsigned num_coeffs, ImmediatePool &pool, bool extension_coeffs) {
+    GateAsm g(&pool);
+    const unsigned d = 2, start_coeffs = 3 * d, start_accs = start_coeffs + (extension_coeffs ? d * num_coeffs : num_coeffs);
+    const Ext alpha = ext_wire(g, d);
+    Ext acc = ext_wire(g, 2 * d);
+    for (unsigned i = 0; i < num_coeffs; i++) {
+        const Ext t = ext_mul(g, acc, alpha);
+        ext_free(g, acc);
+        if (extension_coeffs) {
+            const Ext c = ext_wire(g, start_coeffs + d * i);
+            g.add(t.c0, c.c0, t.c0);
+            g.add(t.c1, c.c1, t.c1);
+            ext_free(g, c);
+        } else {
+            const int c = g.wire((int)(start_coeffs + i));
+            g.add(t.c0, c, t.c0);
+            g.free1(c);
+        }
+        const Ext nxt = ext_wire(g, i == num_coeffs - 1 ? 0 : start_accs + d * i);
+        ext_emit_diff(g, t, nxt);
+        ext_free(g, t);
+        acc = nxt;
+    }
+    return g.instrs;
+}
+
+// ExponentiationGate { num_power_bits } (plonky2/src/gates/exponentiation.rs:266-298)
+Program exponentiation_gate(unsigned n, ImmediatePool &pool) {
+    GateAsm g(&pool);
+    const int one = g.imm(1);
+    const int base = g.wire(0);
+    int prev = -1;
+    for (unsigned i = 0; i < n; i++) {
+        const int cur_bit = g.wire((int)(1 + (n - 1 - i)));  // power bits are little-endian, accumulated big-endian
+        const int t = g.mul(cur_bit, base);
+        g.add(t, one, t);
+        g.sub(t, cur_bit, t);  // cur_bit * base + (1 - cur_bit)
+        g.free1(cur_bit);
+        if (prev >= 0) {
+            g.mul(prev, prev, prev);
+            g.mul(prev, t, t);
+            g.free1(prev);
+        }
+        const int inter = g.wire((int)(2 + n + i));
+        g.emit(g.sub(t, inter, t));
+        g.free1(t);
+        prev = inter;
+    }
+    const int out = g.wire((int)(1 + n));
+    g.emit(g.sub(out, prev, out));
+    return g.instrs;
+}
+
+// PoseidonMdsGate (plonky2/src/gates/poseidon_mds.rs:184-204): outputs = mds_layer_field(inputs) over F_p^2 — every component a sum of
+// thirteen small multiples, one accumulator fold each
+Program poseidon_mds_gate(ImmediatePool &pool) {
+    GateAsm g(&pool);
+    constexpr int SW = 12;
+    Ext ins[SW];
+    for (int i = 0; i < SW; i++) ins[i] = ext_wire(g, 2 * i);
+    for (int r = 0; r < SW; r++)
+        for (int k = 0; k < 2; k++) {
+            std::vector<std::pair<int, uint64_t>> terms;
+            for (int i = 0; i < SW; i++) terms.push_back({ins[(i + r) % SW][k], POSEIDON_MDS_CIRC[i]});
+            if (POSEIDON_MDS_DIAG[r]) terms.push_back({ins[r][k], POSEIDON_MDS_DIAG[r]});
+            const int computed = g.weighted_sum(terms);
+            const int out = g.wire(2 * (SW + r) + k);
+            g.emit(g.sub(out, computed, out));
+            g.free({out, computed});
+        }
+    return g.instrs;
+}
+
+uint64_t mulmod(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % P); }
+uint64_t root_of_unity(unsigned bits) {  // F::primitive_root_of_unity (field/src/types.rs:268-272)
+    uint64_t r = 1753635133440165772ull;
+    for (unsigned i = bits; i < 32; i++) r = mulmod(r, r);
+    return r;
+}
+
+// HighDegreeInterpolationGate (plonky2/src/gates/high_degree_interpolation.rs:119-147) / LowDegreeInterpolationGate
+// (low_degree_interpolation.rs:356-404); wire layout gates/interpolation.rs:19-76
+Program interpolation_gate(unsigned subgroup_bits, ImmediatePool &pool, bool low_degree) {
+    GateAsm g(&pool);
+    const unsigned d = 2, np = 1u << subgroup_bits;
+    const unsigned start_values = 1, eval_point = 1 + np * d, eval_value = eval_point + d, start_coeffs = eval_value + d, end_coeffs = start_coeffs + np * d;
+    const uint64_t w = root_of_unity(subgroup_bits);
+    const int shift = g.wire(0);
+    // Horner with a base-field point in register x: acc = acc * x + c, component-wise; returns a fresh pair
+    auto eval_base = [&](const std::vector<Ext> &cs, int x) {
+        const int z = g.imm(0);
+        const int a0 = g.add(cs.back().c0, z);
+        const int a1 = g.add(cs.back().c1, z);  // copies of the leading coefficient (ADD with a zero immediate)
+        g.free1(z);
+        const Ext acc{a0, a1};
+        for (size_t i = cs.size() - 1; i-- > 0;)
+            for (int k = 0; k < 2; k++) {
+                g.mul(acc[k], x, acc[k]);
+                g.add(acc[k], cs[i][k], acc[k]);
+            }
+        return acc;
+    };
+    std::vector<Ext> coeffs;
+    for (unsigned i = 0; i < np; i++) coeffs.push_back(ext_wire(g, start_coeffs + d * i));
+    if (low_degree) {
+        // powers of the shift: wire i (i = 2..np-1) must be shift^(i-1) * shift; coefficient i is altered by shift^i on the way
+        int prev = shift;
+        for (unsigned i = 1; i < np; i++) {
+            for (int k = 0; k < 2; k++) g.mul(coeffs[i][k], prev, coeffs[i][k]);
+            if (i < np - 1) {
+                const int nxt = g.wire((int)(end_coeffs + i - 1));
+                const int t = g.mul(prev, shift);
+                g.emit(g.sub(t, nxt, t));
+                g.free1(t);
+                if (prev != shift) g.free1(prev);
+                prev = nxt;
+            }
+        }
+        if (prev != shift) g.free1(prev);
+    }
+    uint64_t wi = 1;
+    for (unsigned i = 0; i < np; i++) {
+        const int x = g.imm(wi);
+        wi = mulmod(wi, w);
+        if (!low_degree) g.mul(x, shift, x);  // coset(shift) = g^i * shift
+        const Ext computed = eval_base(coeffs, x);
+        g.free1(x);
+        const Ext value = ext_wire(g, start_values + d * i);
+        ext_emit_diff(g, value, computed);
+        ext_free(g, value);
+        ext_free(g, computed);
+    }
+    const Ext ep = ext_wire(g, eval_point);
+    Ext acc;
+    if (low_degree) {
+        for (const Ext &c : coeffs) ext_free(g, c);
+        Ext prev = ep;
+        bool prev_is_ep = true;
+        for (unsigned i = 1; i < np - 1; i++) {  // powers of the evaluation point: wire pair i+1 must be (pair i) * point
+            const Ext nxt = ext_wire(g, end_coeffs + np - 2 + (i - 1) * d);
+            const Ext t = ext_mul(g, prev, ep);
+            ext_emit_diff(g, t, nxt);
+            ext_free(g, t);
+            if (!prev_is_ep) ext_free(g, prev);
+            prev = nxt;
+            prev_is_ep = false;
+        }
+        if (!prev_is_ep) ext_free(g, prev);
+        acc = ext_wire(g, start_coeffs);  // eval_with_powers uses the ORIGINAL coefficients: c_0 + sum c_i * point^i
+        for (unsigned i = 1; i < np; i++) {
+            const Ext pw = i == 1 ? ep : ext_wire(g, end_coeffs + np - 2 + (i - 2) * d);
+            const Ext c = ext_wire(g, start_coeffs + d * i);
+            const Ext t = ext_mul(g, pw, c);
+            g.add(acc.c0, t.c0, acc.c0);
+            g.add(acc.c1, t.c1, acc.c1);
+            ext_free(g, t);
+            ext_free(g, c);
+            if (i != 1) ext_free(g, pw);
+        }
+    } else {
+        acc = coeffs.back();  // interpolant.eval(point): Horner over the extension
+        for (size_t i = coeffs.size() - 1; i-- > 0;) {
+            const Ext t = ext_mul(g, acc, ep);
+            g.add(t.c0, coeffs[i].c0, t.c0);
+            g.add(t.c1, coeffs[i].c1, t.c1);
+            ext_free(g, acc);
+            acc = t;
+        }
+    }
+    const Ext value = ext_wire(g, eval_value);
+    ext_emit_diff(g, value, acc);
+    return g.instrs;
+}
+
 // Sane parameter ranges per kind, checked BEFORE anything is emitted or allocated: every wire / constant index of the program must
 // fit the 16-bit instruction fields (GateAsm::field throws as the backstop) and nothing may grow without limit. The largest real
 // gates are far inside (ed25519: arithmetic 20 ops, base_sum 63 limbs, u32_add_many 16 addends x 4 ops, random_access 4 bits).
@@ -639,6 +883,13 @@ void check_params(const GlGateSpec &s) {
             need(p[1] >= 1 && p[1] <= 256, "num_copies must be in 1..256");
             need(p[2] <= 256, "num_extra_constants must be at most 256");
             break;
+        case GL_GATE_ARITHMETIC_EXTENSION:
+        case GL_GATE_MUL_EXTENSION: need(p[0] >= 1 && p[0] <= 2048, "num_ops must be in 1..2048"); break;
+        case GL_GATE_REDUCING:
+        case GL_GATE_REDUCING_EXTENSION: need(p[0] >= 1 && p[0] <= 4096, "num_coeffs must be in 1..4096"); break;
+        case GL_GATE_EXPONENTIATION: need(p[0] >= 1 && p[0] <= 4096, "num_power_bits must be in 1..4096"); break;
+        case GL_GATE_LOW_DEGREE_INTERPOLATION:
+        case GL_GATE_HIGH_DEGREE_INTERPOLATION: need(p[0] >= 1 && p[0] <= 4, "subgroup_bits must be in 1..4"); break;
         default: break;
     }
 }
@@ -659,6 +910,14 @@ Program build_gate(const GlGateSpec &s, ImmediatePool &pool) {
         case GL_GATE_COMPARISON: return comparison_gate(p[0], p[1], pool);
         case GL_GATE_RANDOM_ACCESS: return random_access_gate(p[0], p[1], p[2], pool);
         case GL_GATE_POSEIDON: return poseidon_gate(pool);
+        case GL_GATE_ARITHMETIC_EXTENSION: return arithmetic_extension_gate(p[0], pool);
+        case GL_GATE_MUL_EXTENSION: return mul_extension_gate(p[0], pool);
+        case GL_GATE_REDUCING: return reducing_gate(p[0], pool, false);
+        case GL_GATE_REDUCING_EXTENSION: return reducing_gate(p[0], pool, true);
+        case GL_GATE_EXPONENTIATION: return exponentiation_gate(p[0], pool);
+        case GL_GATE_POSEIDON_MDS: return poseidon_mds_gate(pool);
+        case GL_GATE_LOW_DEGREE_INTERPOLATION: return interpolation_gate(p[0], pool, true);
+        case GL_GATE_HIGH_DEGREE_INTERPOLATION: return interpolation_gate(p[0], pool, false);
         default: throw std::runtime_error("no register-program emitter for gate kind " + std::to_string(s.kind));
     }
 }

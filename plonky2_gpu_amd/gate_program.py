@@ -572,8 +572,237 @@ def poseidon_gate(pool):
     return g.instrs
 
 
+# ---- the gates of upstream plonky2 beyond the ed25519 list (round 5) -------------------------------------------------------------
+# Extension-field gates see pairs of wires as elements of F_p[X]/(X^2 - 7) (EvaluationVarsBase::get_local_ext, plonk/vars.rs:122-129;
+# field/src/extension/quadratic.rs:173-185). A pair is a Python tuple (register of c0, register of c1).
+EXT_W = 7
+
+
+def _ext_wire(g, at):
+    return (g.wire(at), g.wire(at + 1))
+
+
+def _ext_mul(g, x, y):
+    """(x0 + x1 X)(y0 + y1 X): c0 = x0 y0 + 7 x1 y1 through an accumulator (weights 1 and 7, one fold), c1 = x0 y1 + x1 y0"""
+    t00, t11 = g.mul(x[0], y[0]), g.mul(x[1], y[1])
+    c0 = g.weighted_sum([(t00, 1), (t11, EXT_W)])
+    g.free(t00, t11)
+    t01, t10 = g.mul(x[0], y[1]), g.mul(x[1], y[0])
+    c1 = g.add(t01, t10, dst=t01)
+    g.free(t10)
+    return (c0, c1)
+
+
+def _ext_free(g, *pairs):
+    for x in pairs:
+        g.free(x[0], x[1])
+
+
+def _ext_emit_diff(g, a, b):
+    """emit a - b component by component (to_basefield_array); `a` is overwritten"""
+    g.emit(g.sub(a[0], b[0], dst=a[0]))
+    g.emit(g.sub(a[1], b[1], dst=a[1]))
+
+
+def arithmetic_extension_gate(num_ops, pool):
+    """ArithmeticExtensionGate { num_ops } (plonky2/src/gates/arithmetic_extension.rs:129-147)"""
+    g = GateAsm(pool)
+    for i in range(num_ops):
+        g.release()
+        c0, c1 = g.const(0), g.const(1)
+        m0, m1, ad, out = (_ext_wire(g, 8 * i + 2 * k) for k in range(4))
+        m = _ext_mul(g, m0, m1)
+        for k in (0, 1):  # computed = m * c0 + addend * c1
+            g.mul(m[k], c0, dst=m[k])
+            g.mul(ad[k], c1, dst=ad[k])
+            g.add(m[k], ad[k], dst=m[k])
+        _ext_emit_diff(g, out, m)
+    return g.instrs
+
+
+def mul_extension_gate(num_ops, pool):
+    """MulExtensionGate { num_ops } (plonky2/src/gates/multiplication_extension.rs:122-137)"""
+    g = GateAsm(pool)
+    for i in range(num_ops):
+        g.release()
+        c0 = g.const(0)
+        m0, m1, out = (_ext_wire(g, 6 * i + 2 * k) for k in range(3))
+        m = _ext_mul(g, m0, m1)
+        for k in (0, 1):
+            g.mul(m[k], c0, dst=m[k])
+        _ext_emit_diff(g, out, m)
+    return g.instrs
+
+
+def reducing_gate(num_coeffs, pool, extension_coeffs=False):
+    """ReducingGate { num_coeffs } (plonky2/src/gates/reducing.rs:160-181) and, with extension_coeffs, ReducingExtensionGate
+    (reducing_extension.rs:157-178): acc_i = acc_{i-1} * alpha + coeff_i, the last accumulator being the output wires."""
+    g = GateAsm(pool)
+    d = 2
+    start_coeffs = 3 * d
+    start_accs = start_coeffs + (d * num_coeffs if extension_coeffs else num_coeffs)
+    alpha = _ext_wire(g, d)
+    acc = _ext_wire(g, 2 * d)
+    for i in range(num_coeffs):
+        t = _ext_mul(g, acc, alpha)
+        _ext_free(g, acc)
+        if extension_coeffs:
+            c = _ext_wire(g, start_coeffs + d * i)
+            g.add(t[0], c[0], dst=t[0])
+            g.add(t[1], c[1], dst=t[1])
+            _ext_free(g, c)
+        else:
+            c = g.wire(start_coeffs + i)
+            g.add(t[0], c, dst=t[0])
+            g.free(c)
+        nxt = _ext_wire(g, 0 if i == num_coeffs - 1 else start_accs + d * i)
+        _ext_emit_diff(g, t, nxt)
+        _ext_free(g, t)
+        acc = nxt
+    return g.instrs
+
+
+def exponentiation_gate(num_power_bits, pool):
+    """ExponentiationGate { num_power_bits } (plonky2/src/gates/exponentiation.rs:266-298)"""
+    g = GateAsm(pool)
+    n = num_power_bits
+    one = g.imm(1)
+    base = g.wire(0)
+    prev = None
+    for i in range(n):
+        cur_bit = g.wire(1 + (n - 1 - i))  # power bits are little-endian, accumulated big-endian
+        t = g.mul(cur_bit, base)
+        g.add(t, one, dst=t)
+        g.sub(t, cur_bit, dst=t)  # cur_bit * base + (1 - cur_bit)
+        g.free(cur_bit)
+        if prev is not None:
+            g.mul(prev, prev, dst=prev)
+            g.mul(prev, t, dst=t)
+            g.free(prev)
+        inter = g.wire(2 + n + i)
+        g.emit(g.sub(t, inter, dst=t))
+        g.free(t)
+        prev = inter
+    out = g.wire(1 + n)
+    g.emit(g.sub(out, prev, dst=out))
+    return g.instrs
+
+
+def poseidon_mds_gate(pool):
+    """PoseidonMdsGate (plonky2/src/gates/poseidon_mds.rs:184-204): outputs = mds_layer_field(inputs) over F_p^2 — every component a sum
+    of thirteen small multiples, i.e. one accumulator fold each"""
+    from .poseidon_tables import TABLES as T
+
+    g = GateAsm(pool)
+    SW = 12
+    ins = [_ext_wire(g, 2 * i) for i in range(SW)]
+    for r in range(SW):
+        for k in (0, 1):
+            terms = [(ins[(i + r) % SW][k], T["MDS_CIRC"][i]) for i in range(SW)]
+            if T["MDS_DIAG"][r]:
+                terms.append((ins[r][k], T["MDS_DIAG"][r]))
+            computed = g.weighted_sum(terms)
+            out = g.wire(2 * (SW + r) + k)
+            g.emit(g.sub(out, computed, dst=out))
+            g.free(out, computed)
+    return g.instrs
+
+
+def _root_of_unity(bits):
+    return pow(1753635133440165772, 1 << (32 - bits), P)  # F::primitive_root_of_unity (field/src/types.rs:268-272)
+
+
+def interpolation_gate(subgroup_bits, pool, low_degree):
+    """HighDegreeInterpolationGate (plonky2/src/gates/high_degree_interpolation.rs:119-147) / LowDegreeInterpolationGate
+    (low_degree_interpolation.rs:356-404); wire layout gates/interpolation.rs:19-76."""
+    g = GateAsm(pool)
+    d, np_ = 2, 1 << subgroup_bits
+    if np_ > 16:
+        raise ValueError("interpolation gates with more than 16 points are not supported by this emitter")
+    start_values, eval_point, eval_value = 1, 1 + np_ * d, 1 + np_ * d + d
+    start_coeffs = eval_value + d
+    end_coeffs = start_coeffs + np_ * d
+    w = _root_of_unity(subgroup_bits)
+    shift = g.wire(0)
+
+    def eval_base(cs, x):
+        """Horner with a base-field point in register x: acc = acc * x + c, component-wise; returns a fresh pair"""
+        z = g.imm(0)
+        acc = (g.add(cs[-1][0], z), g.add(cs[-1][1], z))  # copies of the leading coefficient (ADD with a zero immediate)
+        g.free(z)
+        for c in reversed(cs[:-1]):
+            for k in (0, 1):
+                g.mul(acc[k], x, dst=acc[k])
+                g.add(acc[k], c[k], dst=acc[k])
+        return acc
+
+    coeffs = [_ext_wire(g, start_coeffs + d * i) for i in range(np_)]
+    if low_degree:
+        # powers of the shift: wire i (i = 2..np-1) must be shift^(i-1) * shift; coefficient i is altered by shift^i on the way, so that
+        # at most two powers are live at a time (altered_coeffs[i] = c_i * shift^i, then altered(w^i) = original(shift * w^i))
+        prev = shift
+        for i in range(1, np_):
+            for k in (0, 1):
+                g.mul(coeffs[i][k], prev, dst=coeffs[i][k])
+            if i < np_ - 1:
+                nxt = g.wire(end_coeffs + i - 1)
+                t = g.mul(prev, shift)
+                g.emit(g.sub(t, nxt, dst=t))
+                g.free(t)
+                if prev != shift:
+                    g.free(prev)
+                prev = nxt
+        if prev != shift:
+            g.free(prev)
+    for i in range(np_):
+        x = g.imm(pow(w, i, P))
+        if not low_degree:
+            g.mul(x, shift, dst=x)  # coset(shift) = g^i * shift
+        computed = eval_base(coeffs, x)
+        g.free(x)
+        value = _ext_wire(g, start_values + d * i)
+        _ext_emit_diff(g, value, computed)
+        _ext_free(g, value, computed)
+    ep = _ext_wire(g, eval_point)
+    if low_degree:
+        _ext_free(g, *coeffs)
+        prev = ep
+        for i in range(1, np_ - 1):  # powers of the evaluation point: wire pair i+1 must be (pair i) * point
+            nxt = _ext_wire(g, end_coeffs + np_ - 2 + (i - 1) * d)
+            t = _ext_mul(g, prev, ep)
+            _ext_emit_diff(g, t, nxt)
+            _ext_free(g, t)
+            if prev is not ep:
+                _ext_free(g, prev)
+            prev = nxt
+        if prev is not ep:
+            _ext_free(g, prev)
+        acc = _ext_wire(g, start_coeffs)  # eval_with_powers uses the ORIGINAL coefficients: c_0 + sum c_i * point^i
+        for i in range(1, np_):
+            pw = ep if i == 1 else _ext_wire(g, end_coeffs + np_ - 2 + (i - 2) * d)
+            c = _ext_wire(g, start_coeffs + d * i)
+            t = _ext_mul(g, pw, c)
+            g.add(acc[0], t[0], dst=acc[0])
+            g.add(acc[1], t[1], dst=acc[1])
+            _ext_free(g, t, c)
+            if pw is not ep:
+                _ext_free(g, pw)
+    else:
+        acc = coeffs[-1]  # interpolant.eval(point): Horner over the extension
+        for c in reversed(coeffs[:-1]):
+            t = _ext_mul(g, acc, ep)
+            g.add(t[0], c[0], dst=t[0])
+            g.add(t[1], c[1], dst=t[1])
+            _ext_free(g, acc)
+            acc = t
+    value = _ext_wire(g, eval_value)
+    _ext_emit_diff(g, value, acc)
+    return g.instrs
+
+
 def build_gate(kind, param, pool):
-    """(kind, param) -> instruction list; the kinds of the ed25519 gate list"""
+    """(kind, param) -> instruction list; the kinds of the ed25519 gate list and, since round 5, the other gates of
+    upstream plonky2 that standard_recursion_config circuits are made of"""
     if kind == "noop":
         return noop_gate()
     if kind == "constant":
@@ -598,6 +827,22 @@ def build_gate(kind, param, pool):
         return random_access_gate(param[0], param[1], param[2], pool)
     if kind == "poseidon":
         return poseidon_gate(pool)
+    if kind == "arithmetic_extension":
+        return arithmetic_extension_gate(param, pool)
+    if kind == "mul_extension":
+        return mul_extension_gate(param, pool)
+    if kind == "reducing":
+        return reducing_gate(param, pool)
+    if kind == "reducing_extension":
+        return reducing_gate(param, pool, extension_coeffs=True)
+    if kind == "exponentiation":
+        return exponentiation_gate(param, pool)
+    if kind == "poseidon_mds":
+        return poseidon_mds_gate(pool)
+    if kind == "low_degree_interpolation":
+        return interpolation_gate(param, pool, low_degree=True)
+    if kind == "high_degree_interpolation":
+        return interpolation_gate(param, pool, low_degree=False)
     raise ValueError(f"no register-program emitter for gate kind {kind!r}")
 
 

@@ -146,12 +146,35 @@ FULL_GROUPS = [(0, 5), (5, 9), (9, 12), (12, 13)]
 FULL_SELECTOR_INDICES = [0] * 5 + [1] * 4 + [2] * 3 + [3]
 
 
-def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap_height=1, pow_bits=3, num_queries=2):
+# The gates a standard_recursion_config circuit (plonk/circuit_data.rs:60-90: 135 wires, 80 routed) is made of — the eight kinds of upstream
+# plonky2 beyond the ed25519 list at the parameters that config gives them (new_from_config of each gate file), with the basic ones, sorted
+# and grouped the way the builder does (by degree; degree(gate) + |group| <= quotient_degree_factor + 1 = 9, gates/selectors.rs:40-110):
+# degrees 0 1 1 1 2 2 | 2 2 3 3 3 | 4 4 5 | 7.
+RECURSION_GATES = [("noop", None), ("constant", 2), ("public_input", None), ("poseidon_mds", None), ("reducing", 43), ("reducing_extension", 32),
+                   ("low_degree_interpolation", 4), ("base_sum", (2, 63)), ("arithmetic", 20), ("arithmetic_extension", 10), ("mul_extension", 13),
+                   ("exponentiation", 66), ("high_degree_interpolation", 2), ("random_access", (4, 4, 2)), ("poseidon", None)]
+RECURSION_GROUPS = [(0, 6), (6, 11), (11, 14), (14, 15)]
+RECURSION_SELECTOR_INDICES = [0] * 6 + [1] * 5 + [2] * 3 + [3]
+
+
+def make_recursion_circuit(degree_bits=4, seed=1, **kwargs):
+    """A circuit of standard_recursion_config's shape whose rows use the gates such circuits are made of (RECURSION_GATES),
+    each row honestly generated by the gate's own witness generator (oracle/gates_ref.fill_row)."""
+    return make_full_circuit(degree_bits, seed, gates=RECURSION_GATES, groups=RECURSION_GROUPS, selector_indices=RECURSION_SELECTOR_INDICES, **kwargs)
+
+
+def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap_height=1, pow_bits=3, num_queries=2,
+                      gates=None, groups=None, selector_indices=None):
     """Every gate kind of the ed25519 gate list (small parameters) in one circuit of
     the standard shape (135 wires, 80 routed): each row is one honestly generated gate row
     (oracle/gates_ref.fill_row), copy constraints tie random pairs of arithmetic inputs. The selector
-    groups respect degree(gate) + |group| <= 9 like the reference's grouping (gates/selectors.rs)."""
+    groups respect degree(gate) + |group| <= 9 like the reference's grouping (gates/selectors.rs).
+    With gates / groups / selector_indices: the same construction over another gate list (make_recursion_circuit)."""
     from oracle import gates_ref, prove_ref
+
+    FULL_GATES, FULL_GROUPS, FULL_SELECTOR_INDICES = gates or globals()["FULL_GATES"], groups or globals()["FULL_GROUPS"], selector_indices or globals()["FULL_SELECTOR_INDICES"]
+    pub_row, arith_row = FULL_GATES.index(("public_input", None)), next(i for i, (k, _) in enumerate(FULL_GATES) if k == "arithmetic")
+    arith_ops = FULL_GATES[arith_row][1]
 
     rng = random.Random(seed * 104729)
     n = 1 << degree_bits
@@ -160,11 +183,11 @@ def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap
     public_inputs = [rng.randrange(P) for _ in range(3)]
     pih = pyref.hash_no_pad(public_inputs)
     row_gate = [rng.randrange(len(FULL_GATES)) for _ in range(n)]
-    row_gate[0] = 2
+    row_gate[0] = pub_row
     for k in range(len(FULL_GATES)):  # every gate at least once
-        if k != 2:
-            row_gate[1 + k % (n - 1)] = k if k != 2 else row_gate[1 + k % (n - 1)]
-    row_gate = [g if (g != 2 or r == 0) else 0 for r, g in enumerate(row_gate)]
+        if k != pub_row:
+            row_gate[1 + k % (n - 1)] = k
+    row_gate = [g if (g != pub_row or r == 0) else 0 for r, g in enumerate(row_gate)]
     consts = [[rng.randrange(P) for _ in range(n)] for _ in range(2)]
     sel = [[(row_gate[r] if FULL_SELECTOR_INDICES[row_gate[r]] == g else 0xFFFFFFFF) for r in range(n)] for g in range(num_selectors)]
     wires = [[rng.randrange(P) for _ in range(n)] for _ in range(num_wires)]
@@ -172,9 +195,9 @@ def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap
     w = pyref.root_of_unity(degree_bits)
     subgroup = [pow(w, i, P) for i in range(n)]
     sigma = {(r, j): (r, j) for j in range(num_routed) for r in range(n)}
-    # copy constraints between inputs of arithmetic rows (gate index 4), set before the rows are generated
-    arith_rows = [r for r in range(n) if row_gate[r] == 4]
-    inputs = [(r, 4 * i + k) for r in arith_rows for i in range(3) for k in range(3)]
+    # copy constraints between inputs of arithmetic rows, set before the rows are generated
+    arith_rows = [r for r in range(n) if row_gate[r] == arith_row]
+    inputs = [(r, 4 * i + k) for r in arith_rows for i in range(arith_ops) for k in range(3)]
     rng.shuffle(inputs)
     fixed = {}
     for a, b in zip(inputs[0::2], inputs[1::2]):
@@ -185,7 +208,7 @@ def make_full_circuit(degree_bits=4, seed=1, arity_bits=(2, 1), rate_bits=3, cap
         kind, param = FULL_GATES[row_gate[r]]
         row = gates_ref.fill_row(kind, param, rng, [consts[0][r], consts[1][r]], pih)
         if kind == "arithmetic":
-            for i in range(3):
+            for i in range(arith_ops):
                 for k in range(3):
                     if (r, 4 * i + k) in fixed:
                         row[4 * i + k] = fixed[(r, 4 * i + k)]

@@ -55,7 +55,12 @@ CASES = [("noop", None), ("constant", 1), ("constant", 2), ("public_input", None
          ("base_sum", (2, 63)), ("base_sum", (4, 16)), ("base_sum", (4, 31)), ("base_sum", (3, 7)), ("u32_add_many", (2, 3)), ("u32_add_many", (16, 4)),
          ("u32_add_many", (3, 5)), ("u32_arithmetic", 1), ("u32_arithmetic", 6), ("u32_subtraction", 1), ("u32_subtraction", 11),
          ("u32_range_check", 1), ("u32_range_check", 8), ("comparison", (32, 16)), ("comparison", (2, 1)), ("comparison", (10, 3)),
-         ("random_access", (1, 2, 0)), ("random_access", (4, 4, 2)), ("random_access", (3, 1, 5)), ("poseidon", None)]
+         ("random_access", (1, 2, 0)), ("random_access", (4, 4, 2)), ("random_access", (3, 1, 5)), ("poseidon", None),
+         # the gates of upstream plonky2 beyond the ed25519 list, at the parameters of standard_recursion_config (135 wires, 80 routed) and small ones
+         ("arithmetic_extension", 10), ("arithmetic_extension", 1), ("mul_extension", 13), ("mul_extension", 2), ("reducing", 43), ("reducing", 1),
+         ("reducing_extension", 32), ("reducing_extension", 1), ("exponentiation", 66), ("exponentiation", 1), ("poseidon_mds", None),
+         ("low_degree_interpolation", 4), ("low_degree_interpolation", 2), ("low_degree_interpolation", 1), ("high_degree_interpolation", 2),
+         ("high_degree_interpolation", 1), ("high_degree_interpolation", 3)]
 
 
 @pytest.mark.parametrize("kind,param", CASES)
@@ -96,7 +101,9 @@ def test_errors_are_reported_not_crashed():
     ("base_sum", (2, 4000), "num_limbs"), ("u32_add_many", (70000, 1), "num_addends"), ("u32_add_many", (2, 0), "num_ops"),
     ("u32_arithmetic", 100000, "num_ops"), ("u32_subtraction", 0, "num_ops"), ("u32_range_check", 5000, "num_input_limbs"),
     ("comparison", (200, 4), "num_bits"), ("comparison", (32, 0), "num_chunks"), ("random_access", (20, 1, 0), "bits"),
-    ("random_access", (2, 100000, 0), "num_copies"), ("random_access", (2, 1, 100000), "num_extra_constants")])
+    ("random_access", (2, 100000, 0), "num_copies"), ("random_access", (2, 1, 100000), "num_extra_constants"),
+    ("arithmetic_extension", 0, "num_ops"), ("mul_extension", 100000, "num_ops"), ("reducing", 0, "num_coeffs"), ("reducing_extension", 50000, "num_coeffs"),
+    ("exponentiation", 0, "num_power_bits"), ("low_degree_interpolation", 5, "subgroup_bits"), ("high_degree_interpolation", 0, "subgroup_bits")])
 def test_parameters_out_of_range_are_invalid_arguments_not_wrapped_programs(kind, param, what):
     """wire / constant indices are 16-bit instruction fields: parameters that would wrap them (or allocate without limit) come back as
     GL_E_INVALID with the parameter's name, before anything is emitted"""

@@ -75,6 +75,40 @@ def test_emitted_program_equals_the_oracle_gate(row):
         assert got == exp, (kind, param, trial)
 
 
+UPSTREAM_GATES = [("arithmetic_extension", 10), ("mul_extension", 13), ("reducing", 43), ("reducing_extension", 32), ("exponentiation", 66),
+                  ("exponentiation", 1), ("poseidon_mds", None), ("low_degree_interpolation", 4), ("low_degree_interpolation", 2),
+                  ("low_degree_interpolation", 1), ("high_degree_interpolation", 1), ("high_degree_interpolation", 2), ("high_degree_interpolation", 3),
+                  ("reducing", 1), ("reducing_extension", 1)]
+
+
+@pytest.mark.parametrize("kind,param", UPSTREAM_GATES)
+def test_upstream_gate_programs_equal_the_oracle_gates(kind, param):
+    """The eight gate kinds of upstream plonky2 beyond the ed25519 list (round 5; standard_recursion_config's parameters and small
+    ones): the emitted program, executed with Python integers, gives oracle/gates_ref.py's constraints on small, random and
+    top-of-the-field rows, and zeros on an honestly generated row."""
+    from oracle import gates_ref
+
+    pool = gp.ImmediatePool()
+    instrs = gp.build_gate(kind, param, pool)
+    rng = random.Random(hash((kind, str(param))) & 0xFFFF)
+    width = gates_ref.num_wires(kind, param)
+    for trial in range(4):
+        consts = [rng.randrange(P) for _ in range(6)]
+        pih = [rng.randrange(P) for _ in range(4)]
+        if trial == 3:
+            wires = gates_ref.fill_row(kind, param, rng, consts[4:], pih)
+        else:
+            draw = [lambda: rng.randrange(4), lambda: rng.randrange(P), lambda: P - 1 - rng.randrange(3)][trial]
+            wires = [draw() for _ in range(width)]
+        execute.worst = [0] * 4
+        got = execute(instrs, pool.values, 4, consts, wires + [0] * 4, pih)
+        exp = gates_ref.constraints(kind, param, consts[4:], wires + [0] * 4, pih, gates_ref.Base)
+        assert got == exp, (kind, param, trial)
+        assert len(got) == gates_ref.num_constraints(kind, param)
+        if trial == 3:
+            assert not any(got)
+
+
 def test_accumulator_bound_is_enforced_by_the_emitter():
     g = gp.GateAsm(gp.ImmediatePool())
     x = g.wire(0)

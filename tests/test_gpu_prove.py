@@ -265,6 +265,30 @@ def test_synthetic_circuit_with_the_ed25519_gate_table_proof_bytes(gpu):
         nc.close()
 
 
+@pytest.mark.parametrize("degree_bits,arity_bits,cap_height,num_queries,compile_gates", [(5, (2, 1), 1, 2, True), (5, (2, 1), 1, 2, False), (11, (4, 4), 4, 28, True)])
+def test_recursion_shaped_circuit_with_the_upstream_gate_kinds_proof_bytes(gpu, degree_bits, arity_bits, cap_height, num_queries, compile_gates):
+    """f4 widened (round 5): a circuit of standard_recursion_config's shape — 135 wires, 80 routed, 15 gates in 4 selector groups — whose
+    rows use the eight gate kinds of upstream plonky2 beyond the ed25519 list (ArithmeticExtension{10}, MulExtension{13}, Reducing{43},
+    ReducingExtension{32}, Exponentiation{66}, PoseidonMds, LowDegreeInterpolation{4}, HighDegreeInterpolation{2}: gates/*.rs) next to
+    the basic ones, each row honestly generated: gl_prove's bytes (programs from the emitters, run-time compiled and interpreted) equal
+    the C restatement of prove(), and the oracle's verifier — extension gates over the D = 2 extension algebra — accepts them."""
+    import plonky2_gpu_amd as pg
+    from oracle import accel, prove_c
+    from plonk_instance import make_recursion_circuit
+
+    with accel.c_backend():
+        circuit, wires, pis = make_recursion_circuit(degree_bits, seed=3, arity_bits=arity_bits, cap_height=cap_height, num_queries=num_queries,
+                                                     pow_bits=3 if degree_bits < 8 else 10)
+    want = prove_c.prove(circuit, wires, pis)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None), compile_gates=compile_gates)
+    assert nc.circuit_digest == circuit["circuit_digest"]
+    data = nc.prove_bytes(wires, pis)
+    nc.close()
+    assert data == want
+    with accel.c_backend():
+        assert prove_ref.verify(circuit, pg.serialization.proof_from_bytes(data, circuit))
+
+
 def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
     """gl_prove keeps one proof's working buffers attached to the circuit; proofs are deterministic across
     the recycled buffers (nothing depends on stale contents) and across gl_circuit_trim."""

@@ -13,7 +13,11 @@ from oracle import pyref
 P = pyref.P
 GATES = [("noop", None), ("constant", 2), ("public_input", None), ("arithmetic", 3), ("base_sum", (2, 8)), ("base_sum", (4, 6)),
          ("u32_add_many", (2, 2)), ("u32_add_many", (5, 1)), ("u32_arithmetic", 2), ("u32_subtraction", 2), ("u32_range_check", 2),
-         ("comparison", (8, 4)), ("comparison", (32, 16)), ("random_access", (2, 2, 2)), ("random_access", (4, 4, 2)), ("poseidon", None)]
+         ("comparison", (8, 4)), ("comparison", (32, 16)), ("random_access", (2, 2, 2)), ("random_access", (4, 4, 2)), ("poseidon", None),
+         # the eight other gates of upstream plonky2 (round 5), at standard_recursion_config's parameters and small ones
+         ("arithmetic_extension", 10), ("mul_extension", 13), ("reducing", 43), ("reducing", 1), ("reducing_extension", 32), ("reducing_extension", 2),
+         ("exponentiation", 66), ("exponentiation", 3), ("poseidon_mds", None), ("low_degree_interpolation", 4), ("low_degree_interpolation", 2),
+         ("high_degree_interpolation", 2), ("high_degree_interpolation", 3)]
 
 
 @pytest.mark.parametrize("kind,param", GATES)

@@ -47,6 +47,27 @@ def test_c_prover_on_the_circuit_with_every_ed25519_gate_kind():
     assert prove_c.prove(circuit, wires, pis, threads=4) == exp
 
 
+def test_recursion_shaped_circuit_with_the_upstream_gate_kinds():
+    """A circuit of standard_recursion_config's shape (135 wires, 80 routed, 15 gates in 4 selector groups) whose rows use the eight
+    gate kinds of upstream plonky2 beyond the ed25519 list — ArithmeticExtension, MulExtension, Reducing, ReducingExtension,
+    Exponentiation, PoseidonMds, LowDegreeInterpolation, HighDegreeInterpolation — next to the basic ones: the Python prover's proof is
+    accepted by the verifier (which evaluates every gate over F_p^2 on its own, with the D = 2 extension algebra for the extension
+    gates), and the C prover gives the same bytes."""
+    from plonk_instance import RECURSION_GATES, make_recursion_circuit
+
+    with accel.c_backend():
+        circuit, wires, pis = make_recursion_circuit(5, seed=3)
+        assert [k for k, _ in circuit["gates"]] == [k for k, _ in RECURSION_GATES] and circuit["num_gate_constraints"] == 123
+        exp = prove_ref.prove(circuit, wires, pis)
+        assert prove_ref.verify(circuit, exp)
+        bad = [list(c) for c in wires]
+        row = next(r for r in range(32) if circuit["constants"][1][r] == 6)  # a LowDegreeInterpolationGate row (selector group 1)
+        bad[40][row] = (bad[40][row] + 1) % P
+        with pytest.raises(AssertionError):
+            prove_ref.verify(circuit, prove_ref.prove(circuit, bad, pis))
+    assert prove_c.prove(circuit, wires, pis, threads=4) == serialize_ref.proof_bytes(exp)
+
+
 def test_c_prover_blinded():
     circuit, wires, pis = make_circuit(5, seed=14, arity_bits=(2, 1))
     circuit = dict(circuit, fri_params=dict(circuit["fri_params"], hiding=True))
@@ -67,7 +88,11 @@ def test_c_prover_reports_a_quotient_that_is_not_a_polynomial():
 
 @pytest.mark.parametrize("kind,param", FULL_GATES + [("base_sum", (2, 63)), ("comparison", (32, 16)), ("u32_add_many", (0, 11)), ("u32_add_many", (16, 4)),
                                                        ("u32_range_check", 0), ("u32_range_check", 8), ("random_access", (4, 4, 2)),
-                                                       ("u32_subtraction", 11), ("u32_arithmetic", 6), ("arithmetic", 20)])
+                                                       ("u32_subtraction", 11), ("u32_arithmetic", 6), ("arithmetic", 20),
+                                                       ("arithmetic_extension", 10), ("mul_extension", 13), ("reducing", 43), ("reducing", 1),
+                                                       ("reducing_extension", 32), ("exponentiation", 66), ("exponentiation", 1), ("poseidon_mds", None),
+                                                       ("low_degree_interpolation", 4), ("low_degree_interpolation", 1), ("high_degree_interpolation", 2),
+                                                       ("high_degree_interpolation", 3)])
 def test_gate_constraints_c_equal_python(kind, param):
     """Gate by gate: honest rows give zeros in both, random rows give the same non-zero values."""
     rng = random.Random(hash((kind, str(param))) & 0xFFFF)
