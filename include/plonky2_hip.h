@@ -380,6 +380,10 @@ typedef struct GlFriParams {
                       * 985-1002); such a circuit is proved with gl_prove_zk */
 } GlFriParams;
 typedef struct GlCircuitDesc {
+    uint32_t struct_size; /* = sizeof(GlCircuitDesc) of the header the caller was compiled against. The struct embeds GlFriParams by
+                           * value and has grown before (`hiding`, round 4): a caller built against another layout gets GL_E_INVALID
+                           * from gl_circuit_create instead of shifted fields. (A caller of the 0.3 layout passes its degree_bits here,
+                           * which no size equals.) */
     uint32_t degree_bits, num_wires, num_routed_wires, num_constants, num_challenges, quotient_degree_factor;
     uint32_t num_gate_constraints;
     GlFriParams fri;
@@ -410,7 +414,8 @@ GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h
  * products, quotient chunks (plonk/prover.rs:84, 125, 174; PlonkOracle::*.blinding, plonk/plonk_common.rs:20-44) — get SALT_SIZE = 4
  * extra elements per leaf, which the proof's initial-tree openings carry and the verifier strips (fri/proof.rs:45-52).
  * The reference draws them from OsRng (F::rand_vec, fri/oracle.rs:998-1002); here the randomness is the CALLER's:
- *   d_salts  [3][4][n_ext] uniform field elements (n_ext = 2^(degree_bits + rate_bits)): block 0 for the wires commitment, 1 for
+ *   d_salts  [3][4][n_ext] uniform field elements, any u64 representative (words >= p are reduced on their way into the commitment, so
+ *            the proof carries canonical words like the reference's rand_vec output) (n_ext = 2^(degree_bits + rate_bits)): block 0 for the wires commitment, 1 for
  *            Zs / partial products, 2 for the quotient; column k of a block is element k of the salt of every leaf, in LEAF order
  *            (entry j belongs to leaf j, the leaf of the LDE point bitrev(j)).
  * gl_prove on a hiding circuit and gl_prove_zk on a non-hiding one return GL_E_INVALID. */

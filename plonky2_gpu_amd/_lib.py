@@ -88,6 +88,7 @@ class GlFriParams(ctypes.Structure):
 
 class GlCircuitDesc(ctypes.Structure):
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
         ("degree_bits", ctypes.c_uint32),
         ("num_wires", ctypes.c_uint32),
         ("num_routed_wires", ctypes.c_uint32),

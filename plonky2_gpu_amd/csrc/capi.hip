@@ -556,7 +556,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
 
 extern "C" {
 
-const char *gl_version(void) { return "plonky2_hip 0.3.0 gfx950"; }
+const char *gl_version(void) { return "plonky2_hip 0.5.0 gfx950"; }
 
 int gl_device_count(void) {
     int n = 0;

@@ -70,7 +70,10 @@ template <int LOGG>
 struct ColGeom {
     static constexpr int G = 1 << LOGG, LOGC = 6 - LOGG, C = 1 << LOGC, LOGR = 8 + LOGG, R = 1 << LOGR;
     static constexpr uint32_t ROWB = C * 8;                            // bytes of one (kAB, w) row of the exchange image
-    static constexpr uint32_t SA = 16 * ROWB + (G >= 4 ? ROWB : 0);    // kAB stride: one pad row makes rows kAB, kAB+1 differ by 128 mod 256 bytes
+    // kAB stride: one pad row. For G = 4 (ROWB = 128) rows kAB and kAB + 1 then differ by 128 mod 256 bytes and every access of both
+    // exchanges is conflict-free; for G = 8 (ROWB = 64) the stride is 1088 = 64 mod 256 and the first write of the private exchange keeps a
+    // two-way conflict that only a row swizzle would remove (3 % of that kernel, profiles/r04_ntt_sizes.jsonl).
+    static constexpr uint32_t SA = 16 * ROWB + (G >= 4 ? ROWB : 0);
     static constexpr uint32_t XBYTES = 16 * G * SA;
     static constexpr uint32_t TWBYTES = 16 * G * 16 * 8;               // per wave: w_R^(kA (16 g + w)), [g][kA]
     static constexpr uint32_t LDS_BYTES = XBYTES + TWBYTES;
@@ -80,6 +83,8 @@ struct ColGeom {
     static constexpr uint32_t cs_entries(uint32_t gz) { return gz * C; }                          // [z][c]
     static constexpr uint32_t coset_bytes(uint32_t gz) { return (cu_entries(gz) + t2z_entries(gz) + cs_entries(gz)) * 8; }
 };
+
+static_assert(ColGeom<3>::LDS_BYTES <= 160 * 1024 && ColGeom<2>::LDS_BYTES <= 160 * 1024, "the exchange image and the tables must fit the 160 KiB of LDS of a gfx950 CU");
 
 // COSET (the first pass of the coset LDE, F_COSET): grid z = coset, every coset reads the same coefficients (in_sz = 0) scaled by the
 // powers of its shift s_z and writes block bitrev(z). With j = m in_m + L (m = row = (R/16) i + 16 g + w, L = column):

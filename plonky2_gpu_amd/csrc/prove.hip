@@ -210,6 +210,18 @@ uint32_t num_partial_products(uint32_t routed, uint32_t qdf) { return (routed + 
 
 constexpr uint32_t SALT_SIZE = 4;  // fri/oracle.rs:41
 
+__global__ void canon_copy_kernel(uint64_t *dst, const uint64_t *src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = gl::canon(src[i]);
+}
+GlError canon_copy(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, void *ctx) {
+    if (n == 0) return ok();
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(canon_copy_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, *reinterpret_cast<hipStream_t *>(ctx), d_dst, d_src, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(hipGetErrorString(e));
+    return ok();
+}
+
 // d_salt: SALT_SIZE columns of n_ext caller-provided random elements in leaf order (a blinded commitment, prover.rs:84, 125, 174), or null
 GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx, const uint64_t *d_salt = nullptr) {
     const uint64_t n_ext = 1ull << (c.degree_bits + c.rate_bits);
@@ -220,8 +232,10 @@ GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, con
     TRY(b->lde.alloc((uint64_t)b->leaf_len * n_ext));
     TRY(b->digests.alloc(8 * (n_ext - (1ull << c.cap_height))));
     TRY(b->cap_d.alloc(4ull << c.cap_height));
-    // the salt columns sit behind the LDE's columns and are hashed with them (gl_commit_from_*: "read as given")
-    if (salt) TRY(gl_memcpy_d2d(b->lde.p + (uint64_t)n_polys * n_ext, d_salt, 8ull * salt * n_ext, ctx));
+    // the salt columns sit behind the LDE's columns and are hashed with them (gl_commit_from_* reads them as given). They also go into
+    // the proof verbatim (fri/prover.rs:203-210), where every word must be canonical like the reference's F::rand_vec output
+    // (fri/oracle.rs:998-1002): a caller who fills d_salts with raw 64-bit randoms gets them reduced here, not >= p words on the wire.
+    if (salt) TRY(canon_copy(b->lde.p + (uint64_t)n_polys * n_ext, d_salt, (uint64_t)salt * n_ext, ctx));
     if (from_values)
         TRY(gl_commit_from_values(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, salt, 7, b->lde.p, nullptr, b->digests.p,
                                   b->cap_d.p, ctx));
@@ -271,6 +285,8 @@ extern "C" {
 GlError gl_circuit_create(const GlCircuitDesc *d, void **circuit, void *ctx) {
     if (!d || !circuit || !ctx || !d->h_k_is || !d->h_constants || !d->h_sigmas || (d->fri.num_reductions && !d->fri.reduction_arity_bits))
         return fail("null pointer");
+    if (d->struct_size != sizeof(GlCircuitDesc))
+        return fail("GlCircuitDesc.struct_size does not equal sizeof(GlCircuitDesc) of this library: the caller was compiled against another version of include/plonky2_hip.h");
     if (d->degree_bits > 24 || d->num_challenges == 0 || d->num_challenges > 4 || d->num_routed_wires > d->num_wires ||
         d->quotient_degree_factor < 2 || d->quotient_degree_factor >= d->num_routed_wires)
         return fail("bad circuit shape (the prover needs quotient_degree_factor < num_routed_wires, prover.rs:99-102)");

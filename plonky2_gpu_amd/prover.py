@@ -295,7 +295,7 @@ class NativeCircuit:
         k_is, consts, sigmas = _host_u64(circuit["k_is"]), _host_u64(circuit["constants"]), _host_u64(circuit["sigmas"])
         digest = _host_u64(circuit["circuit_digest"]) if circuit.get("circuit_digest") is not None else None
         desc = _lib.GlCircuitDesc(
-            circuit["degree_bits"], circuit["num_wires"], circuit["num_routed_wires"], circuit["num_constants"], circuit["num_challenges"],
+            ctypes.sizeof(_lib.GlCircuitDesc), circuit["degree_bits"], circuit["num_wires"], circuit["num_routed_wires"], circuit["num_constants"], circuit["num_challenges"],
             circuit["quotient_degree_factor"], circuit["num_gate_constraints"],
             _lib.GlFriParams(fp["rate_bits"], fp["cap_height"], fp["proof_of_work_bits"], fp["num_query_rounds"], arity.size,
                              arity.ctypes.data, 1 if fp.get("hiding") else 0),

@@ -59,6 +59,7 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> arity;
     for (const uint64_t *p = take(h[12]), *e = p + h[12]; p < e; p++) arity.push_back((uint32_t)*p);
     GlCircuitDesc desc = {};
+    desc.struct_size = sizeof desc;
     desc.degree_bits = (uint32_t)h[1], desc.num_wires = (uint32_t)h[2], desc.num_routed_wires = (uint32_t)h[3];
     desc.num_constants = (uint32_t)h[4], desc.num_challenges = (uint32_t)h[5], desc.quotient_degree_factor = (uint32_t)h[6];
     desc.num_gate_constraints = (uint32_t)h[7];

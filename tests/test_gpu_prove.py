@@ -289,6 +289,29 @@ def test_recursion_shaped_circuit_with_the_upstream_gate_kinds_proof_bytes(gpu, 
         assert prove_ref.verify(circuit, pg.serialization.proof_from_bytes(data, circuit))
 
 
+def test_a_circuit_description_of_another_header_version_is_refused(gpu):
+    """GlCircuitDesc embeds GlFriParams by value and has grown before: its first field is sizeof(GlCircuitDesc) of the caller's header, and
+    gl_circuit_create refuses any other value (a caller compiled against the 0.3 layout passes its degree_bits there)."""
+    import ctypes
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    circuit, wires, pis = make_circuit(4, seed=3)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))  # a good description is accepted
+    nc.close()
+    desc = _lib.GlCircuitDesc()
+    desc.struct_size = 4  # what a stale caller's degree_bits would look like
+    h = ctypes.c_void_p()
+    with pytest.raises(pg.Plonky2HipError, match="null pointer|struct_size"):
+        _lib.call("gl_circuit_create", ctypes.byref(desc), ctypes.byref(h), gpu.ptr)
+    k = np.zeros(16, dtype=np.uint64)
+    desc.h_k_is = desc.h_constants = desc.h_sigmas = k.ctypes.data
+    with pytest.raises(pg.Plonky2HipError, match="struct_size"):
+        _lib.call("gl_circuit_create", ctypes.byref(desc), ctypes.byref(h), gpu.ptr)
+    assert pg.load().gl_version().startswith(b"plonky2_hip 0.5")
+
+
 def test_working_buffers_are_recycled_and_can_be_trimmed(gpu):
     """gl_prove keeps one proof's working buffers attached to the circuit; proofs are deterministic across
     the recycled buffers (nothing depends on stale contents) and across gl_circuit_trim."""
@@ -613,6 +636,14 @@ def test_blinded_proof_bytes_equal_the_oracle(gpu, which, degree_bits, compile_g
     assert other[:32] != data[:32] and prove_ref.verify(circuit, pg.serialization.proof_from_bytes(other, circuit))
     with pytest.raises(pg.Plonky2HipError, match="hiding"):
         nc.prove_bytes(wires, pis)
+    # salts given as RAW 64-bit words (a caller filling d_salts from a byte stream): about one word in 2^32 is >= p, here a few are
+    # forced to be. They are reduced on their way into the commitment: the proof's bytes stay canonical (util/serialization.rs:492-497
+    # writes to_canonical_u64) and equal the proof for the reduced salts.
+    raw, small = salts.copy(), salts.copy()
+    small[:, :, :5] = salts[:, :, :5] % np.uint64(0xFFFFFFFF)
+    raw[:, :, :5] = small[:, :, :5] + np.uint64(P)
+    assert (raw >= np.uint64(P)).sum() >= 60
+    assert nc.prove_bytes(wires, pis, salts=raw) == nc.prove_bytes(wires, pis, salts=small)
     nc.close()
     nc2 = pg.NativeCircuit(gpu, dict(plain, circuit_digest=None), compile_gates=compile_gates)
     with pytest.raises(pg.Plonky2HipError, match="not hiding"):
