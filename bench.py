@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--prove-degree-bits", type=int, default=18)
     ap.add_argument("--prove-wires", type=int, default=234)
     ap.add_argument("--prove-reps", type=int, default=3)
+    ap.add_argument("--prove-larger", default="19,20", help="further trace sizes (log2 rows) at which one proof of the same shape is timed, rank 0 at N = 1 ('' = none)")
     ap.add_argument("--commit-cols", type=int, default=135)
     ap.add_argument("--commit-log-n", type=int, default=20)
     return ap.parse_args()
@@ -636,6 +637,14 @@ def main():
         if dist.rank == 0:
             extra["prove"] = pr
 
+    if not args.no_prove and dist.world == 1 and args.prove_larger and args.prove_wires == 234:
+        # north_star's 2^20-row traces as whole proofs (and 2^19 between): the same circuit shape, one timed proof each after a warm-up
+        larger = {}
+        for db in [int(x) for x in args.prove_larger.split(",") if x]:
+            r, _ = bench_prove(pg, ctx, dist, db, args.prove_wires, 1)
+            larger["2^%d rows" % db] = {k: r[k] for k in ("prove_ms", "proof_bytes", "stage_ms")}
+        extra["prove_larger_traces"] = larger
+
     if dist.rank == 0:
         ntts = 2 * batch * inner * args.steps * dist.world
         rates = sorted(ntts / w for w in window_s)
@@ -782,6 +791,7 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
             "validity_checked_by": "tests/test_gpu_prove.py::test_full_size_proof_bytes_equal_the_c_oracle",
         }
     d_wires.free()
+    nc.close()  # the circuit's working buffers (one proof's worth of HBM) go back before the next leg
     # rank 0 at N = 1 hands its circuit, witness and proof to the CPU leg (cpu_baseline_prove), which proves the same thing
     return res, ((circuit, wires, pis, data) if dist.rank == 0 and dist.world == 1 else None)
 

@@ -825,6 +825,16 @@ static bool wide_ok(uint32_t logr, uint64_t t_limit) {
            (t_limit & ((1ull << (LOGE + 1 - logr)) - 1)) == 0;
 }
 
+// 2^22 natural-order forward transforms in two passes (round 5). PLONKY2_NTT_TWO_PASS_22=0 in the diagnostic build restores the
+// three-pass plan (A/B measurements).
+static bool two_pass_2p22() {
+    static const bool enabled = [] {
+        const char *e = PLONKY2_KNOB("PLONKY2_NTT_TWO_PASS_22");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && direct_mode();
+}
+
 hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, uint64_t n_polys, uint32_t log_n,
                      uint64_t src_stride, uint64_t dst_stride, NttOrder order, bool inverse, hipStream_t stream) {
     if (log_n > NTT_MAX_LOG) return hipErrorInvalidValue;
@@ -863,6 +873,58 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         if (n_polys > 0xFFFFFFFFull) return hipErrorInvalidValue;
         dim3 grid((unsigned)((n_polys + T - 1) / T), 1, 1);
         return dispatch_pass<false>(log_n, p, grid, stream);
+    }
+
+    if (log_n == 22 && natural && !inverse && two_pass_2p22()) {
+        // 2^22 = 2048 x 2048 in TWO passes, both the direct column pass with eight lane groups (tiles of 2048 rows x 8 columns,
+        // 64-byte segments): pass A takes the columns L of the matrix [m][L] (stride 2048), applies w_n^(L k1) and stores its tile
+        // TRANSPOSED into the workspace, mid[L * 2048 + k1]; pass B takes the columns k1 of that matrix [L][k1], has no twiddle left to
+        // apply and writes X[k1 + 2048 k2] in natural order. HBM-side traffic 2 x the algorithmic bytes instead of the three-pass
+        // plan's 3 x (round 4 priced this plan at the three-pass plan's time from memory-only measurements; round 5 measures it:
+        // profiles/r05_ntt_sizes.jsonl). Forward transforms only: the inverse's index flip lives in the row pass.
+        const uint64_t N1 = 2048, C = 8;
+        if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
+        const uint64_t chunk = tb.scratch_elems / n;
+        for (uint64_t off = 0; off < n_polys; off += chunk) {
+            const uint64_t cnt = n_polys - off < chunk ? n_polys - off : chunk;
+            base_params(p, tb);
+            p.src = src + off * src_stride;
+            p.dst = tb.scratch;
+            p.logt = 3;
+            p.t_limit = (uint32_t)N1;
+            p.in_sa = src_stride;
+            p.in_sb = C;
+            p.in_t = 1;
+            p.in_m = N1;
+            p.out_sa = n;
+            p.out_sb = C * N1;   // column tile b of the input = rows [8 b, 8 b + 8) of the transposed matrix
+            p.out_t = 1;
+            p.out_m = 1;         // output frequency k1 runs along the row
+            p.out_c = N1;        // the tile's columns L are N1 elements apart
+            p.flags = F_NATURAL | F_WIDE | F_RAW_OUT;
+            p.log_n = log_n;
+            p.tw_hi = log_n;
+            hipError_t e = nttk::launch_col_direct(3, p, dim3((unsigned)(N1 / C), (unsigned)cnt, 1), stream);
+            if (e != hipSuccess) return e;
+            base_params(p, tb);
+            p.src = tb.scratch;
+            p.dst = dst + off * dst_stride;
+            p.logt = 3;
+            p.t_limit = (uint32_t)N1;
+            p.in_sa = n;
+            p.in_sb = C;
+            p.in_t = 1;
+            p.in_m = N1;
+            p.out_sa = dst_stride;
+            p.out_sb = C;
+            p.out_t = 1;
+            p.out_m = N1;
+            p.flags = F_NATURAL | F_WIDE | F_FINAL_COL;
+            p.log_n = log_n;
+            e = nttk::launch_col_direct_final(p, dim3((unsigned)(N1 / C), (unsigned)cnt, 1), stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
 
     if (log_n <= 20 || (log_n == 21 && wide_ok(11, 1024))) {

@@ -94,7 +94,7 @@ static_assert(ColGeom<3>::LDS_BYTES <= 160 * 1024 && ColGeom<2>::LDS_BYTES <= 16
 //                               for R = 256, which has no such twiddle, it is part of CU [z][w][i]),
 //   s^L                         rides on the start of the inter-pass twiddle chain (CS [z][c]; the workgroup keeps its column tile).
 // Sixteen + 16/G + 1 multiplications per lane and tile more than the plain pass; the tables are built once per workgroup.
-template <int LOGG, bool NATURAL, bool COSET = false>
+template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_direct_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t gz, const uint32_t per_b) {
     using GEO = ColGeom<LOGG>;
     constexpr int G = GEO::G, LOGC = GEO::LOGC, C = GEO::C, LOGR = GEO::LOGR;
@@ -171,10 +171,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto xr_base_of = [&](uint32_t l) { return kab_of(l) * SA + (l & (C - 1)) * 8; };   // + w'' * ROWB
     auto ld_off_of = [&](uint32_t l) { return (uint32_t)(((l & (C - 1)) + (uint64_t)(16 * (l >> LOGC) + wave) * p.in_m) * 8); };
     // row of frequency k1 = kAB + 16 G kC in the output: k1 itself, or its bit reversal when the transform runs in place
+    const uint64_t out_c = p.out_c ? p.out_c : 1;   // stride between the tile's columns in the output (N1 with out_m = 1: transposed store)
     auto st_off_of = [&](uint32_t l) {
         const uint32_t kab = kab_of(l);
         const uint32_t out_row_lane = natural ? kab : (brev_rt(kab & 15, 4) << (LOGR - 4)) | (brev_rt(kab >> 4, LOGG) << 4);
-        return (uint32_t)(((l & (C - 1)) + (uint64_t)out_row_lane * p.out_m) * 8);
+        return (uint32_t)(((l & (C - 1)) * out_c + (uint64_t)out_row_lane * p.out_m) * 8);
     };
 
     auto tile_of = [&](uint32_t t, uint32_t &b, uint32_t &a, uint32_t &z) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // Without cosets a lane's sixteen twiddles are the same for every tile of the workgroup (it keeps its column tile): the first
     // eight stay in registers, the other eight are one multiplication by step^8 away — 24 multiplications per tile instead of the
     // chain's 31. (With cosets the chain starts from a different power per tile and is walked as before.)
-    constexpr bool kept_twiddles = !COSET;
+    constexpr bool kept_twiddles = !COSET && !FINAL;
     uint64_t cw[kept_twiddles ? 8 : 1], cstep8 = 1;
     uint32_t chain_b = 0xFFFFFFFFu;
     const uint32_t st_row = (uint32_t)(p.out_m * 8);
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto tail_begin = [&](uint32_t k) {
         uint32_t b, a, z;
         tile_of(k, b, a, z);
-        if (b != chain_b) {
+        if (!FINAL && b != chain_b) {
             chain_b = b;
             const uint32_t l = opaque_lane();
             const uint64_t L = (uint64_t)b * C + (l & (C - 1));
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto tail_unit = [&](auto J_) {
         constexpr int j = decltype(J_)::value;   // kC
         constexpr int s3 = brev_c(j, 4);
-        if constexpr (kept_twiddles) {
+        if constexpr (FINAL) {
+            B[s3] = gl::canon(B[s3]);   // the last pass of a transform: no inter-pass twiddle, a boundary buffer gets canonical values
+        } else if constexpr (kept_twiddles) {
             if constexpr (j < 8) B[s3] = gl::mul(B[s3], cw[j]);
             else B[s3] = gl::mul(B[s3], gl::mul(cw[j - 8], cstep8));
         } else {
@@ -392,12 +395,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 }
 
-template <int LOGG, bool NATURAL, bool COSET = false>
+template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false>
 hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
     using GEO = ColGeom<LOGG>;
     const uint32_t lds_bytes = GEO::LDS_BYTES + (COSET ? GEO::coset_bytes(grid.z) : 0);
     static DynamicLds attr;
-    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET>), lds_bytes); e != hipSuccess) return e;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL>), lds_bytes); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t pairs = (uint64_t)grid.y * grid.z, total = pairs * grid.x;
@@ -414,7 +417,7 @@ hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t strea
         wgs = (uint32_t)cus;
     }
     if (COSET && per_b == 0) return hipErrorInvalidValue;   // col_direct_coset_ok() said otherwise
-    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL, COSET>), dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
+    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL>), dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
     return hipGetLastError();
 }
 
@@ -808,6 +811,11 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
     }
 }
 
+
+hipError_t launch_col_direct_final(const PassParams &p, dim3 grid, hipStream_t stream) {
+    if (!(p.flags & F_NATURAL) || (p.flags & F_COSET)) return hipErrorInvalidValue;
+    return launch_col_direct_t<3, true, false, true>(p, grid, stream);
+}
 
 hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream) { return launch_row_inplace_direct_t(p, grid, stream); }
 

@@ -15,7 +15,8 @@ namespace nttk {
 
 enum : uint32_t { F_LOAD_ROWS = 1, F_STORE_ROWS = 2, F_NATURAL = 4, F_INVERSE = 8, F_COSET = 16,
                   F_WIDE = 32,
-                  F_RAW_OUT = 64 };  // the pass feeds another pass: its output need not be canonical (any u64 representative is a legal input)  // F_WIDE: the planner laid the pass out for tiles of 2^(LOGE+1) elements (ntt_pass_wave_kernel, LOGW = 4)
+                  F_RAW_OUT = 64,
+                  F_FINAL_COL = 128 };  // direct column pass that is the LAST pass of a transform: no inter-pass twiddle, canonical output  // the pass feeds another pass: its output need not be canonical (any u64 representative is a legal input)  // F_WIDE: the planner laid the pass out for tiles of 2^(LOGE+1) elements (ntt_pass_wave_kernel, LOGW = 4)
 
 struct PassParams {
     const uint64_t *src;
@@ -26,6 +27,8 @@ struct PassParams {
     const uint64_t *cs_lo;  // s_r^e, e < 1024
     uint64_t in_sa, in_sb, in_sz, in_t, in_m;
     uint64_t out_sa, out_sb, out_sz, out_t, out_m;
+    uint64_t out_c;      // direct column pass only: stride between the columns of a tile in the output (0 = 1 = adjacent; N1 with out_m = 1
+                         // writes the tile TRANSPOSED — the first pass of the two-pass plan for 2^22, ntt.hip)
     uint64_t scale;      // multiplied into every output (1 = none)
     uint64_t chain_scale;  // folded into the inter-pass twiddle chain start (1 = none): n^-1 of the inverse
     uint32_t logt;       // log2 T
@@ -382,6 +385,8 @@ inline hipError_t allow_dynamic_lds(DynamicLds &st, const void *fn, uint32_t lds
 // ---- direct passes (ntt_direct.hip) -------------------------------------------------------------------------------------
 // Column pass of R = 2^(8 + logg) rows on tiles of 64 >> logg adjacent columns (the planner's F_WIDE geometry), logg = 0, 1, 2.
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream);
+// The same pass as the LAST pass of a transform (F_FINAL_COL; logg = 3, natural order only): no twiddle chain, outputs canonical.
+hipError_t launch_col_direct_final(const PassParams &p, dim3 grid, hipStream_t stream);
 // F_COSET passes (first pass of the coset LDE): only when this says so
 bool col_direct_coset_ok(int logg, dim3 grid);
 // Row pass of 1024-point rows with natural-order (transposed) output on tiles of SIXTEEN rows: the planner lays the pass out

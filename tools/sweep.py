@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """NTTs/s and Merkle-leaves-hashed/s over trace sizes 2^16..2^23 on one GPU (north-star sweep).
 NTT: batch of columns sized to 512 MiB, forward + inverse, natural order. Commit: from_values with
-rate 8, cap height 4, P columns scaled so that the LDE stays <= 16 GiB. HIP-event timing."""
+rate 8, cap height 4, leaf-major copy included: the three commitments of the ed25519 shape at 2^18 rows, and — since round 5 — the
+FULL WIDTH of standard_recursion_config, 135 columns, at 2^20, 2^21, 2^22 and 2^23 rows (LDE 9 / 18 / 36 / 72 GB; the last two hold
+more than 2^32 elements), each with its fraction of the HBM roofline (algorithmic bytes of SURVEY 8d / time / 8 TB/s). HIP-event timing."""
 import json
 import os
 import sys
@@ -44,7 +46,7 @@ def main():
         r = {"kind": "ntt", "log_n": log_n, "batch": batch, "ntts_per_s": 2 * batch / (ms * 1e-3),
              "alg_GBps": 2 * batch * 16.0 * n / (ms * 1e-3) / 1e9}
         rows.append(r); print(json.dumps(r)); buf.free()
-    for log_n, cols in [(18, 234), (18, 20), (18, 16), (20, 135), (21, 96), (22, 48), (23, 24)]:
+    for log_n, cols in [(18, 234), (18, 20), (18, 16), (20, 135), (21, 135), (22, 135), (23, 135)]:
         n, n_ext = 1 << log_n, 1 << (log_n + 3)
         d_vals = pg.DeviceBuffer(ctx, cols * n); fill(ctx, d_vals, cols * n, 100 + log_n)
         d_work = pg.DeviceBuffer(ctx, cols * n)
@@ -59,8 +61,10 @@ def main():
             e1.record(ctx); ctx.synchronize()
             if it: best = min(best, e1.elapsed_ms_since(e0))
         perms = n_ext * ((cols + 7) // 8) + n_ext - 16
-        r = {"kind": "commit", "log_n": log_n, "cols": cols, "ms": best, "leaves_per_s": n_ext / (best * 1e-3),
-             "permutations_per_s": perms / (best * 1e-3)}
+        alg = 8.0 * cols * n + 8.0 * cols * n_ext + 32.0 * (2 * (n_ext - 16) + 16)
+        r = {"kind": "commit", "log_n": log_n, "cols": cols, "lde_elements": cols * n_ext, "lde_GB": cols * n_ext * 8 / 1e9, "ms": best,
+             "leaves_per_s": n_ext / (best * 1e-3), "permutations_per_s": perms / (best * 1e-3),
+             "algorithmic_GBps": alg / (best * 1e-3) / 1e9, "hbm_frac": alg / (best * 1e-3) / 1e9 / 8000.0}
         rows.append(r); print(json.dumps(r))
         for b in (d_vals, d_work, d_lde, d_leaves, d_dig, d_cap): b.free()
 
