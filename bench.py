@@ -309,7 +309,7 @@ def dft_point(x, log_n, k):
     return int(terms[0])
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
 # the kernel sources whose counters the summary holds: tools/pmc_summary.py records their sha256 next to the counters
 PMC_SOURCES = ["plonky2_gpu_amd/csrc/ntt.hip", "plonky2_gpu_amd/csrc/ntt_direct.hip", "plonky2_gpu_amd/csrc/ntt_kernels.h",
                "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/poseidon_limb_constants.h", "plonky2_gpu_amd/csrc/gl_field.h"]
@@ -357,7 +357,9 @@ def forward_ntt_kernels(d):
     col, row = [], []
     for name, e in d.get("kernels", {}).items():
         base, args, grid = _kernel_key(name)
-        if base == "ntt_col_direct_kernel" and len(args) >= 3 and args[1] == "true" and args[2] == "false":
+        # <LOGG, NATURAL, COSET[, FINAL]>: the natural-order, non-coset pass that carries the inter-pass twiddle (FINAL, round 5, is the
+        # last pass of the two-pass plan for 2^22 and never part of the 2^20 transform)
+        if base == "ntt_col_direct_kernel" and len(args) >= 3 and args[1] == "true" and args[2] == "false" and (len(args) < 4 or args[3] == "false"):
             col.append((grid, name, e))
         elif base == "ntt_row_natural_direct_kernel" and args[:1] == ["false"]:
             row.append((grid, name, e))

@@ -144,6 +144,76 @@ def test_ntt_three_pass_sizes(gpu, oracle, log_n):
     assert (b == exp[1][bitrev_perm(log_n)]).all()
 
 
+def test_two_pass_plan_for_2e22_over_several_workspace_chunks_and_against_the_three_pass_plan(gpu, oracle):
+    """2^22 natural-order forward transforms run as 2048 x 2048 in two passes through the workspace (round 5, csrc/ntt.hip): eighteen
+    columns = more than the sixteen the 512 MiB workspace holds at once (two chunks), non-canonical inputs in one column; four of them
+    (first, the two either side of the chunk boundary, last) against the C oracle, ALL of them against the three-pass plan of the
+    diagnostic build (PLONKY2_NTT_TWO_PASS_22=0, a child process), and the inverse (still three passes) brings every column back."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import plonky2_gpu_amd as pg
+
+    log_n, n_polys = 22, 18
+    n = 1 << log_n
+    x = oracle.random_field((n_polys, n), seed=2222)
+    x[3, :1000] = np.uint64(2**64 - 1) - np.arange(1000, dtype=np.uint64)  # representatives >= p
+    f = pg.fft_with_options(gpu, x)
+    watch = [0, 15, 16, 17]
+    exp = oracle.canon(oracle.fft_batch(x[watch].copy(), threads=4))
+    for k, c in enumerate(watch):
+        assert (f[c] == exp[k]).all(), c
+    assert (pg.ifft_with_options(gpu, f) == oracle.canon(x)).all()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "x.npy"), x)
+        code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import plonky2_gpu_amd as pg
+ctx = pg.Context(0)
+np.save({os.path.join(tmp, 'f.npy')!r}, pg.fft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r})))
+"""
+        env = dict(os.environ, PLONKY2_NTT_TWO_PASS_22="0", PLONKY2_HIP_LIBRARY=os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert (np.load(os.path.join(tmp, "f.npy")) == f).all(), "the two-pass and the three-pass plan disagree"
+
+
+def test_ntt_batch_with_more_than_2e32_elements(gpu, oracle):
+    """gl_ntt_batch over 520 polynomials of 2^23 points = 4.36e9 elements (35 GB) in ONE call: every polynomial offset is 64-bit or
+    the later ones land on the earlier. The buffer is filled on the device with copies of eight distinct columns; natural order (the
+    workspace holds eight polynomials at a time: 65 chunks) and bit-reversed (in place); polynomials 0, 7, 263 and 519 against the C
+    oracle, all replicas of one column against each other through a device-side comparison."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    log_n, distinct, copies = 23, 8, 65
+    n, n_polys = 1 << log_n, 8 * 65
+    assert n_polys * n > 1 << 32
+    x = oracle.random_field((distinct, n), seed=2323)
+    exp = oracle.canon(oracle.fft_batch(x, threads=8))
+    perm = bitrev_perm(log_n)
+    buf = pg.DeviceBuffer(gpu, n_polys * n)
+    for order, expect in ((0, exp), (1, exp[:, perm])):
+        buf.upload(x, 0)
+        for k in range(1, copies):
+            _lib.call("gl_memcpy_d2d", buf.at(k * distinct * n), buf.ptr, 8 * distinct * n, gpu.ptr)
+        _lib.call("gl_ntt_batch", buf.ptr, n_polys, log_n, n, 0, order, gpu.ptr)
+        gpu.synchronize()
+        for c in (0, 7, 263, 519):
+            assert (buf.download(c * n, n) == expect[c % distinct]).all(), (order, c)
+        # every replica equals the first copy: subtract block k from block 0 on the device (op 1 = sub), the result must be all zero
+        diff = pg.DeviceBuffer(gpu, distinct * n)
+        for k in (1, 31, 32, 33, 64):
+            _lib.call("gl_debug_field_op", 1, buf.ptr, buf.at(k * distinct * n), diff.ptr, distinct * n, gpu.ptr)
+            assert not diff.download().any(), (order, k)
+        diff.free()
+    buf.free()
+
+
 @pytest.mark.parametrize("log_n,rate_bits", [(21, 1), (22, 1), (23, 0), (21, 3), (24, 0)])
 def test_coset_lde_three_pass(gpu, oracle, log_n, rate_bits):
     """Coset LDE of the large sizes: 2^21 in two passes (split 2048-point columns), 2^22 .. 2^24 points in three."""
