@@ -75,6 +75,7 @@ struct GateUnit {
     hipFunction_t fn = nullptr;
     uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
     uint64_t *d_pih = nullptr;  // the module's g_pih[4]
+    uint64_t *d_par = nullptr;  // the module's g_par[6]: where the LDE lives
     std::string error;
 };
 
@@ -142,6 +143,15 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     // alpha powers and the public-inputs hash live at link-time-constant addresses, so every read is a scalar
     // load (a pointer ARGUMENT of a non-inlined device function arrives in VGPRs and would be read per lane)
     o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n";
+    // Where the LDE lives: {wires, row stride, element stride, constants/sigmas, row stride, element stride} (strides in elements), as
+    // link-time-constant scalars for the same reason: the element stride that every wire load multiplies by is then a scalar, not a
+    // vector register of a function argument. (Measured in round 5, profiles/r05_quotient_codegen_ab.jsonl: going further — a BUFFER
+    // load per wire whose descriptor carries the uniform part of the address, zero vector instructions per load, 16 k of 165 k fewer —
+    // made the ed25519 quotient 2 % SLOWER: the scalar chain that rebuilds the descriptor in front of every load keeps the compiler from
+    // issuing a gate's loads in one batch, and four waves per SIMD do not hide the latency that exposes.)
+    o << "__constant__ uint64_t g_par[6];\n"
+         "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
+         "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
     for (uint32_t g : unit_gates) {
         const uint32_t *d = gates + 6 * g;
         const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
@@ -149,8 +159,10 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
             *error = "gate descriptor out of range";
             return "";
         }
-        o << "static __device__ __noinline__ GateSum gate_" << g
-          << "(const uint64_t* __restrict__ W, uint64_t wes, const uint64_t* __restrict__ C, uint64_t ces) {\n";
+        o << "static __device__ __noinline__ GateSum gate_" << g << "() {\n"
+             "  const uint64_t t_ = (uint64_t)blockIdx.x * 128u + threadIdx.x;\n"   // the kernel runs 128 lanes per block
+             "  const uint64_t* W = (const uint64_t*)g_par[0] + t_ * g_par[1]; const uint64_t wes = g_par[2];\n"
+             "  const uint64_t* C = (const uint64_t*)g_par[3] + t_ * g_par[4]; const uint64_t ces = g_par[5];\n";
         // compute_filter (gates/gate.rs:261-268)
         o << "  const uint64_t s = C[" << si << " * ces];\n  uint64_t filt = 1;\n";
         for (uint32_t i = gs; i < ge; i++)
@@ -219,8 +231,9 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                         *error = "ACC: the accumulator could reach 2^63 before its ACCR";
                         return "";
                     }
-                    o << "  acc" << q << "l += (uint64_t)(uint32_t)r" << ra << " * " << imms[b] << "u; acc" << q << "h += (uint64_t)(uint32_t)(r" << ra << " >> 32) * "
-                      << imms[b] << "u;\n";
+                    // both halves as ONE statement of two multiply-adds: left to itself the compiler strength-reduces the small constant
+                    // weights (x 4^j: a 64-bit shift, four ANDs and two 64-bit adds, 24 issue cycles where two multiply-adds take 12)
+                    o << "  gj_acc(acc" << q << "l, acc" << q << "h, r" << ra << ", " << imms[b] << "u);\n";
                     break;
                 }
                 case GP_ACCR: {  // r[dst] = acc[a] mod p; acc[a] = 0
@@ -249,10 +262,9 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     o << "extern \"C\" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
          "uint64_t wes, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces, uint64_t lde_size, uint64_t* __restrict__ out, int accumulate) {\n"
          "  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;\n  if (t >= lde_size) return;\n"
-         "  const uint64_t* W = wires + t * wrs;\n  const uint64_t* C = cs + t * crs;\n"
          "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = accumulate ? out[(uint64_t)c * lde_size + t] : 0;\n";
     for (uint32_t g : unit_gates)
-        o << "  { GateSum s = gate_" << g << "(W, wes, C, ces); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
+        o << "  { GateSum s = gate_" << g << "(); for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], s.v[c]); }\n";
     o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t] = gl::canon(acc[c]);\n}\n";
     return o.str();
 }
@@ -333,6 +345,7 @@ static hipError_t load_unit(GateUnit &u) {
     size_t bytes = 0;
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_apow), &bytes, u.module, "g_apow");
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_pih), &bytes, u.module, "g_pih");
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_par), &bytes, u.module, "g_par");
     return e;
 }
 
@@ -532,11 +545,14 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
         }
     }
     const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
+    const uint64_t par[6] = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es};
     for (const GateUnit &u : k->units) {
         // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
         hipError_t e = hipMemcpyAsync(u.d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         e = hipMemcpyAsync(u.d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(u.d_par, par, sizeof par, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
     }
     hipError_t e = hipStreamSynchronize(stream);
