@@ -42,6 +42,9 @@ namespace {
 const char *const GL_FIELD_SRC =
 #include "build/gl_field_src.inc"
     ;
+const char *const GL_JIT_FIELD_SRC =
+#include "build/gate_jit_field_src.inc"
+    ;
 
 enum : uint16_t { GP_LOAD_WIRE, GP_LOAD_CONST, GP_LOAD_PI, GP_LOAD_IMM, GP_ADD, GP_SUB, GP_MUL, GP_EMIT, GP_MULK, GP_ACC, GP_ACCR };
 constexpr uint32_t MAX_REGS = 64, MAX_CH = 4;
@@ -76,6 +79,10 @@ struct GateUnit {
     uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
     uint64_t *d_pih = nullptr;  // the module's g_pih[4]
     uint64_t *d_par = nullptr;  // the module's g_par[6]: where the LDE lives
+    // Constraints the generated code emits with a known constant added (the peephole pass below): bias[i] lists (k, b) for the
+    // i-th gate of the unit — the code accumulates alpha^k (c_k + b), the launch supplies sum alpha^k b in g_bias to take off.
+    std::vector<std::vector<std::pair<uint32_t, uint64_t>>> bias;
+    uint64_t *d_bias = nullptr;  // the module's g_bias[num_challenges][gates of the unit], if any gate has a bias
     std::string error;
 };
 
@@ -132,17 +139,140 @@ bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const u
     return true;
 }
 
-// Source of one unit: the device functions of `unit_gates` and the kernel that calls them.
+// ---- peephole pass ---------------------------------------------------------------------------------------------------------
+// The programs are executed as written by the interpreter (plonk.hip) and by the oracles; the compiled kernel may compute the same
+// field values more cheaply. Two rewrites, both found by following each register read back to the instruction that wrote the value
+// (the programs are straight-line code):
+//   1. ADD / SUB whose other operand is a LOAD_IMM below 2^32 become gl::add_small / gl::sub_small (two vector instructions instead of
+//      four / five; adding or subtracting zero becomes a copy).
+//   2. The range check of a base-4 limb, as every emitter writes it: t = a * b; u = t + 2; c = t * u; EMIT c, with t, u, c read nowhere
+//      else. t (t + 2) = (t + 1)^2 - 1, and t + 1 is a * b + 1 at the price of a * b (gl::mul_add_small), so the ADD disappears: the
+//      code emits (t + 1)^2 and the constant 1 it is too large by is taken off ONCE per gate and challenge, as sum of alpha^k over
+//      those constraints (GateUnit::bias, g_bias) — wave-uniform, computed by the host with the powers of alpha.
+//   3. Any other MUL / ADD / SUB with a LOAD_IMM operand reads the constant's halves as scalar operands (gl::mul_k, gl::add_k), and a
+//      LOAD_IMM whose readers all do is not generated (two v_mov each).
+// On the ed25519 table (1 838 such limbs among 21 467 operations) the executed vector instructions per LDE point go from 150 k to
+// 135 k. PLONKY2_HIP_JIT_PEEPHOLE=0 turns the pass off (A/B, and the tests that hold one form against the other).
+struct Peep {
+    enum Kind : uint8_t { PLAIN, ADD_SMALL, SUB_SMALL, COPY, MUL_ADD1, SQUARE, MUL_K, ADD_K, SKIP } kind = PLAIN;
+    uint32_t src = 0;      // ADD_SMALL / SUB_SMALL / COPY / SQUARE / MUL_K / ADD_K: the register read
+    int src_def = -1;      // ... and the instruction that wrote it
+    uint64_t k = 0;        // ADD_SMALL / SUB_SMALL / MUL_K / ADD_K: the constant
+    uint64_t bias = 0;     // EMIT: what the emitted value is too large by
+};
+
+static bool peephole_enabled() {
+    const char *e = getenv("PLONKY2_HIP_JIT_PEEPHOLE");
+    return !(e && e[0] == '0');
+}
+
+static std::vector<Peep> peephole(const uint16_t *instrs, uint32_t ps, uint32_t pl, const uint64_t *imms, uint32_t num_imms) {
+    std::vector<Peep> out(pl);
+    if (!peephole_enabled()) return out;
+    // reaching definitions: which instruction wrote the value an operand reads (-1: none), and who reads each value
+    std::vector<int> def_a(pl, -1), def_b(pl, -1);
+    std::vector<std::vector<uint32_t>> uses(pl);
+    int last[MAX_REGS];
+    for (uint32_t r = 0; r < MAX_REGS; r++) last[r] = -1;
+    auto op_of = [&](uint32_t i) { return instrs[4 * (ps + i)]; };
+    auto fld = [&](uint32_t i, int f) { return instrs[4 * (ps + i) + f]; };
+    for (uint32_t i = 0; i < pl; i++) {
+        const uint16_t op = op_of(i);
+        const bool reads_a = op == GP_ADD || op == GP_SUB || op == GP_MUL || op == GP_EMIT || op == GP_MULK || op == GP_ACC;
+        const bool reads_b = op == GP_ADD || op == GP_SUB || op == GP_MUL;
+        if (reads_a && (def_a[i] = last[fld(i, 2) & (MAX_REGS - 1)]) >= 0) uses[def_a[i]].push_back(i);
+        if (reads_b && (def_b[i] = last[fld(i, 3) & (MAX_REGS - 1)]) >= 0) uses[def_b[i]].push_back(i);
+        if (op != GP_EMIT && op != GP_ACC) last[fld(i, 1) & (MAX_REGS - 1)] = (int)i;  // ACC's dst names an accumulator
+    }
+    auto small_imm = [&](int d, uint64_t *v) {
+        if (d < 0 || op_of(d) != GP_LOAD_IMM || fld(d, 2) >= num_imms) return false;
+        *v = imms[fld(d, 2)] % glh::P;
+        return *v <= 0xFFFFFFFFull;
+    };
+    for (uint32_t i = 0; i < pl; i++) {
+        const uint16_t op = op_of(i);
+        uint64_t v = 0;
+        if (op == GP_ADD || op == GP_SUB) {
+            const bool b_small = small_imm(def_b[i], &v);
+            const bool a_small = !b_small && op == GP_ADD && small_imm(def_a[i], &v);
+            if (!b_small && !a_small) continue;
+            const int other = b_small ? def_a[i] : def_b[i];
+            if (other < 0) continue;  // read before any write: left to the generator's own check
+            out[i].kind = v == 0 ? Peep::COPY : op == GP_ADD ? Peep::ADD_SMALL : Peep::SUB_SMALL;
+            out[i].src = fld(i, b_small ? 2 : 3) & (MAX_REGS - 1);
+            out[i].src_def = other;
+            out[i].k = v;
+        }
+    }
+    for (uint32_t m2 = 0; m2 < pl; m2++) {
+        if (op_of(m2) != GP_MUL || def_a[m2] < 0 || def_b[m2] < 0) continue;
+        for (int swap = 0; swap < 2; swap++) {
+            const int m1 = swap ? def_b[m2] : def_a[m2], ad = swap ? def_a[m2] : def_b[m2];
+            if (m1 == ad || op_of(m1) != GP_MUL || op_of(ad) != GP_ADD) continue;
+            // the ADD is t + 2 with t the very value of m1
+            uint64_t v = 0;
+            const bool t_is_a = def_a[ad] == m1 && small_imm(def_b[ad], &v) && v == 2;
+            const bool t_is_b = !t_is_a && def_b[ad] == m1 && small_imm(def_a[ad], &v) && v == 2;
+            if (!t_is_a && !t_is_b) continue;
+            if (uses[m1].size() != 2 || uses[ad].size() != 1 || uses[m2].size() != 1) continue;  // (m1: the ADD and m2; each once)
+            const uint32_t e = uses[m2][0];
+            if (op_of(e) != GP_EMIT || def_a[m1] < 0 || def_b[m1] < 0) continue;
+            if (out[m1].kind != Peep::PLAIN || out[m2].kind != Peep::PLAIN) continue;  // m1 already rewritten as another limb's square
+            out[m1].kind = Peep::MUL_ADD1;
+            out[ad].kind = Peep::SKIP;
+            out[m2].kind = Peep::SQUARE;
+            out[m2].src = fld(m1, 1) & (MAX_REGS - 1);
+            out[m2].src_def = m1;
+            out[e].bias = 1;
+            break;
+        }
+    }
+    // 3. what is left of MUL / ADD / SUB with a LOAD_IMM operand takes the constant as a scalar operand (gl::mul_k, gl::add_k; x - K is
+    //    x + (p - K)), and a LOAD_IMM that nothing reads any more is not generated.
+    auto any_imm = [&](int d, uint64_t *v) {
+        if (d < 0 || op_of(d) != GP_LOAD_IMM || fld(d, 2) >= num_imms) return false;
+        *v = imms[fld(d, 2)] % glh::P;
+        return true;
+    };
+    for (uint32_t i = 0; i < pl; i++) {
+        const uint16_t op = op_of(i);
+        if ((op != GP_MUL && op != GP_ADD && op != GP_SUB) || out[i].kind != Peep::PLAIN || def_a[i] < 0 || def_b[i] < 0) continue;
+        uint64_t v = 0;
+        const bool b_imm = any_imm(def_b[i], &v);
+        const bool a_imm = !b_imm && op != GP_SUB && any_imm(def_a[i], &v);
+        if (!b_imm && !a_imm) continue;
+        out[i].kind = op == GP_MUL ? Peep::MUL_K : Peep::ADD_K;
+        out[i].src = fld(i, b_imm ? 2 : 3) & (MAX_REGS - 1);
+        out[i].src_def = b_imm ? def_a[i] : def_b[i];
+        out[i].k = op == GP_SUB ? (glh::P - v) % glh::P : v;
+    }
+    for (uint32_t d = 0; d < pl; d++) {
+        if (op_of(d) != GP_LOAD_IMM) continue;
+        bool read = false;
+        for (uint32_t u : uses[d]) {
+            const Peep::Kind kd = out[u].kind;
+            const bool constant_only = kd == Peep::ADD_SMALL || kd == Peep::SUB_SMALL || kd == Peep::COPY || kd == Peep::MUL_K || kd == Peep::ADD_K;
+            read |= !(kd == Peep::SKIP || (constant_only && out[u].src_def != (int)d));
+        }
+        if (!read) out[d].kind = Peep::SKIP;  // (also a LOAD_IMM nothing ever read)
+    }
+    return out;
+}
+
+// Source of one unit: the device functions of `unit_gates` and the kernel that calls them. `bias`: per gate of the unit, the
+// constraints emitted with a constant added.
 static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, const std::vector<uint32_t> &unit_gates,
                                    const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
-                                   std::string *error) {
+                                   std::vector<std::vector<std::pair<uint32_t, uint64_t>>> *bias, std::string *error) {
     std::ostringstream o;
-    o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n";
+    o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n" << GL_JIT_FIELD_SRC << "\n";
+    o << "#define NGU " << unit_gates.size() << "\n";
+    bias->assign(unit_gates.size(), {});
     o << "#define NCH " << nch << "\n#define NGC " << ngc << "\n";
     o << "struct GateSum { uint64_t v[NCH]; };\n";
     // alpha powers and the public-inputs hash live at link-time-constant addresses, so every read is a scalar
     // load (a pointer ARGUMENT of a non-inlined device function arrives in VGPRs and would be read per lane)
-    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n";
+    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n";
     // Where the LDE lives: {wires, row stride, element stride, constants/sigmas, row stride, element stride} (strides in elements), as
     // link-time-constant scalars for the same reason: the element stride that every wire load multiplies by is then a scalar, not a
     // vector register of a function argument. (Measured in round 5, profiles/r05_quotient_codegen_ab.jsonl: going further — a BUFFER
@@ -152,13 +282,15 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     o << "__constant__ uint64_t g_par[6];\n"
          "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
          "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
-    for (uint32_t g : unit_gates) {
+    for (size_t gi = 0; gi < unit_gates.size(); gi++) {
+        const uint32_t g = unit_gates[gi];
         const uint32_t *d = gates + 6 * g;
         const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
         if (ps + pl > num_instrs || si >= num_selectors || gs > ge) {
             *error = "gate descriptor out of range";
             return "";
         }
+        const std::vector<Peep> peep = peephole(instrs, ps, pl, imms, num_imms);
         o << "static __device__ __noinline__ GateSum gate_" << g << "() {\n"
              "  const uint64_t t_ = (uint64_t)blockIdx.x * 128u + threadIdx.x;\n"   // the kernel runs 128 lanes per block
              "  const uint64_t* W = (const uint64_t*)g_par[0] + t_ * g_par[1]; const uint64_t wes = g_par[2];\n"
@@ -191,6 +323,25 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
         for (uint32_t pc = ps; pc < ps + pl; pc++) {
             const uint16_t op = instrs[4 * pc], dst = instrs[4 * pc + 1] & (MAX_REGS - 1), a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
             const uint32_t ra = a & (MAX_REGS - 1), rb = b & (MAX_REGS - 1);
+            const Peep &pp = peep[pc - ps];
+            if (pp.kind != Peep::PLAIN && (op == GP_ADD || op == GP_SUB || op == GP_MUL)) {
+                if (!used[ra] || !used[rb]) {
+                    *error = "register read before any write";
+                    return "";
+                }
+                switch (pp.kind) {
+                    case Peep::ADD_SMALL: o << "  r" << dst << " = gl::add_small<" << pp.k << "u>(r" << pp.src << ");\n"; break;
+                    case Peep::SUB_SMALL: o << "  r" << dst << " = gl::sub_small<" << pp.k << "u>(r" << pp.src << ");\n"; break;
+                    case Peep::COPY: o << "  r" << dst << " = r" << pp.src << ";\n"; break;
+                    case Peep::MUL_ADD1: o << "  r" << dst << " = gl::mul_add_small<1>(r" << ra << ", r" << rb << ");\n"; break;
+                    case Peep::SQUARE: o << "  r" << dst << " = gl::mul(r" << pp.src << ", r" << pp.src << ");\n"; break;
+                    case Peep::MUL_K: o << "  r" << dst << " = gl::mul_k<0x" << std::hex << pp.k << std::dec << "ull>(r" << pp.src << ");\n"; break;
+                    case Peep::ADD_K: o << "  r" << dst << " = gl::add_k<0x" << std::hex << pp.k << std::dec << "ull>(r" << pp.src << ");\n"; break;
+                    default: break;  // SKIP: the value is read by nothing the generated code still contains
+                }
+                continue;
+            }
+            if (pp.kind == Peep::SKIP && op == GP_LOAD_IMM) continue;  // every reader takes the constant as an operand
             switch (op) {
                 case GP_LOAD_WIRE: o << "  r" << dst << " = W[" << a << " * wes];\n"; break;
                 case GP_LOAD_CONST: o << "  r" << dst << " = C[" << (num_selectors + a) << " * ces];\n"; break;
@@ -218,6 +369,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                         return "";
                     }
                     o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga[c], r" << ra << ", g_apow[c * NGC + " << k << "]);\n";  // k < ngc: validated
+                    if (pp.bias) (*bias)[gi].push_back({k, pp.bias});
                     k++;
                     break;
                 case GP_ACC: {  // acc[dst] += r[a] * imm[b]: two 32x32+64 multiply-adds, no modular step
@@ -256,7 +408,11 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
                 default: *error = "unknown opcode"; return "";
             }
         }
-        o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::dot_finish(ga[c]));\n  return out;\n}\n";
+        if ((*bias)[gi].empty())
+            o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::dot_finish(ga[c]));\n  return out;\n}\n";
+        else
+            o << "  GateSum out;\n  for (int c = 0; c < NCH; c++) out.v[c] = gl::mul(filt, gl::sub(gl::dot_finish(ga[c]), g_bias[c * NGU + " << gi
+              << "]));\n  return out;\n}\n";
     }
     // `accumulate`: the output already holds the sum of the units that ran before this one
     o << "extern \"C\" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
@@ -346,6 +502,9 @@ static hipError_t load_unit(GateUnit &u) {
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_apow), &bytes, u.module, "g_apow");
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_pih), &bytes, u.module, "g_pih");
     if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_par), &bytes, u.module, "g_par");
+    bool biased = false;
+    for (const auto &b : u.bias) biased |= !b.empty();
+    if (e == hipSuccess && biased) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_bias), &bytes, u.module, "g_bias");
     return e;
 }
 
@@ -382,7 +541,8 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
     std::vector<std::string> cache_paths;
     for (GateUnit &u : k->units) {
         std::sort(u.gates.begin(), u.gates.end());
-        u.source = generate_source(instrs, num_instrs, gates, u.gates, imms, num_imms, num_selectors, num_gate_constraints, num_challenges, error);
+        u.source = generate_source(instrs, num_instrs, gates, u.gates, imms, num_imms, num_selectors, num_gate_constraints, num_challenges, &u.bias,
+                                   error);
         if (u.source.empty()) {
             delete k;
             return nullptr;
@@ -546,10 +706,27 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
     }
     const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
     const uint64_t par[6] = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es};
-    for (const GateUnit &u : k->units) {
+    std::vector<std::vector<uint64_t>> unit_bias(k->units.size());
+    for (size_t ui = 0; ui < k->units.size(); ui++) {
+        const GateUnit &u = k->units[ui];
+        if (!u.d_bias) continue;
+        unit_bias[ui].assign((size_t)k->num_challenges * u.gates.size(), 0);
+        for (uint32_t c = 0; c < k->num_challenges; c++)
+            for (size_t gi = 0; gi < u.gates.size(); gi++) {
+                uint64_t b = 0;
+                for (const auto &kb : u.bias[gi]) b = glh::add(b, glh::mul(apow[(size_t)c * k->num_constraints + kb.first], kb.second));
+                unit_bias[ui][(size_t)c * u.gates.size() + gi] = b;
+            }
+    }
+    for (size_t ui = 0; ui < k->units.size(); ui++) {
+        const GateUnit &u = k->units[ui];
         // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
         hipError_t e = hipMemcpyAsync(u.d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
+        if (u.d_bias) {
+            e = hipMemcpyAsync(u.d_bias, unit_bias[ui].data(), unit_bias[ui].size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+            if (e != hipSuccess) return e;
+        }
         e = hipMemcpyAsync(u.d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         e = hipMemcpyAsync(u.d_par, par, sizeof par, hipMemcpyHostToDevice, stream);

@@ -131,6 +131,9 @@ class GateProgram:
         """Turn the programs into a kernel specialised to this circuit (hiprtc, once per circuit)."""
         k = ctypes.c_void_p()
         n_instr = self._instrs.size // 4
+        if self.kernel:
+            _lib.load().gl_gate_kernel_destroy(self.kernel)
+            self.kernel = None
         _lib.call("gl_gate_kernel_build", self._instrs, n_instr, self._descs, self._descs.size // 6, self._imms,
                   0 if self._imms is None else self._imms.size, self.num_selectors, num_gate_constraints, num_challenges, ctypes.byref(k))
         self.kernel = k.value

@@ -137,6 +137,77 @@ def test_reference_symbol_equals_the_generic_entry_point(gpu):
     assert (out.download().reshape(2, -1) == got).all()
 
 
+EDGE_VALUES = [0, 1, 2, 3, 4, 5, (1 << 32) - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, (1 << 63) - 1, 1 << 63, P - 4, P - 3, P - 2, P - 1]
+NON_CANONICAL = [P, P + 1, P + 2, P + 3, (1 << 64) - 3, (1 << 64) - 2, (1 << 64) - 1]
+
+
+def _generic(gpu, inst, bufs, log_len, kernel=None, prog=None, pih=None):
+    import ctypes
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib, ed25519_circuit as ed
+
+    a, b, g = (np.ascontiguousarray(inst[k]) for k in ("alphas", "betas", "gammas"))
+    h = np.array(pih if pih is not None else ed.REFERENCE_PUBLIC_INPUTS_HASH, dtype=np.uint64)
+    work = pg.DeviceBuffer(gpu, 2 * inst["n_ext"]) if kernel else None
+    args = _lib.GlQuotientArgs(bufs["wires"].ptr, bufs["cs"].ptr, bufs["zs"].ptr, ed.NUM_WIRES, ed.CONSTANTS_SIGMAS_LEAF_LEN,
+                               ed.ZS_PARTIAL_PRODUCTS_LEAF_LEN, bufs["k_is"].ptr, None, b.ctypes.data, g.ctypes.data, a.ctypes.data,
+                               ed.NUM_CONSTANTS, ed.NUM_ROUTED_WIRES, 2, ed.NUM_GATE_CONSTRAINTS, log_len, ed.RATE_BITS,
+                               ed.QUOTIENT_DEGREE_FACTOR, ed.COSET_SHIFT, ctypes.pointer(prog.struct) if prog is not None and not kernel else None, 0,
+                               kernel, h.ctypes.data if kernel else None, work.ptr if kernel else None)
+    out = pg.DeviceBuffer(gpu, 2 * inst["n_ext"])
+    _lib.call("gl_compute_quotient_polys", ctypes.byref(args), out.ptr, gpu.ptr)
+    res = out.download().reshape(2, -1)
+    if work is not None:
+        work.free()
+    out.free()
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["edges", "edges among random", "non-canonical"])
+def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_rare_paths(gpu, which):
+    """The run-time compiled kernel computes l - 3, t + 2, b - 1 ... with two-instruction forms whose wrap correction sits behind a
+    branch, and a base-4 limb's range check as (l (l - 3) + 1)^2 with the constant taken off per gate (csrc/gate_jit.hip, peephole
+    pass). On an LDE those wraps need a wire within 3 of zero: never. Here the leaves ARE such values — every wire and constant drawn
+    from {0..5, 2^32 +- 1, 2^63, p - 4..p - 1}, the same sprinkled into random leaves (so that some lanes of a wave take a correction
+    and others do not), and representatives at and above p — and the compiled kernel, with the pass and without it, gives what the
+    interpreter gives, which executes the programs as written; on the canonical leaves, also what the oracle's gates give."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import ed25519_circuit as ed, gate_program as gp
+
+    log_len = 4
+    inst = random_instance(log_len, seed=9300)
+    rng = np.random.default_rng(77)
+    edge = np.array(EDGE_VALUES + (NON_CANONICAL if which == "non-canonical" else []), dtype=np.uint64)
+    for key in ("wires", "cs"):
+        drawn = edge[rng.integers(0, edge.size, size=inst[key].shape)]
+        if which == "edges among random":
+            inst[key] = np.where(rng.random(inst[key].shape) < 0.02, drawn, inst[key])
+        else:
+            inst[key] = drawn
+    got, bufs = run_symbol(gpu, inst)  # the compiled-in table, compiled with the pass
+    pool = gp.ImmediatePool()
+    prog = pg.GateProgram(gpu, [gp.build_gate(k, p, pool) for k, p in ed.GATES], ed.SELECTOR_INDICES, ed.GROUPS,
+                          ed.REFERENCE_PUBLIC_INPUTS_HASH, immediates=pool.values)
+    interpreted = _generic(gpu, inst, bufs, log_len, prog=prog)
+    assert (interpreted == got).all()
+    if which != "non-canonical":
+        assert (got == np.array(oracle_quotient(inst, ed.REFERENCE_PUBLIC_INPUTS_HASH), dtype=np.uint64)).all()
+    os.environ["PLONKY2_HIP_JIT_PEEPHOLE"] = "0"
+    try:
+        prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
+    finally:
+        del os.environ["PLONKY2_HIP_JIT_PEEPHOLE"]
+    src = prog.kernel_source()
+    assert "gl::mul_add_small<" not in src and "gl::sub_small<" not in src and "g_bias[c" not in src
+    assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all()
+    prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
+    src = prog.kernel_source()
+    assert src.count("gl::mul_add_small<1>(") == 1838 and src.count("gl::sub_small<3u>(") == 1838 and "g_bias[c * NGU + " in src
+    assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all()
+
+
 def _poly_at(coeffs, x):
     """sum_j coeffs[j] x^j mod p with vectorised numpy field arithmetic (tools/synth_circuit.py), no oracle arithmetic involved"""
     import synth_circuit as sc

@@ -1,0 +1,32 @@
+#!/bin/bash
+# round 5: the gate kernels with their wire loads replaced by arithmetic on the row index (experiment knob JITX_NOLOAD; wrong results,
+# same field arithmetic, nothing the compiler can merge) against the real ones; FETCH_SIZE of the real ones
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05qmem2; rm -rf $O; mkdir -p $O
+for rep in 1 2; do
+echo "baseline:  $(timeout 400 python3 tools/bench_quotient_ed25519.py 18 7 0 2>/dev/null | tail -n 1 | grep -o '"compiled_ms": [0-9.]*')" | tee -a $O/summary.txt
+echo "noload: $(JITX_NOLOAD=1 PLONKY2_HIP_KERNEL_CACHE=/tmp/kc_noload PLONKY2_HIP_JIT_FORK=1 timeout 600 python3 tools/bench_quotient_ed25519.py 18 7 0 2>/dev/null | tail -n 1 | grep -o '"hiprtc_compile_s": [0-9.]*\|"compiled_ms": [0-9.]*' | tr '\n' ' ')" | tee -a $O/summary.txt
+done
+for db in 14 15 16 17; do
+echo "2^$db rows: $(timeout 400 python3 tools/bench_quotient_ed25519.py $db 7 0 2>/dev/null | tail -n 1 | grep -o '"compiled_ms": [0-9.]*')" | tee -a $O/summary.txt
+done
+cd /tmp
+pmc() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$n -- python3 $R/tools/bench_quotient_ed25519.py 18 2 0 > $O/pmc_$n.log 2>&1; }
+pmc fetch FETCH_SIZE
+pmc tcc TCC_HIT_sum TCC_MISS_sum
+pmc ea TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum
+cd $R
+python3 - $O <<'PY' | tee -a $O/summary.txt
+import csv, glob, sys, collections
+c = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(sys.argv[1] + "/pmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "gate_constraints" in r["Kernel_Name"]:
+            c[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+for k in sorted(c):
+    d = c[k]; per_launch = sum(d.values()) / len(d)
+    print(k, "per unit launch", round(per_launch), "per quotient (x8)", round(per_launch * 8), "launches seen", len(d))
+PY
+find $O -name "*.csv" -size +6M -delete
