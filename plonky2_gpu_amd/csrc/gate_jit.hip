@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <algorithm>
+#include <map>
 #include <sstream>
 #include <thread>
 #include <vector>
@@ -259,11 +260,340 @@ static std::vector<Peep> peephole(const uint16_t *instrs, uint32_t ps, uint32_t 
     return out;
 }
 
+// ---- fused units --------------------------------------------------------------------------------------------------------------
+// One gate at a time, every gate loads the wires it reads and computes what it needs from them — and the gates of a circuit read the
+// same wires and need the same things: the ten U32AddMany gates of the ed25519 table, U32Arithmetic, U32Subtraction and the range
+// checks all range-check the limbs that sit in wires 60..233. Value numbering over the whole table leaves 1 861 of 5 107
+// multiplications, 1 179 of 2 822 additions, 977 of 2 653 subtractions and 234 of 3 204 wire loads; and the loads are not free: a
+// row's 1.9 KB of wires times the rows in flight does not stay in L2 between two gates, the gate kernels fetched 40 GB per quotient
+// for a 3.9 GB LDE and ran 13.3 ms where the same arithmetic without loads runs 9.6 (profiles/r05_quotient_loads_experiment.txt).
+//
+// So the gates of a unit are generated as ONE straight-line function over a common value graph:
+//   * every operation becomes a node keyed by what it computes (kind, operand nodes, constants; ADD and MUL with sorted operands;
+//     an ACCR is the node "sum of weight_i * node_i"), so that two gates asking for the same value share the node;
+//   * what stays per gate is where its constraints go: the alpha-accumulators (gl::DotAcc per challenge) and the list
+//     (constraint index k, node);
+//   * the code is emitted in the order of the first gate's program, then the second's ..., skipping what exists — but every value is
+//     PUSHED to its consumers the moment it is computed: an EMIT of any gate of the unit that takes it is issued right there
+//     (its own k, its own accumulator), a term of an ACCR sum is accumulated right there, and an operation whose operands are now
+//     all there is computed (and pushed in turn). A limb's range check is computed once and lands in four gates' accumulators
+//     within a few instructions; nothing is kept for a later gate except the running sums.
+// What bounds a unit is the registers of those per-gate accumulators (18 per gate with two challenges), hence few gates per unit
+// (PLONKY2_HIP_JIT_FUSE_GATES, default 4; units are runs of consecutive gates of the circuit: the gate list is sorted by kind).
+// PLONKY2_HIP_JIT_FUSE=0 generates one function per gate as before (A/B; tests hold the two against each other).
+static bool fuse_enabled() {
+    const char *e = getenv("PLONKY2_HIP_JIT_FUSE");
+    return !(e && e[0] == '0');
+}
+
+// waves per SIMD the fused kernels are compiled for (their register budget: 128 VGPRs at 4, 168 at 3, 256 at 2)
+static uint32_t fuse_waves() {
+    if (const char *e = getenv("PLONKY2_HIP_JIT_WAVES")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 8) return (uint32_t)v;
+    }
+    return 4;
+}
+
+static uint32_t fuse_gates_per_unit() {
+    if (const char *e = getenv("PLONKY2_HIP_JIT_FUSE_GATES")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 64) return (uint32_t)v;
+    }
+    return 4;
+}
+
+struct FNode {
+    enum Kind : uint8_t { WIRE, CONST, PI, IMM, ADD, SUB, MUL, MULK, ADD_SMALL, SUB_SMALL, MUL_ADD1, MUL_K, ADD_K, LIN } kind;
+    uint32_t a = ~0u, b = ~0u;
+    uint64_t k = 0;
+    std::vector<std::pair<uint32_t, uint64_t>> terms;  // LIN: (node, weight < 2^32)
+};
+
+struct FGraph {
+    std::vector<FNode> nodes;
+    std::map<std::string, uint32_t> index;
+    uint32_t intern(const FNode &n) {
+        std::string key(1, (char)n.kind);
+        auto put = [&](uint64_t v) { key.append(reinterpret_cast<const char *>(&v), sizeof v); };
+        put(n.a), put(n.b), put(n.k);
+        for (const auto &t : n.terms) put(t.first), put(t.second);
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        nodes.push_back(n);
+        index.emplace(std::move(key), (uint32_t)nodes.size() - 1);
+        return (uint32_t)nodes.size() - 1;
+    }
+    uint32_t make(FNode::Kind kind, uint32_t a = ~0u, uint32_t b = ~0u, uint64_t k = 0) {
+        FNode n;
+        n.kind = kind, n.a = a, n.b = b, n.k = k;
+        if ((kind == FNode::ADD || kind == FNode::MUL || kind == FNode::MUL_ADD1) && n.a > n.b) std::swap(n.a, n.b);
+        return intern(n);
+    }
+};
+
+struct FEmit {
+    uint32_t k, node;
+};
+
+// One gate's program -> nodes of `g`, its EMITs in `emits`, the constants its emitted values are too large by in `bias`.
+static bool fuse_gate(FGraph &g, const uint16_t *instrs, uint32_t ps, uint32_t pl, const uint64_t *imms, uint32_t num_imms,
+                      std::vector<FEmit> *emits, std::vector<std::pair<uint32_t, uint64_t>> *bias, std::string *error) {
+    const std::vector<Peep> peep = peephole(instrs, ps, pl, imms, num_imms);
+    uint32_t reg[MAX_REGS];
+    for (uint32_t r = 0; r < MAX_REGS; r++) reg[r] = ~0u;
+    std::vector<std::pair<uint32_t, uint64_t>> acc[4];
+    bool acc_used[4] = {};
+    unsigned __int128 acc_bound[4] = {0, 0, 0, 0};
+    uint32_t k = 0;
+    for (uint32_t pc = ps; pc < ps + pl; pc++) {
+        const uint16_t op = instrs[4 * pc], dst = instrs[4 * pc + 1] & (MAX_REGS - 1), a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
+        const uint32_t ra = a & (MAX_REGS - 1), rb = b & (MAX_REGS - 1);
+        const Peep &pp = peep[pc - ps];
+        switch (op) {
+            case GP_LOAD_WIRE: reg[dst] = g.make(FNode::WIRE, a); break;
+            case GP_LOAD_CONST: reg[dst] = g.make(FNode::CONST, a); break;
+            case GP_LOAD_PI: reg[dst] = g.make(FNode::PI, a & 3); break;
+            case GP_LOAD_IMM:
+                if (a >= num_imms) {
+                    *error = "LOAD_IMM index out of range";
+                    return false;
+                }
+                reg[dst] = g.make(FNode::IMM, ~0u, ~0u, imms[a] % glh::P);
+                break;
+            case GP_ADD:
+            case GP_SUB:
+            case GP_MUL:
+                if (reg[ra] == ~0u || reg[rb] == ~0u) {
+                    *error = "register read before any write";
+                    return false;
+                }
+                switch (pp.kind) {
+                    case Peep::PLAIN: reg[dst] = g.make(op == GP_ADD ? FNode::ADD : op == GP_SUB ? FNode::SUB : FNode::MUL, reg[ra], reg[rb]); break;
+                    case Peep::ADD_SMALL: reg[dst] = g.make(FNode::ADD_SMALL, reg[pp.src], ~0u, pp.k); break;
+                    case Peep::SUB_SMALL: reg[dst] = g.make(FNode::SUB_SMALL, reg[pp.src], ~0u, pp.k); break;
+                    case Peep::COPY: reg[dst] = reg[pp.src]; break;
+                    case Peep::MUL_ADD1: reg[dst] = g.make(FNode::MUL_ADD1, reg[ra], reg[rb]); break;
+                    case Peep::SQUARE: reg[dst] = g.make(FNode::MUL, reg[pp.src], reg[pp.src]); break;
+                    case Peep::MUL_K: reg[dst] = g.make(FNode::MUL_K, reg[pp.src], ~0u, pp.k); break;
+                    case Peep::ADD_K: reg[dst] = g.make(FNode::ADD_K, reg[pp.src], ~0u, pp.k); break;
+                    case Peep::SKIP: break;  // t + 2 of a range check: read by nothing that is still generated
+                }
+                break;
+            case GP_EMIT:
+                if (reg[ra] == ~0u) {
+                    *error = "register read before any write";
+                    return false;
+                }
+                emits->push_back({k, reg[ra]});
+                if (pp.bias) bias->push_back({k, pp.bias});
+                k++;
+                break;
+            case GP_ACC: {
+                const uint32_t q = instrs[4 * pc + 1] & 3;
+                if (reg[ra] == ~0u || b >= num_imms || imms[b] > 0xFFFFFFFFull) {
+                    *error = "ACC: register read before any write, or the immediate is missing / not below 2^32";
+                    return false;
+                }
+                acc_bound[q] += (unsigned __int128)imms[b] * 0xFFFFFFFFull;
+                if (acc_bound[q] >> 63) {
+                    *error = "ACC: the accumulator could reach 2^63 before its ACCR";
+                    return false;
+                }
+                acc[q].push_back({reg[ra], imms[b]});
+                acc_used[q] = true;
+                break;
+            }
+            case GP_ACCR: {
+                const uint32_t q = a & 3;
+                if (!acc_used[q]) {
+                    *error = "ACCR of an accumulator nothing was added to";
+                    return false;
+                }
+                FNode n;
+                n.kind = FNode::LIN;
+                n.terms = acc[q];
+                std::sort(n.terms.begin(), n.terms.end());
+                reg[dst] = g.intern(n);
+                acc[q].clear();
+                acc_bound[q] = 0;
+                break;
+            }
+            case GP_MULK:
+                if (reg[ra] == ~0u || b >= 96) {
+                    *error = "MULK: register read before any write, or shift >= 96";
+                    return false;
+                }
+                reg[dst] = g.make(FNode::MULK, reg[ra], ~0u, b);
+                break;
+            default: *error = "unknown opcode"; return false;
+        }
+    }
+    return true;
+}
+
+// The fused function of a unit, as statements of the kernel's body. `gate_emits[i]`: the EMITs of the unit's i-th gate.
+static void fuse_schedule(std::ostringstream &o, const FGraph &g, const std::vector<std::vector<FEmit>> &gate_emits, uint32_t num_selectors) {
+    const size_t n = g.nodes.size();
+    struct Cons {
+        uint8_t type;  // 0: node x; 1: EMIT of gate x, constraint y; 2: term y of LIN node x
+        uint32_t x, y;
+    };
+    // only what some EMIT depends on is generated
+    std::vector<char> needed(n, 0);
+    {
+        std::vector<uint32_t> st;
+        for (const auto &ge : gate_emits)
+            for (const FEmit &e : ge) st.push_back(e.node);
+        while (!st.empty()) {
+            const uint32_t v = st.back();
+            st.pop_back();
+            if (needed[v]) continue;
+            needed[v] = 1;
+            const FNode &nd = g.nodes[v];
+            if (nd.a != ~0u && nd.kind != FNode::WIRE && nd.kind != FNode::CONST && nd.kind != FNode::PI) st.push_back(nd.a);
+            if (nd.b != ~0u) st.push_back(nd.b);
+            for (const auto &t : nd.terms) st.push_back(t.first);
+        }
+    }
+    std::vector<std::vector<Cons>> cons(n);
+    std::vector<uint32_t> pending(n, 0);
+    for (uint32_t v = 0; v < n; v++) {
+        if (!needed[v]) continue;
+        const FNode &nd = g.nodes[v];
+        const bool leaf = nd.kind == FNode::WIRE || nd.kind == FNode::CONST || nd.kind == FNode::PI || nd.kind == FNode::IMM;
+        if (leaf) continue;
+        if (nd.kind == FNode::LIN) {
+            for (uint32_t t = 0; t < nd.terms.size(); t++) cons[nd.terms[t].first].push_back({2, v, t});
+            pending[v] = (uint32_t)nd.terms.size();
+            continue;
+        }
+        cons[nd.a].push_back({0, v, 0});
+        pending[v] = 1;
+        if (nd.b != ~0u && nd.b != nd.a) {
+            cons[nd.b].push_back({0, v, 0});
+            pending[v] = 2;
+        }
+    }
+    for (uint32_t gi = 0; gi < gate_emits.size(); gi++)
+        for (const FEmit &e : gate_emits[gi]) cons[e.node].push_back({1, gi, e.k});
+    std::vector<char> done(n, 0), lin_open(n, 0);
+    std::vector<uint32_t> work;
+    auto define = [&](uint32_t v) {
+        const FNode &nd = g.nodes[v];
+        o << "  const uint64_t v" << v << " = ";
+        switch (nd.kind) {
+            case FNode::WIRE: o << "W[" << nd.a << " * wes]"; break;
+            case FNode::CONST: o << "C[" << (num_selectors + nd.a) << " * ces]"; break;
+            case FNode::PI: o << "g_pih[" << nd.a << "]"; break;
+            case FNode::IMM: o << "0x" << std::hex << nd.k << std::dec << "ull"; break;
+            case FNode::ADD: o << "gl::add(v" << nd.a << ", v" << nd.b << ")"; break;
+            case FNode::SUB: o << "gl::sub(v" << nd.a << ", v" << nd.b << ")"; break;
+            case FNode::MUL: o << "gl::mul(v" << nd.a << ", v" << nd.b << ")"; break;
+            case FNode::MULK: o << "gl::mul_pow2<" << nd.k << ">(v" << nd.a << ")"; break;
+            case FNode::ADD_SMALL: o << "gl::add_small<" << nd.k << "u>(v" << nd.a << ")"; break;
+            case FNode::SUB_SMALL: o << "gl::sub_small<" << nd.k << "u>(v" << nd.a << ")"; break;
+            case FNode::MUL_ADD1: o << "gl::mul_add_small<1>(v" << nd.a << ", v" << nd.b << ")"; break;
+            case FNode::MUL_K: o << "gl::mul_k<0x" << std::hex << nd.k << std::dec << "ull>(v" << nd.a << ")"; break;
+            case FNode::ADD_K: o << "gl::add_k<0x" << std::hex << nd.k << std::dec << "ull>(v" << nd.a << ")"; break;
+            case FNode::LIN: o << "gl::fold96(l" << v << "l, l" << v << "h)"; break;
+        }
+        o << ";\n";
+    };
+    // compute v (its operands exist), hand it to its consumers, and go on with whatever that completes: depth first, so that a
+    // chain is followed to its EMIT before the next value is loaded
+    auto produce = [&](uint32_t first) {
+        work.push_back(first);
+        while (!work.empty()) {
+            const uint32_t v = work.back();
+            work.pop_back();
+            if (done[v]) continue;
+            done[v] = 1;
+            define(v);
+            const size_t mark = work.size();
+            for (const Cons &c : cons[v]) {
+                if (c.type == 1) {
+                    o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga" << c.x << "[c], v" << v << ", g_apow[c * NGC + " << c.y << "]);\n";
+                } else if (c.type == 2) {
+                    if (!lin_open[c.x]) {
+                        o << "  uint64_t l" << c.x << "l = 0, l" << c.x << "h = 0;\n";
+                        lin_open[c.x] = 1;
+                    }
+                    o << "  gj_acc(l" << c.x << "l, l" << c.x << "h, v" << v << ", " << g.nodes[c.x].terms[c.y].second << "u);\n";
+                    if (--pending[c.x] == 0) work.push_back(c.x);
+                } else if (--pending[c.x] == 0) {
+                    work.push_back(c.x);
+                }
+            }
+            std::reverse(work.begin() + (long)mark, work.end());  // first consumer first
+        }
+    };
+    // leaves in the order the gates' programs reach them: nodes are numbered in that order
+    for (uint32_t v = 0; v < n; v++) {
+        if (!needed[v] || done[v]) continue;
+        const FNode &nd = g.nodes[v];
+        const bool leaf = nd.kind == FNode::WIRE || nd.kind == FNode::CONST || nd.kind == FNode::PI || nd.kind == FNode::IMM;
+        if (leaf || pending[v] == 0) produce(v);
+    }
+}
+
+static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, const std::vector<uint32_t> &unit_gates,
+                                         const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
+                                         std::vector<std::vector<std::pair<uint32_t, uint64_t>>> *bias, std::string *error) {
+    std::ostringstream o;
+    o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n" << GL_JIT_FIELD_SRC << "\n";
+    o << "#define NGU " << unit_gates.size() << "\n#define NCH " << nch << "\n#define NGC " << ngc << "\n";
+    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n"
+         "__constant__ uint64_t g_par[6];\n"
+         "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
+         "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
+    bias->assign(unit_gates.size(), {});
+    FGraph graph;
+    std::vector<std::vector<FEmit>> gate_emits(unit_gates.size());
+    for (size_t gi = 0; gi < unit_gates.size(); gi++) {
+        const uint32_t *d = gates + 6 * unit_gates[gi];
+        const uint32_t si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
+        if (ps + pl > num_instrs || si >= num_selectors || gs > ge) {
+            *error = "gate descriptor out of range";
+            return "";
+        }
+        if (!fuse_gate(graph, instrs, ps, pl, imms, num_imms, &gate_emits[gi], &(*bias)[gi], error)) return "";
+    }
+    o << "extern \"C\" __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(" << fuse_waves() << ", " << fuse_waves()
+      << "))) void gate_constraints_kernel(const uint64_t* __restrict__ wires, uint64_t wrs, "
+         "uint64_t wes_, const uint64_t* __restrict__ cs, uint64_t crs, uint64_t ces_, uint64_t lde_size, uint64_t* __restrict__ out, int accumulate) {\n"
+         "  const uint64_t t_ = (uint64_t)blockIdx.x * 128u + threadIdx.x;\n  if (t_ >= lde_size) return;\n"
+         "  const uint64_t* W = (const uint64_t*)g_par[0] + t_ * g_par[1]; const uint64_t wes = g_par[2];\n"
+         "  const uint64_t* C = (const uint64_t*)g_par[3] + t_ * g_par[4]; const uint64_t ces = g_par[5];\n";
+    for (size_t gi = 0; gi < unit_gates.size(); gi++)
+        if (!gate_emits[gi].empty()) o << "  gl::DotAcc ga" << gi << "[NCH];  // gate_" << unit_gates[gi] << "\n";
+    fuse_schedule(o, graph, gate_emits, num_selectors);
+    o << "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = accumulate ? out[(uint64_t)c * lde_size + t_] : 0;\n";
+    for (size_t gi = 0; gi < unit_gates.size(); gi++) {
+        if (gate_emits[gi].empty()) continue;  // a gate without constraints (NoopGate) contributes nothing
+        const uint32_t *d = gates + 6 * unit_gates[gi];
+        const uint32_t row = d[0], si = d[1], gs = d[2], ge = d[3];
+        // compute_filter (gates/gate.rs:261-268)
+        o << "  {\n    const uint64_t s = C[" << si << " * ces];\n    uint64_t filt = 1;\n";
+        for (uint32_t i = gs; i < ge; i++)
+            if (i != row) o << "    filt = gl::mul(filt, gl::sub(" << i << "ull, s));\n";
+        if (num_selectors > 1) o << "    filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));\n";  // UNUSED_SELECTOR (selectors.rs:11)
+        if ((*bias)[gi].empty())
+            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::dot_finish(ga" << gi << "[c])));\n  }\n";
+        else
+            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::sub(gl::dot_finish(ga" << gi << "[c]), g_bias[c * NGU + "
+              << gi << "])));\n  }\n";
+    }
+    o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t_] = gl::canon(acc[c]);\n}\n";
+    return o.str();
+}
+
 // Source of one unit: the device functions of `unit_gates` and the kernel that calls them. `bias`: per gate of the unit, the
 // constraints emitted with a constant added.
 static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, const std::vector<uint32_t> &unit_gates,
                                    const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t ngc, uint32_t nch,
                                    std::vector<std::vector<std::pair<uint32_t, uint64_t>>> *bias, std::string *error) {
+    if (fuse_enabled()) return generate_fused_source(instrs, num_instrs, gates, unit_gates, imms, num_imms, num_selectors, ngc, nch, bias, error);
     std::ostringstream o;
     o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n" << GL_JIT_FIELD_SRC << "\n";
     o << "#define NGU " << unit_gates.size() << "\n";
@@ -508,6 +838,103 @@ static hipError_t load_unit(GateUnit &u) {
     return e;
 }
 
+// Which gates share a fused unit: a unit is opened by the first gate (in circuit order) that has none, and takes in, one at a time,
+// the gate that would recompute least — the largest share of its own operations (priced as vector instructions) already in the
+// unit's value graph — while that share is above a quarter, the unit has fewer than fuse_gates_per_unit() gates and its value graph
+// stays below 4 500 nodes (hiprtc's time grows faster than the function). Gates without constraints belong to no unit.
+static bool fuse_partition(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates, const uint64_t *imms,
+                           uint32_t num_imms, uint32_t num_selectors, std::vector<GateUnit> *units, std::string *error) {
+    FGraph graph;
+    std::vector<std::vector<uint32_t>> nodes_of(num_gates);
+    for (uint32_t g = 0; g < num_gates; g++) {
+        const uint32_t *d = gates + 6 * g;
+        if ((uint64_t)d[4] + d[5] > num_instrs || d[1] >= num_selectors || d[2] > d[3]) {
+            *error = "gate descriptor out of range";
+            return false;
+        }
+        std::vector<FEmit> emits;
+        std::vector<std::pair<uint32_t, uint64_t>> bias;
+        if (!fuse_gate(graph, instrs, d[4], d[5], imms, num_imms, &emits, &bias, error)) return false;
+        std::vector<uint32_t> st;
+        for (const FEmit &e : emits) st.push_back(e.node);
+        std::vector<uint32_t> &seen = nodes_of[g];
+        std::vector<char> mark(graph.nodes.size(), 0);
+        while (!st.empty()) {
+            const uint32_t v = st.back();
+            st.pop_back();
+            if (mark[v]) continue;
+            mark[v] = 1;
+            seen.push_back(v);
+            const FNode &nd = graph.nodes[v];
+            if (nd.a != ~0u && nd.kind != FNode::WIRE && nd.kind != FNode::CONST && nd.kind != FNode::PI) st.push_back(nd.a);
+            if (nd.b != ~0u) st.push_back(nd.b);
+            for (const auto &t : nd.terms) st.push_back(t.first);
+        }
+    }
+    auto price = [&](uint32_t v) -> uint64_t {
+        const FNode &nd = graph.nodes[v];
+        switch (nd.kind) {
+            case FNode::MUL: case FNode::MUL_ADD1: case FNode::MUL_K: return 12;
+            case FNode::ADD: case FNode::ADD_K: return 4;
+            case FNode::SUB: return 5;
+            case FNode::MULK: return 8;
+            case FNode::LIN: return 7 + 2 * nd.terms.size();
+            case FNode::IMM: case FNode::PI: return 0;
+            default: return 2;
+        }
+    };
+    const uint32_t per = fuse_gates_per_unit();
+    std::vector<char> assigned(num_gates, 0), in_unit(graph.nodes.size(), 0);
+    std::vector<uint64_t> unit_size;
+    for (uint32_t g = 0; g < num_gates; g++) {
+        if (assigned[g] || nodes_of[g].empty()) continue;
+        GateUnit u;
+        std::fill(in_unit.begin(), in_unit.end(), 0);
+        uint64_t unit_nodes = 0;
+        uint32_t next = g;
+        while (true) {
+            assigned[next] = 1;
+            u.gates.push_back(next);
+            for (uint32_t v : nodes_of[next]) unit_nodes += !in_unit[v], in_unit[v] = 1;
+            if (u.gates.size() >= per) break;
+            double best = 0.25;
+            next = ~0u;
+            for (uint32_t h = g + 1; h < num_gates; h++) {
+                if (assigned[h] || nodes_of[h].empty()) continue;
+                uint64_t all = 0, shared = 0, fresh = 0;
+                for (uint32_t v : nodes_of[h]) all += price(v), shared += in_unit[v] ? price(v) : 0, fresh += !in_unit[v];
+                const double share = all ? (double)shared / (double)all : 0.0;
+                if (unit_nodes + fresh <= 4500 && share > best) best = share, next = h;
+            }
+            if (next == ~0u) break;
+        }
+        std::sort(u.gates.begin(), u.gates.end());
+        unit_size.push_back(unit_nodes);
+        units->push_back(std::move(u));
+    }
+    // small units that found no company share a launch all the same (a launch streams the selectors and the output once more)
+    for (size_t i = 0; i < units->size(); i++) {
+        if (unit_size[i] >= 600) continue;
+        for (size_t j = i + 1; j < units->size();) {
+            if (unit_size[j] < 600 && unit_size[i] + unit_size[j] < 1200 && (*units)[i].gates.size() + (*units)[j].gates.size() <= per) {
+                (*units)[i].gates.insert((*units)[i].gates.end(), (*units)[j].gates.begin(), (*units)[j].gates.end());
+                unit_size[i] += unit_size[j];
+                units->erase(units->begin() + (long)j);
+                unit_size.erase(unit_size.begin() + (long)j);
+            } else {
+                j++;
+            }
+        }
+        std::sort((*units)[i].gates.begin(), (*units)[i].gates.end());
+    }
+    if (units->empty()) {  // no gate has a constraint: one unit that writes zeros
+        GateUnit u;
+        u.gates.push_back(0);
+        units->push_back(std::move(u));
+    }
+    return true;
+}
+
 GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, uint32_t num_gates,
                               const uint64_t *imms, uint32_t num_imms, uint32_t num_selectors, uint32_t num_gate_constraints,
                               uint32_t num_challenges, std::string *error) {
@@ -523,20 +950,27 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         delete k;
         return nullptr;
     }
-    // Units of about equal program length: longest gate first, each into the unit that is shortest so far; inside a unit the
-    // gates keep the circuit's order.
-    const uint32_t n_units = std::min(jit_unit_limit(), num_gates);
-    std::vector<uint32_t> order(num_gates);
-    for (uint32_t g = 0; g < num_gates; g++) order[g] = g;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return gates[6 * x + 5] > gates[6 * y + 5]; });
-    k->units.resize(n_units);
-    std::vector<uint64_t> load(n_units, 0);
-    for (uint32_t g : order) {
-        const uint32_t u = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
-        k->units[u].gates.push_back(g);
-        load[u] += gates[6 * g + 5] + 16;  // + the gate's fixed part (filter, reduction)
+    if (fuse_enabled()) {
+        if (!fuse_partition(instrs, num_instrs, gates, num_gates, imms, num_imms, num_selectors, &k->units, error)) {
+            delete k;
+            return nullptr;
+        }
+    } else {
+        // Units of about equal program length: longest gate first, each into the unit that is shortest so far; inside a unit the
+        // gates keep the circuit's order.
+        const uint32_t n_units = std::min(jit_unit_limit(), num_gates);
+        std::vector<uint32_t> order(num_gates);
+        for (uint32_t g = 0; g < num_gates; g++) order[g] = g;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return gates[6 * x + 5] > gates[6 * y + 5]; });
+        k->units.resize(n_units);
+        std::vector<uint64_t> load(n_units, 0);
+        for (uint32_t g : order) {
+            const uint32_t u = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            k->units[u].gates.push_back(g);
+            load[u] += gates[6 * g + 5] + 16;  // + the gate's fixed part (filter, reduction)
+        }
+        k->units.erase(std::remove_if(k->units.begin(), k->units.end(), [](const GateUnit &u) { return u.gates.empty(); }), k->units.end());
     }
-    k->units.erase(std::remove_if(k->units.begin(), k->units.end(), [](const GateUnit &u) { return u.gates.empty(); }), k->units.end());
     const std::string dir = kernel_cache_dir();
     std::vector<std::string> cache_paths;
     for (GateUnit &u : k->units) {

@@ -52,7 +52,32 @@ def objects(tmp):
     return sorted(f for f in os.listdir(tmp) if f.endswith(".hsaco"))
 
 
-def test_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path):
+def test_fused_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path):
+    """The default generator: gates that share values share a unit (csrc/gate_jit.hip, fused units). Of the seven gates here the noop
+    gate has no constraints and belongs to no unit; at most PLONKY2_HIP_JIT_FUSE_GATES gates go into one."""
+    a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
+    for d in (a, b, c):
+        d.mkdir()
+    out = run(a, PLONKY2_HIP_JIT_FORK="1")
+    assert "built" in out or "loading the compiled gate kernel" in out, out
+    n = len(objects(a))
+    assert 2 <= n <= 6 and len([f for f in os.listdir(a) if f.endswith(".hip")]) == n, os.listdir(a)
+    sources = "".join((a / f).read_text() for f in os.listdir(a) if f.endswith(".hip"))
+    assert all(("// gate_%d\n" % g) in sources for g in (0, 1, 2, 4, 5, 6)) and "// gate_3\n" not in sources  # gate 3 is the noop gate
+    assert "GateSum gate_" not in sources
+    run(b)  # no fork: same sources -> same names, same code objects
+    assert objects(a) == objects(b)
+    for f in objects(a):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
+    run(c, PLONKY2_HIP_JIT_FUSE_GATES="1")  # one gate per unit
+    assert len(objects(c)) == 6
+    out = run(a)
+    assert float(out.split("seconds")[1]) < 2.0, out
+
+
+def test_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path, monkeypatch):
+    """One function per gate (PLONKY2_HIP_JIT_FUSE=0, the generator of rounds 3-4, kept for A/B): PLONKY2_HIP_JIT_UNITS units."""
+    monkeypatch.setenv("PLONKY2_HIP_JIT_FUSE", "0")
     a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
     for d in (a, b, c):
         d.mkdir()

@@ -169,7 +169,7 @@ def _generic(gpu, inst, bufs, log_len, kernel=None, prog=None, pih=None):
 def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_rare_paths(gpu, which):
     """The run-time compiled kernel computes l - 3, t + 2, b - 1 ... with two-instruction forms whose wrap correction sits behind a
     branch, and a base-4 limb's range check as (l (l - 3) + 1)^2 with the constant taken off per gate (csrc/gate_jit.hip, peephole
-    pass). On an LDE those wraps need a wire within 3 of zero: never. Here the leaves ARE such values — every wire and constant drawn
+    pass), once for all the gates of a unit that check the same wire (fused units). On an LDE those wraps need a wire within 3 of zero: never. Here the leaves ARE such values — every wire and constant drawn
     from {0..5, 2^32 +- 1, 2^63, p - 4..p - 1}, the same sprinkled into random leaves (so that some lanes of a wave take a correction
     and others do not), and representatives at and above p — and the compiled kernel, with the pass and without it, gives what the
     interpreter gives, which executes the programs as written; on the canonical leaves, also what the oracle's gates give."""
@@ -194,18 +194,20 @@ def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_r
     assert (interpreted == got).all()
     if which != "non-canonical":
         assert (got == np.array(oracle_quotient(inst, ed.REFERENCE_PUBLIC_INPUTS_HASH), dtype=np.uint64)).all()
-    os.environ["PLONKY2_HIP_JIT_PEEPHOLE"] = "0"
-    try:
-        prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
-    finally:
-        del os.environ["PLONKY2_HIP_JIT_PEEPHOLE"]
-    src = prog.kernel_source()
-    assert "gl::mul_add_small<" not in src and "gl::sub_small<" not in src and "g_bias[c" not in src
-    assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all()
-    prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
-    src = prog.kernel_source()
-    assert src.count("gl::mul_add_small<1>(") == 1838 and src.count("gl::sub_small<3u>(") == 1838 and "g_bias[c * NGU + " in src
-    assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all()
+    # the generator's three forms: one function per gate as written (round 4), the same with the peephole pass, and fused units
+    for env, check in (({"PLONKY2_HIP_JIT_FUSE": "0", "PLONKY2_HIP_JIT_PEEPHOLE": "0"},
+                        lambda src: "gl::mul_add_small<" not in src and "gl::sub_small<" not in src and "g_bias[c" not in src and "GateSum gate_8()" in src),
+                       ({"PLONKY2_HIP_JIT_FUSE": "0"},
+                        lambda src: src.count("gl::mul_add_small<1>(") == 1838 and src.count("gl::sub_small<3u>(") == 1838 and "g_bias[c * NGU + " in src),
+                       ({}, lambda src: 0 < src.count("gl::mul_add_small<1>(") < 1000 and "GateSum gate_8()" not in src and "// gate_8" in src)):
+        os.environ.update(env)
+        try:
+            prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert check(prog.kernel_source()), env
+        assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all(), env
 
 
 def _poly_at(coeffs, x):

@@ -47,7 +47,7 @@ def compile_into(cache):
 GENERATED = [("mul", r"gl::mul\(", 12, 3), ("mul_add_small", r"gl::mul_add_small<", 12, 3), ("add", r"gl::add\(", 4, 2), ("sub", r"gl::sub\(", 5, 3),
              ("add_small", r"gl::add_small<", 2, 3), ("sub_small", r"gl::sub_small<", 2, 3), ("mul_k", r"gl::mul_k<", 12, 3), ("add_k", r"gl::add_k<", 4, 2), ("emit (dot_term per challenge)", r"gl::dot_term\(", 16, 0),
              ("acc", r"gj_acc\(", 2, 0), ("accr (fold96)", r"gl::fold96\(", 7, 0), ("mulk", r"gl::mul_pow2<", 8, 0),
-             ("load wire / constant", r"= [WC]\[", 2, 0), ("load immediate", r"= 0x[0-9a-f]+ull;", 2, 0), ("dot_finish", r"gl::dot_finish\(", 20, 0)]
+             ("load wire / constant", r"= [WC]\[[0-9]", 2, 0), ("load immediate", r"= 0x[0-9a-f]+ull;", 2, 0), ("dot_finish", r"gl::dot_finish\(", 20, 0)]
 
 
 def main():
@@ -66,7 +66,8 @@ def main():
     generated = collections.Counter()
     for f in sorted(glob.glob(os.path.join(cache, "*.hip"))):
         body = open(f).read()
-        body = body[body.index("static __device__ __noinline__ GateSum gate_"):]
+        starts = [body.find(m) for m in ("static __device__ __noinline__ GateSum gate_", 'extern "C" __global__')]
+        body = body[min(i for i in starts if i >= 0):]
         for name, rx, _, _ in GENERATED:
             generated[name] += len(re.findall(rx, body))
     generated["dot_finish"] *= 2  # written once, in a loop over the two challenges
