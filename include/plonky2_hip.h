@@ -227,8 +227,10 @@ GlError gl_gate_programs_emit(const GlGateSpec *gates, uint32_t num_gates, const
 void gl_gate_programs_free(GlGatePrograms *programs);
 
 /* The same gate programs compiled at run time (hiprtc, gfx950) into a kernel specialised to the circuit:
- * one device function per gate, registers in VGPRs, immediates as literals. Built once per circuit
- * (under a second for a few small gates; the 25-gate ed25519 list: about a minute of CPU, spread over up to eight forked hiprtc workers — 11 s on 8 cores), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.
+ * gates that share wires and subexpressions are generated together (fused units: each value is loaded / computed once and goes to every
+ * gate's accumulators), registers in VGPRs, immediates as literals or scalar operands. Built once per circuit
+ * (under a second for a few small gates; the 25-gate ed25519 list: about a minute of CPU, in six units — 15 s when forked hiprtc workers
+ * compile them side by side, PLONKY2_HIP_JIT_FORK=1), reused for every proof; h_* are HOST arrays in the GlGateInstr / GlGateDesc encoding.
  * On failure the GlError message carries the compiler log. */
 GlError gl_gate_kernel_build(const GlGateInstr *h_instrs, uint32_t num_instrs, const GlGateDesc *h_gates, uint32_t num_gates,
                              const uint64_t *h_immediates, uint32_t num_immediates, uint32_t num_selectors,
@@ -479,8 +481,8 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
  * the kernels derive these from the library's own tables. Other shapes return GL_E_INVALID: every other circuit goes
  * through gl_compute_quotient_polys, of which this is one instance with the gate programs compiled in
  * (csrc/ed25519_gate_program.inc). The first call on a device builds its kernels with hiprtc: about a minute
- * of compilation spread over up to eight forked workers when nothing is cached (11 s on the 8-core build container; 68 s as one
- * program, PLONKY2_HIP_JIT_UNITS=1), about 2 s when ROCm's own compilation cache (~/.cache/comgr, on by default) has seen the
+ * of compilation when nothing is cached (six units; 15 s on the 8-core build container when forked workers compile them side by
+ * side), about 2 s when ROCm's own compilation cache (~/.cache/comgr, on by default) has seen the
  * sources, immediate from
  * $PLONKY2_HIP_KERNEL_CACHE or, when that is unset, from the directory kernel_cache/ next to this library, where the
  * build (__graft_entry__.build()) puts the precompiled code objects. gl_reference_quotient_prepare() does it ahead of

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <thread>
@@ -90,6 +91,7 @@ struct GateUnit {
 struct GateKernel {
     std::vector<GateUnit> units;
     uint32_t num_challenges = 0, num_constraints = 0;
+    bool fused = false;  // fused units read g_apow as pairs {alpha^k, alpha^k * 2^32}
     uint32_t wires_needed = 0, constants_needed = 0;  // 1 + the largest wire / constant column any gate loads
     std::string source;  // all units, for inspection
 };
@@ -278,8 +280,8 @@ static std::vector<Peep> peephole(const uint16_t *instrs, uint32_t ps, uint32_t 
 //     (its own k, its own accumulator), a term of an ACCR sum is accumulated right there, and an operation whose operands are now
 //     all there is computed (and pushed in turn). A limb's range check is computed once and lands in four gates' accumulators
 //     within a few instructions; nothing is kept for a later gate except the running sums.
-// What bounds a unit is the registers of those per-gate accumulators (18 per gate with two challenges), hence few gates per unit
-// (PLONKY2_HIP_JIT_FUSE_GATES, default 4; units are runs of consecutive gates of the circuit: the gate list is sorted by kind).
+// What bounds a unit is the registers of those per-gate accumulators (12 per gate with two challenges, gl::DotCol2), hence few gates per unit
+// (PLONKY2_HIP_JIT_FUSE_GATES, default 5; units are runs of consecutive gates of the circuit: the gate list is sorted by kind).
 // PLONKY2_HIP_JIT_FUSE=0 generates one function per gate as before (A/B; tests hold the two against each other).
 static bool fuse_enabled() {
     const char *e = getenv("PLONKY2_HIP_JIT_FUSE");
@@ -295,12 +297,31 @@ static uint32_t fuse_waves() {
     return 4;
 }
 
+// The fused function is one basic block of thousands of statements, and the compiler's scheduler moves loads (vector and scalar)
+// up as far as it likes: a scheduling barrier every so many statements keeps what it hoists within reach of the registers.
+static uint32_t fuse_sched_interval() {
+    if (const char *e = getenv("PLONKY2_HIP_JIT_SCHED")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 100000) return (uint32_t)v;
+    }
+    return 0;
+}
+
+// how many statements before its first use a wire is loaded
+static uint32_t fuse_prefetch_distance() {
+    if (const char *e = getenv("PLONKY2_HIP_JIT_PREFETCH")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 4096) return (uint32_t)v;
+    }
+    return 16;
+}
+
 static uint32_t fuse_gates_per_unit() {
     if (const char *e = getenv("PLONKY2_HIP_JIT_FUSE_GATES")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) return (uint32_t)v;
     }
-    return 4;
+    return 5;
 }
 
 struct FNode {
@@ -433,7 +454,8 @@ static bool fuse_gate(FGraph &g, const uint16_t *instrs, uint32_t ps, uint32_t p
 }
 
 // The fused function of a unit, as statements of the kernel's body. `gate_emits[i]`: the EMITs of the unit's i-th gate.
-static void fuse_schedule(std::ostringstream &o, const FGraph &g, const std::vector<std::vector<FEmit>> &gate_emits, uint32_t num_selectors) {
+static void fuse_schedule(std::ostringstream &final_out, const FGraph &g, const std::vector<std::vector<FEmit>> &gate_emits, uint32_t num_selectors) {
+    std::ostringstream o;
     const size_t n = g.nodes.size();
     struct Cons {
         uint8_t type;  // 0: node x; 1: EMIT of gate x, constraint y; 2: term y of LIN node x
@@ -477,29 +499,96 @@ static void fuse_schedule(std::ostringstream &o, const FGraph &g, const std::vec
     }
     for (uint32_t gi = 0; gi < gate_emits.size(); gi++)
         for (const FEmit &e : gate_emits[gi]) cons[e.node].push_back({1, gi, e.k});
+    // A sum whose terms are computed far apart would keep its accumulator open all the way (four registers): only sums whose terms
+    // are numbered — i.e. first computed — close together take their terms as they come; the others are gathered where the first
+    // program that needs them stands, re-loading the wires among their terms.
+    std::vector<char> gathered(n, 0);
+    for (uint32_t v = 0; v < n; v++) {
+        if (!needed[v] || g.nodes[v].kind != FNode::LIN) continue;
+        uint32_t lo = ~0u, hi = 0;
+        for (const auto &t : g.nodes[v].terms) lo = std::min(lo, t.first), hi = std::max(hi, t.first);
+        gathered[v] = hi - lo > 400;
+    }
     std::vector<char> done(n, 0), lin_open(n, 0);
-    std::vector<uint32_t> work;
+    std::vector<std::string> name(n);
+    std::vector<uint64_t> at(n, 0);
+    uint64_t stmt = 0, serial = 0;
+    const uint64_t WINDOW = 96;  // statements a loaded wire is kept for; a later reader loads it again
+    auto is_load = [&](uint32_t v) { return g.nodes[v].kind == FNode::WIRE || g.nodes[v].kind == FNode::CONST; };
+    // `name = <load of v>`: the element stride goes through an asm that returns it unchanged — otherwise the compiler keeps the
+    // scalar product index * stride of every wire it has seen (two scalar registers each, 234 wires) for the next load of the same
+    // wire, runs out of scalar registers and parks them in lanes of vector registers (600 spills, ten vector registers, in a
+    // four-gate unit); a product per load is two scalar instructions. A re-load also hides the pointer (see use()).
+    auto load = [&](const std::string &nm, uint32_t v, bool again) {
+        const bool wire = g.nodes[v].kind == FNode::WIRE;
+        std::ostringstream e;
+        // (every such asm carries a number of its own in a comment: identical asm statements of identical inputs are merged)
+        e << "{ uint64_t e = " << (wire ? "wes" : "ces") << "; asm(\"; " << ++serial << "\" : \"+s\"(e)); ";
+        if (again) e << "const uint64_t* q = " << (wire ? "W" : "C") << "; asm(\"; " << ++serial << "\" : \"+v\"(q)); ";
+        e << nm << " = " << (again ? "q" : wire ? "W" : "C") << "[" << (wire ? g.nodes[v].a : num_selectors + g.nodes[v].a) << " * e]; }";
+        return e.str();
+    };
+    // the name to read value v by; a wire loaded long ago is loaded again through a pointer the compiler cannot tell from W (else it
+    // would merge the two loads and keep the first one's registers occupied in between)
+    auto use = [&](uint32_t v) -> const std::string & {
+        if (is_load(v) && stmt - at[v] > WINDOW) {
+            std::ostringstream nm;
+            nm << "v" << v << "_" << ++serial;
+            o << "  uint64_t " << nm.str() << "; " << load(nm.str(), v, true) << "\n";
+            name[v] = nm.str();
+            at[v] = ++stmt;
+        }
+        return name[v];
+    };
     auto define = [&](uint32_t v) {
         const FNode &nd = g.nodes[v];
-        o << "  const uint64_t v" << v << " = ";
+        std::ostringstream e;
         switch (nd.kind) {
-            case FNode::WIRE: o << "W[" << nd.a << " * wes]"; break;
-            case FNode::CONST: o << "C[" << (num_selectors + nd.a) << " * ces]"; break;
-            case FNode::PI: o << "g_pih[" << nd.a << "]"; break;
-            case FNode::IMM: o << "0x" << std::hex << nd.k << std::dec << "ull"; break;
-            case FNode::ADD: o << "gl::add(v" << nd.a << ", v" << nd.b << ")"; break;
-            case FNode::SUB: o << "gl::sub(v" << nd.a << ", v" << nd.b << ")"; break;
-            case FNode::MUL: o << "gl::mul(v" << nd.a << ", v" << nd.b << ")"; break;
-            case FNode::MULK: o << "gl::mul_pow2<" << nd.k << ">(v" << nd.a << ")"; break;
-            case FNode::ADD_SMALL: o << "gl::add_small<" << nd.k << "u>(v" << nd.a << ")"; break;
-            case FNode::SUB_SMALL: o << "gl::sub_small<" << nd.k << "u>(v" << nd.a << ")"; break;
-            case FNode::MUL_ADD1: o << "gl::mul_add_small<1>(v" << nd.a << ", v" << nd.b << ")"; break;
-            case FNode::MUL_K: o << "gl::mul_k<0x" << std::hex << nd.k << std::dec << "ull>(v" << nd.a << ")"; break;
-            case FNode::ADD_K: o << "gl::add_k<0x" << std::hex << nd.k << std::dec << "ull>(v" << nd.a << ")"; break;
-            case FNode::LIN: o << "gl::fold96(l" << v << "l, l" << v << "h)"; break;
+            case FNode::WIRE: case FNode::CONST:
+                name[v] = "v" + std::to_string(v);
+                o << "  uint64_t " << name[v] << "; " << load(name[v], v, false) << "\n";
+                at[v] = ++stmt;
+                return;
+            case FNode::PI: e << "g_pih[" << nd.a << "]"; break;
+            case FNode::IMM: e << "0x" << std::hex << nd.k << std::dec << "ull"; break;
+            case FNode::ADD: { const std::string x = use(nd.a), y = use(nd.b); e << "gl::add(" << x << ", " << y << ")"; break; }
+            case FNode::SUB: { const std::string x = use(nd.a), y = use(nd.b); e << "gl::sub(" << x << ", " << y << ")"; break; }
+            case FNode::MUL: { const std::string x = use(nd.a), y = use(nd.b); e << "gl::mul(" << x << ", " << y << ")"; break; }
+            case FNode::MUL_ADD1: { const std::string x = use(nd.a), y = use(nd.b); e << "gl::mul_add_small<1>(" << x << ", " << y << ")"; break; }
+            case FNode::MULK: e << "gl::mul_pow2<" << nd.k << ">(" << use(nd.a) << ")"; break;
+            case FNode::ADD_SMALL: e << "gl::add_small<" << nd.k << "u>(" << use(nd.a) << ")"; break;
+            case FNode::SUB_SMALL: e << "gl::sub_small<" << nd.k << "u>(" << use(nd.a) << ")"; break;
+            case FNode::MUL_K: e << "gl::mul_k<0x" << std::hex << nd.k << std::dec << "ull>(" << use(nd.a) << ")"; break;
+            case FNode::ADD_K: e << "gl::add_k<0x" << std::hex << nd.k << std::dec << "ull>(" << use(nd.a) << ")"; break;
+            case FNode::LIN:
+                if (gathered[v]) {
+                    o << "  uint64_t l" << v << "l = 0, l" << v << "h = 0;\n";
+                    for (const auto &t : nd.terms) {
+                        const std::string x = use(t.first);
+                        o << "  gj_acc(l" << v << "l, l" << v << "h, " << x << ", " << t.second << "u);\n";
+                        stmt++;
+                    }
+                }
+                e << "gl::fold96(l" << v << "l, l" << v << "h)";
+                break;
         }
-        o << ";\n";
+        name[v] = "v" + std::to_string(v);
+        o << "  const uint64_t " << name[v] << " = " << e.str() << ";\n";
+        at[v] = ++stmt;
     };
+    // Would computing m now lead to an EMIT or to a term of a sum that takes its terms as they come — directly, or through operations
+    // that wait for nothing else? If not, m waits until the program that wants it is generated: it would only occupy registers.
+    std::function<bool(uint32_t, int)> fires = [&](uint32_t m, int depth) -> bool {
+        for (const Cons &c : cons[m]) {
+            if (c.type == 1) return true;
+            if (c.type == 2 && !gathered[c.x]) return true;
+            if (c.type == 0 && pending[c.x] == 1 && depth < 48 && fires(c.x, depth + 1)) return true;
+        }
+        return false;
+    };
+    std::vector<uint32_t> work;
+    const uint64_t sched = fuse_sched_interval();
+    uint64_t next_barrier = sched;
     // compute v (its operands exist), hand it to its consumers, and go on with whatever that completes: depth first, so that a
     // chain is followed to its EMIT before the next value is loaded
     auto produce = [&](uint32_t first) {
@@ -509,32 +598,62 @@ static void fuse_schedule(std::ostringstream &o, const FGraph &g, const std::vec
             work.pop_back();
             if (done[v]) continue;
             done[v] = 1;
+            if (sched && stmt >= next_barrier) {
+                o << "  __builtin_amdgcn_sched_barrier(0);\n";
+                next_barrier = stmt + sched;
+            }
             define(v);
             const size_t mark = work.size();
             for (const Cons &c : cons[v]) {
                 if (c.type == 1) {
-                    o << "  for (int c = 0; c < NCH; c++) gl::dot_term(ga" << c.x << "[c], v" << v << ", g_apow[c * NGC + " << c.y << "]);\n";
+                    // (the table pointer goes through an asm as well: the gates of a unit number their constraints from zero each, and
+                    // the compiler would keep alpha^k in scalar registers from one gate's EMIT to the next gate's with the same k)
+                    o << "  { apow_t ap = (apow_t)g_apow; asm(\"; " << ++serial << "\" : \"+s\"(ap)); for (int c = 0; c < NCH; c++) gl::dot_term2(ga" << c.x << "[c], "
+                      << name[v] << ", ap[(c * NGC + " << c.y << ") * 2], ap[(c * NGC + " << c.y << ") * 2 + 1]); }\n";
+                    stmt++;
                 } else if (c.type == 2) {
+                    if (gathered[c.x]) continue;
                     if (!lin_open[c.x]) {
                         o << "  uint64_t l" << c.x << "l = 0, l" << c.x << "h = 0;\n";
                         lin_open[c.x] = 1;
                     }
-                    o << "  gj_acc(l" << c.x << "l, l" << c.x << "h, v" << v << ", " << g.nodes[c.x].terms[c.y].second << "u);\n";
+                    o << "  gj_acc(l" << c.x << "l, l" << c.x << "h, " << name[v] << ", " << g.nodes[c.x].terms[c.y].second << "u);\n";
+                    stmt++;
                     if (--pending[c.x] == 0) work.push_back(c.x);
-                } else if (--pending[c.x] == 0) {
+                } else if (--pending[c.x] == 0 && fires(c.x, 0)) {
                     work.push_back(c.x);
                 }
             }
             std::reverse(work.begin() + (long)mark, work.end());  // first consumer first
         }
     };
-    // leaves in the order the gates' programs reach them: nodes are numbered in that order
-    for (uint32_t v = 0; v < n; v++) {
-        if (!needed[v] || done[v]) continue;
-        const FNode &nd = g.nodes[v];
-        const bool leaf = nd.kind == FNode::WIRE || nd.kind == FNode::CONST || nd.kind == FNode::PI || nd.kind == FNode::IMM;
-        if (leaf || pending[v] == 0) produce(v);
+    // the order of the gates' programs: nodes are numbered as the programs first reach them, operands before their operations
+    for (uint32_t v = 0; v < n; v++)
+        if (needed[v] && !done[v]) produce(v);
+    // Every load stands where its value is first used, and a wave that waits for each of its thousand loads in turn is not hidden by
+    // the three others of its SIMD: the loads move up by `ahead` statements (their order kept), that many statements' work — a few
+    // hundred instructions — between the request and the use.
+    const uint32_t ahead = fuse_prefetch_distance();
+    std::vector<std::string> lines;
+    {
+        const std::string text = o.str();
+        size_t from = 0;
+        for (size_t nl; (nl = text.find('\n', from)) != std::string::npos; from = nl + 1) lines.push_back(text.substr(from, nl - from));
     }
+    std::vector<std::string> placed;
+    size_t last_load = 0;  // no load is placed above the load before it
+    for (const std::string &ln : lines) {
+        const bool is_a_load = ln.compare(0, 12, "  uint64_t v") == 0 && ln.find(" * e]; }") != std::string::npos;
+        if (!is_a_load || ahead == 0) {
+            placed.push_back(ln);
+            continue;
+        }
+        // (the barrier after it: left alone, the compiler's scheduler moves the load back down to its use to save the two registers)
+        const size_t where = std::max(last_load, placed.size() > ahead ? placed.size() - ahead : 0);
+        placed.insert(placed.begin() + (long)where, ln + " __builtin_amdgcn_sched_barrier(0);");
+        last_load = where + 1;
+    }
+    for (const std::string &ln : placed) final_out << ln << "\n";
 }
 
 static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_instrs, const uint32_t *gates, const std::vector<uint32_t> &unit_gates,
@@ -543,8 +662,10 @@ static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_in
     std::ostringstream o;
     o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n" << GL_JIT_FIELD_SRC << "\n";
     o << "#define NGU " << unit_gates.size() << "\n#define NCH " << nch << "\n#define NGC " << ngc << "\n";
-    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n"
+    // g_apow[c][k] = {alpha_c^k, alpha_c^k * 2^32}: the two-column accumulators of gate_jit_field.h (gl::DotCol2)
+    o << "__constant__ uint64_t g_apow[NCH * NGC * 2];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n"
          "__constant__ uint64_t g_par[6];\n"
+         "typedef const __attribute__((address_space(4))) uint64_t* apow_t;\n"
          "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
          "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
     bias->assign(unit_gates.size(), {});
@@ -566,7 +687,7 @@ static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_in
          "  const uint64_t* W = (const uint64_t*)g_par[0] + t_ * g_par[1]; const uint64_t wes = g_par[2];\n"
          "  const uint64_t* C = (const uint64_t*)g_par[3] + t_ * g_par[4]; const uint64_t ces = g_par[5];\n";
     for (size_t gi = 0; gi < unit_gates.size(); gi++)
-        if (!gate_emits[gi].empty()) o << "  gl::DotAcc ga" << gi << "[NCH];  // gate_" << unit_gates[gi] << "\n";
+        if (!gate_emits[gi].empty()) o << "  gl::DotCol2 ga" << gi << "[NCH];  // gate_" << unit_gates[gi] << "\n";
     fuse_schedule(o, graph, gate_emits, num_selectors);
     o << "  uint64_t acc[NCH];\n  for (int c = 0; c < NCH; c++) acc[c] = accumulate ? out[(uint64_t)c * lde_size + t_] : 0;\n";
     for (size_t gi = 0; gi < unit_gates.size(); gi++) {
@@ -579,9 +700,9 @@ static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_in
             if (i != row) o << "    filt = gl::mul(filt, gl::sub(" << i << "ull, s));\n";
         if (num_selectors > 1) o << "    filt = gl::mul(filt, gl::sub(0xFFFFFFFFull, s));\n";  // UNUSED_SELECTOR (selectors.rs:11)
         if ((*bias)[gi].empty())
-            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::dot_finish(ga" << gi << "[c])));\n  }\n";
+            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::dot_finish2(ga" << gi << "[c])));\n  }\n";
         else
-            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::sub(gl::dot_finish(ga" << gi << "[c]), g_bias[c * NGU + "
+            o << "    for (int c = 0; c < NCH; c++) acc[c] = gl::add(acc[c], gl::mul(filt, gl::sub(gl::dot_finish2(ga" << gi << "[c]), g_bias[c * NGU + "
               << gi << "])));\n  }\n";
     }
     o << "  for (int c = 0; c < NCH; c++) out[(uint64_t)c * lde_size + t_] = gl::canon(acc[c]);\n}\n";
@@ -950,7 +1071,8 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         delete k;
         return nullptr;
     }
-    if (fuse_enabled()) {
+    k->fused = fuse_enabled();
+    if (k->fused) {
         if (!fuse_partition(instrs, num_instrs, gates, num_gates, imms, num_imms, num_selectors, &k->units, error)) {
             delete k;
             return nullptr;
@@ -1138,6 +1260,11 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
             p = glh::mul(p, a);
         }
     }
+    std::vector<uint64_t> table = apow;  // what the units' g_apow holds
+    if (k->fused) {
+        table.resize(apow.size() * 2);
+        for (size_t i = 0; i < apow.size(); i++) table[2 * i] = apow[i], table[2 * i + 1] = glh::mul(apow[i], 1ull << 32);
+    }
     const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
     const uint64_t par[6] = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es};
     std::vector<std::vector<uint64_t>> unit_bias(k->units.size());
@@ -1155,7 +1282,7 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
     for (size_t ui = 0; ui < k->units.size(); ui++) {
         const GateUnit &u = k->units[ui];
         // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
-        hipError_t e = hipMemcpyAsync(u.d_apow, apow.data(), apow.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+        hipError_t e = hipMemcpyAsync(u.d_apow, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         if (u.d_bias) {
             e = hipMemcpyAsync(u.d_bias, unit_bias[ui].data(), unit_bias[ui].size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);

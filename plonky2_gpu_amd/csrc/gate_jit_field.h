@@ -126,4 +126,38 @@ __device__ __forceinline__ uint64_t add_k(uint64_t a) {
     return r;
 }
 
+// sum_k c_k * alpha^k with TWO column accumulators instead of gl::DotAcc's three: with beta_k = alpha^k * 2^32 (mod p) from the
+// same table, c * alpha^k = c.lo * alpha^k + c.hi * beta_k, and both products have only the columns 2^0 and 2^32:
+//     A0 += c.lo * alpha.lo + c.hi * beta.lo        A1 += c.lo * alpha.hi + c.hi * beta.hi
+// The same four multiply-adds and four carry counts per term as gl::dot_term, but six registers per challenge where DotAcc takes nine
+// — and in a fused unit the accumulators of all its gates are live from the first statement to the last.
+struct DotCol2 {
+    uint64_t a0 = 0, a1 = 0;
+    uint32_t k0 = 0, k1 = 0;
+};
+
+__device__ __forceinline__ void dot_term2(DotCol2 &d, uint64_t c, uint64_t alpha, uint64_t beta) {
+    uint32_t cl = (uint32_t)c, ch = (uint32_t)(c >> 32);
+    uint32_t al = (uint32_t)alpha, ah = (uint32_t)(alpha >> 32), bl = (uint32_t)beta, bh = (uint32_t)(beta >> 32);
+    uint64_t c0, c1, c2, c3;
+    // a carry written to a scalar pair is read three instructions later (two wait states are needed, see gl::dot_term)
+    asm("v_mad_u64_u32 %0, %4, %8, %10, %0\n\t"
+        "v_mad_u64_u32 %1, %5, %8, %11, %1\n\t"
+        "v_mad_u64_u32 %0, %6, %9, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %9, %13, %1\n\t"
+        "v_addc_co_u32_e64 %2, vcc, 0, %2, %4\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, %3, %5\n\t"
+        "v_addc_co_u32_e64 %2, vcc, 0, %2, %6\n\t"
+        "v_addc_co_u32_e64 %3, vcc, 0, %3, %7"
+        : "+v"(d.a0), "+v"(d.a1), "+v"(d.k0), "+v"(d.k1), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+        : "v"(cl), "v"(ch), "s"(al), "s"(ah), "s"(bl), "s"(bh)
+        : "vcc");
+}
+
+__device__ __forceinline__ uint64_t dot_finish2(const DotCol2 &d) {
+    DotAcc full;
+    full.a0 = d.a0, full.a1 = d.a1, full.a2 = 0, full.k0 = d.k0, full.k1 = d.k1, full.k2 = 0;
+    return dot_finish(full);
+}
+
 }  // namespace gl

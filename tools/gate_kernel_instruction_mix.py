@@ -45,9 +45,9 @@ def compile_into(cache):
 # what the generated source calls, and what each costs in vector instructions (executed; the correction behind the never-taken
 # branch of an operation is listed separately)
 GENERATED = [("mul", r"gl::mul\(", 12, 3), ("mul_add_small", r"gl::mul_add_small<", 12, 3), ("add", r"gl::add\(", 4, 2), ("sub", r"gl::sub\(", 5, 3),
-             ("add_small", r"gl::add_small<", 2, 3), ("sub_small", r"gl::sub_small<", 2, 3), ("mul_k", r"gl::mul_k<", 12, 3), ("add_k", r"gl::add_k<", 4, 2), ("emit (dot_term per challenge)", r"gl::dot_term\(", 16, 0),
+             ("add_small", r"gl::add_small<", 2, 3), ("sub_small", r"gl::sub_small<", 2, 3), ("mul_k", r"gl::mul_k<", 12, 3), ("add_k", r"gl::add_k<", 4, 2), ("emit (dot_term per challenge)", r"gl::dot_term2?\(", 16, 0),
              ("acc", r"gj_acc\(", 2, 0), ("accr (fold96)", r"gl::fold96\(", 7, 0), ("mulk", r"gl::mul_pow2<", 8, 0),
-             ("load wire / constant", r"= [WC]\[[0-9]", 2, 0), ("load immediate", r"= 0x[0-9a-f]+ull;", 2, 0), ("dot_finish", r"gl::dot_finish\(", 20, 0)]
+             ("load wire / constant", r"= [WCq]\[[0-9]", 2, 0), ("load immediate", r"= 0x[0-9a-f]+ull;", 2, 0), ("dot_finish", r"gl::dot_finish2?\(", 20, 0)]
 
 
 def main():
