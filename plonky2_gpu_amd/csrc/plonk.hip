@@ -319,6 +319,88 @@ hipError_t permutation_partial_products(const NttTables &tb, const uint64_t *wir
     return hipGetLastError();
 }
 
+namespace {
+// ---- the same kernel for the case the prover runs: gate constraints from the run-time compiled kernels (gate_partial) or none ------
+// quotient_values_kernel above serves every source of gate constraints, the interpreter included, and pays for it on every path: 3.8 KB
+// of scratch per lane (the interpreter's registers, its constraint sums, the term array), two Fermat inversions per point
+// (127 multiplications each) — 4.4 ms of a 8.8 ms quotient at n = 2^18 (profiles/r05_quotient_kernel_trace.txt). Here:
+//   * no arrays: the permutation terms are produced last to first and go straight into the Horner sums of all challenges
+//     (reduce_with_powers_multi, plonk_common.rs:97-114, runs from the last term);
+//   * Z_H(x) takes 2^qdb values on the quotient domain (zero_poly_coset.rs:20-41): they and their inverses come from the host;
+//   * the one inversion left, 1 / (n (x - 1)) for L_0 (zero_poly_coset.rs:57-60), by an addition chain for p - 2 = 2^64 - 2^32 - 1:
+//     64 squarings and 9 multiplications.
+struct ZhTable {
+    uint64_t zh[16], zh_inv[16];
+};
+
+// x^(p-2): with e_k = x^(2^k - 1), p - 2 = (2^31 - 1) 2^33 + (2^32 - 1)
+__device__ __forceinline__ uint64_t inverse_chain(uint64_t x) {
+    auto sqn = [](uint64_t v, int k) {
+        for (int i = 0; i < k; i++) v = gl::sqr(v);
+        return v;
+    };
+    const uint64_t e2 = gl::mul(gl::sqr(x), x), e3 = gl::mul(gl::sqr(e2), x), e6 = gl::mul(sqn(e3, 3), e3), e12 = gl::mul(sqn(e6, 6), e6);
+    const uint64_t e15 = gl::mul(sqn(e12, 3), e3), e30 = gl::mul(sqn(e15, 15), e15), e31 = gl::mul(gl::sqr(e30), x), e32 = gl::mul(gl::sqr(e31), x);
+    return gl::mul(sqn(e31, 33), e32);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(128) void quotient_values_fast_kernel(const QuotientParams p, const ZhTable zt) {
+    const uint32_t log_lde = p.degree_bits + p.qdb;
+    const uint64_t lde_size = 1ull << log_lde, n = 1ull << p.degree_bits;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lde_size) return;
+    const uint64_t i = log_lde ? (__brevll(t) >> (64 - log_lde)) : 0;
+    const uint64_t i_next = (i + (1ull << p.qdb)) & (lde_size - 1);  // the point g*x
+    const uint64_t t_next = log_lde ? (__brevll(i_next) >> (64 - log_lde)) : 0;
+    const uint64_t *wires = p.wires_leaves + t * p.w_rs;
+    const uint64_t *sig = p.cs_leaves + t * p.c_rs + p.num_constants * p.c_es;
+    const uint64_t *zpp = p.zpp_leaves + t * p.z_rs;
+    const uint64_t *zpp_next = p.zpp_leaves + t_next * p.z_rs;
+    const uint64_t x = gl::mul(p.shift, root_pow(p.twl, p.twh, log_lde, i));  // shifted_x (prover.rs:903)
+    uint64_t zh = zt.zh[0], zh_inv = zt.zh_inv[0];
+    const uint32_t which = (uint32_t)i & ((1u << p.qdb) - 1);
+    for (uint32_t e = 1; e < (1u << p.qdb); e++) {
+        zh = which == e ? zt.zh[e] : zh;
+        zh_inv = which == e ? zt.zh_inv[e] : zh_inv;
+    }
+    // the gate-constraint tail of the Horner sums, already reduced by the compiled gate kernels
+    uint64_t cumul[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) cumul[c] = p.gate_partial ? p.gate_partial[(uint64_t)c * lde_size + t] : 0;
+    const uint32_t chunks = p.num_prods + 1;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--) {
+        const uint64_t beta = p.ch.beta[c], gamma = p.ch.gamma[c];
+        const uint64_t bx = gl::mul(beta, x);
+        for (uint32_t k = chunks; k-- > 0;) {
+            const uint32_t j0 = k * p.degree, j1 = j0 + p.degree < p.num_routed ? j0 + p.degree : p.num_routed;
+            uint64_t num = 1, den = 1;
+            for (uint32_t j = j0; j < j1; j++) {
+                const uint64_t wg = gl::add(wires[j * p.w_es], gamma);
+                num = gl::mul(num, gl::add(wg, gl::mul(bx, p.k_is[j])));
+                den = gl::mul(den, gl::add(wg, gl::mul(beta, sig[j * p.c_es])));
+            }
+            const uint64_t prev = k == 0 ? zpp[c * p.z_es] : zpp[(NCH + c * p.num_prods + k - 1) * p.z_es];
+            const uint64_t next = k < p.num_prods ? zpp[(NCH + c * p.num_prods + k) * p.z_es] : zpp_next[c * p.z_es];
+            // check_partial_products (util/partial_products.rs:52-76): prev*num - next*den
+            const uint64_t term = gl::sub(gl::mul(prev, num), gl::mul(next, den));
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) cumul[cc] = gl::mac(term, cumul[cc], p.ch.alpha[cc]);
+        }
+    }
+    const uint64_t l0 = gl::mul(zh, inverse_chain(gl::mul(n, gl::sub(x, 1))));  // eval_l_0 (zero_poly_coset.rs:57-60)
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--) {
+        const uint64_t term = gl::mul(l0, gl::sub(zpp[c * p.z_es], 1));
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++) cumul[cc] = gl::mac(term, cumul[cc], p.ch.alpha[cc]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) p.out[(uint64_t)c * lde_size + i] = gl::canon(gl::mul(cumul[c], zh_inv));  // prover.rs:985-991
+}
+}  // namespace
+
 hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t *out, hipStream_t stream) {
     if (a.num_challenges == 0 || a.num_challenges > MAX_CHALLENGES || a.quotient_degree_factor < 2 || a.num_routed == 0)
         return hipErrorInvalidValue;
@@ -390,6 +472,22 @@ hipError_t quotient_values(const NttTables &tb, const QuotientArgs &a, uint64_t 
         p.ch.alpha[c] = a.alphas[c] % glh::P;
     }
     const uint64_t lde_size = 1ull << (a.degree_bits + qdb);
+    if (!p.has_program && !p.gate_terms && qdb <= 4) {
+        ZhTable zt = {};
+        const uint64_t w = glh::root_of_unity(qdb);
+        for (uint32_t e = 0; e < (1u << qdb); e++) {  // Z_H(x) = g^n * w^(i mod 2^qdb) - 1 (zero_poly_coset.rs:20-41)
+            zt.zh[e] = glh::add(glh::mul(p.g_pow_n, glh::pow(w, e)), glh::P - 1);
+            zt.zh_inv[e] = glh::inv(zt.zh[e]);
+        }
+        const dim3 grid(grid_for(lde_size, 128)), block(128);
+        switch (a.num_challenges) {
+            case 1: hipLaunchKernelGGL(quotient_values_fast_kernel<1>, grid, block, 0, stream, p, zt); break;
+            case 2: hipLaunchKernelGGL(quotient_values_fast_kernel<2>, grid, block, 0, stream, p, zt); break;
+            case 3: hipLaunchKernelGGL(quotient_values_fast_kernel<3>, grid, block, 0, stream, p, zt); break;
+            default: hipLaunchKernelGGL(quotient_values_fast_kernel<4>, grid, block, 0, stream, p, zt); break;
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(quotient_values_kernel, dim3(grid_for(lde_size, 128)), dim3(128), 0, stream, p);
     return hipGetLastError();
 }
