@@ -273,15 +273,17 @@ static std::vector<Peep> peephole(const uint16_t *instrs, uint32_t ps, uint32_t 
 // So the gates of a unit are generated as ONE straight-line function over a common value graph:
 //   * every operation becomes a node keyed by what it computes (kind, operand nodes, constants; ADD and MUL with sorted operands;
 //     an ACCR is the node "sum of weight_i * node_i"), so that two gates asking for the same value share the node;
-//   * what stays per gate is where its constraints go: the alpha-accumulators (gl::DotAcc per challenge) and the list
+//   * what stays per gate is where its constraints go: the alpha-accumulators (gl::DotCol2 per challenge) and the list
 //     (constraint index k, node);
 //   * the code is emitted in the order of the first gate's program, then the second's ..., skipping what exists — but every value is
 //     PUSHED to its consumers the moment it is computed: an EMIT of any gate of the unit that takes it is issued right there
 //     (its own k, its own accumulator), a term of an ACCR sum is accumulated right there, and an operation whose operands are now
-//     all there is computed (and pushed in turn). A limb's range check is computed once and lands in four gates' accumulators
-//     within a few instructions; nothing is kept for a later gate except the running sums.
-// What bounds a unit is the registers of those per-gate accumulators (12 per gate with two challenges, gl::DotCol2), hence few gates per unit
-// (PLONKY2_HIP_JIT_FUSE_GATES, default 5; units are runs of consecutive gates of the circuit: the gate list is sorted by kind).
+//     all there is computed (and pushed in turn) IF that leads to an EMIT or to such a sum — otherwise it waits for the program
+//     that wants it, and a wire it needs that was loaded long before is loaded again (fuse_schedule). A limb's range check is
+//     computed once and lands in five gates' accumulators within a few instructions; nothing is kept for a later gate except the
+//     running sums.
+// What bounds a unit is the registers of those per-gate accumulators (12 per gate with two challenges, gl::DotCol2), hence few gates
+// per unit (PLONKY2_HIP_JIT_FUSE_GATES, default 5), chosen by what they share (fuse_partition).
 // PLONKY2_HIP_JIT_FUSE=0 generates one function per gate as before (A/B; tests hold the two against each other).
 static bool fuse_enabled() {
     const char *e = getenv("PLONKY2_HIP_JIT_FUSE");
@@ -295,16 +297,6 @@ static uint32_t fuse_waves() {
         if (v >= 1 && v <= 8) return (uint32_t)v;
     }
     return 4;
-}
-
-// The fused function is one basic block of thousands of statements, and the compiler's scheduler moves loads (vector and scalar)
-// up as far as it likes: a scheduling barrier every so many statements keeps what it hoists within reach of the registers.
-static uint32_t fuse_sched_interval() {
-    if (const char *e = getenv("PLONKY2_HIP_JIT_SCHED")) {
-        const long v = strtol(e, nullptr, 10);
-        if (v >= 0 && v <= 100000) return (uint32_t)v;
-    }
-    return 0;
 }
 
 // how many statements before its first use a wire is loaded
@@ -578,17 +570,20 @@ static void fuse_schedule(std::ostringstream &final_out, const FGraph &g, const 
     };
     // Would computing m now lead to an EMIT or to a term of a sum that takes its terms as they come — directly, or through operations
     // that wait for nothing else? If not, m waits until the program that wants it is generated: it would only occupy registers.
-    std::function<bool(uint32_t, int)> fires = [&](uint32_t m, int depth) -> bool {
+    uint32_t budget = 0;  // nodes one question may visit (a wide graph of waiting operations must not make the generator quadratic)
+    std::function<bool(uint32_t, int)> fires_from = [&](uint32_t m, int depth) -> bool {
         for (const Cons &c : cons[m]) {
             if (c.type == 1) return true;
             if (c.type == 2 && !gathered[c.x]) return true;
-            if (c.type == 0 && pending[c.x] == 1 && depth < 48 && fires(c.x, depth + 1)) return true;
+            if (c.type == 0 && pending[c.x] == 1 && depth < 48 && budget > 0 && (--budget, fires_from(c.x, depth + 1))) return true;
         }
         return false;
     };
+    auto fires = [&](uint32_t m, int) {
+        budget = 512;
+        return fires_from(m, 0);
+    };
     std::vector<uint32_t> work;
-    const uint64_t sched = fuse_sched_interval();
-    uint64_t next_barrier = sched;
     // compute v (its operands exist), hand it to its consumers, and go on with whatever that completes: depth first, so that a
     // chain is followed to its EMIT before the next value is loaded
     auto produce = [&](uint32_t first) {
@@ -598,10 +593,6 @@ static void fuse_schedule(std::ostringstream &final_out, const FGraph &g, const 
             work.pop_back();
             if (done[v]) continue;
             done[v] = 1;
-            if (sched && stmt >= next_barrier) {
-                o << "  __builtin_amdgcn_sched_barrier(0);\n";
-                next_barrier = stmt + sched;
-            }
             define(v);
             const size_t mark = work.size();
             for (const Cons &c : cons[v]) {
