@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "gl_field.h"
+#include "knobs.h"
 
 namespace plonky2_hip {
 
@@ -155,7 +156,8 @@ bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const u
 //   3. Any other MUL / ADD / SUB with a LOAD_IMM operand reads the constant's halves as scalar operands (gl::mul_k, gl::add_k), and a
 //      LOAD_IMM whose readers all do is not generated (two v_mov each).
 // On the ed25519 table (1 838 such limbs among 21 467 operations) the executed vector instructions per LDE point go from 150 k to
-// 135 k. PLONKY2_HIP_JIT_PEEPHOLE=0 turns the pass off (A/B, and the tests that hold one form against the other).
+// 135 k. PLONKY2_HIP_JIT_PEEPHOLE=0 turns the pass off (A/B, and the tests that hold one form against the other; like every switch of the
+// generator it is read by the DIAGNOSTIC build of the library only, knobs.h).
 struct Peep {
     enum Kind : uint8_t { PLAIN, ADD_SMALL, SUB_SMALL, COPY, MUL_ADD1, SQUARE, MUL_K, ADD_K, SKIP } kind = PLAIN;
     uint32_t src = 0;      // ADD_SMALL / SUB_SMALL / COPY / SQUARE / MUL_K / ADD_K: the register read
@@ -165,7 +167,7 @@ struct Peep {
 };
 
 static bool peephole_enabled() {
-    const char *e = getenv("PLONKY2_HIP_JIT_PEEPHOLE");
+    const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_PEEPHOLE");
     return !(e && e[0] == '0');
 }
 
@@ -286,13 +288,13 @@ static std::vector<Peep> peephole(const uint16_t *instrs, uint32_t ps, uint32_t 
 // per unit (PLONKY2_HIP_JIT_FUSE_GATES, default 5), chosen by what they share (fuse_partition).
 // PLONKY2_HIP_JIT_FUSE=0 generates one function per gate as before (A/B; tests hold the two against each other).
 static bool fuse_enabled() {
-    const char *e = getenv("PLONKY2_HIP_JIT_FUSE");
+    const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_FUSE");
     return !(e && e[0] == '0');
 }
 
 // waves per SIMD the fused kernels are compiled for (their register budget: 128 VGPRs at 4, 168 at 3, 256 at 2)
 static uint32_t fuse_waves() {
-    if (const char *e = getenv("PLONKY2_HIP_JIT_WAVES")) {
+    if (const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_WAVES")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= 8) return (uint32_t)v;
     }
@@ -301,7 +303,7 @@ static uint32_t fuse_waves() {
 
 // how many statements before its first use a wire is loaded
 static uint32_t fuse_prefetch_distance() {
-    if (const char *e = getenv("PLONKY2_HIP_JIT_PREFETCH")) {
+    if (const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_PREFETCH")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0 && v <= 4096) return (uint32_t)v;
     }
@@ -309,7 +311,7 @@ static uint32_t fuse_prefetch_distance() {
 }
 
 static uint32_t fuse_gates_per_unit() {
-    if (const char *e = getenv("PLONKY2_HIP_JIT_FUSE_GATES")) {
+    if (const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_FUSE_GATES")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) return (uint32_t)v;
     }
@@ -870,7 +872,7 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
 // How many units a circuit is cut into: PLONKY2_HIP_JIT_UNITS (1 = one program, as before round 3), else one per hardware
 // thread up to eight.
 static uint32_t jit_unit_limit() {
-    if (const char *e = getenv("PLONKY2_HIP_JIT_UNITS")) {
+    if (const char *e = PLONKY2_KNOB("PLONKY2_HIP_JIT_UNITS")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= 64) return (uint32_t)v;
     }

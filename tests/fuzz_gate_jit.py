@@ -17,6 +17,8 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
+# the generator's switches are read by the DIAGNOSTIC build of the library only (csrc/knobs.h)
+os.environ.setdefault("PLONKY2_HIP_LIBRARY", os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))
 
 import plonky2_gpu_amd as pg  # noqa: E402
 from plonky2_gpu_amd import _lib, gate_program as gp  # noqa: E402

@@ -137,10 +137,11 @@ def test_the_product_library_has_no_ab_knobs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     product = open(os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip.so"), "rb").read()
     for knob in (b"PLONKY2_NTT_DIRECT", b"PLONKY2_NTT_KERNEL", b"PLONKY2_NTT_WIDE", b"PLONKY2_NTT_XCD", b"PLONKY2_NTT_WG_PER_CU", b"PLONKY2_NTT_CHUNK_COLS",
-                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_COMMIT_CHUNK", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON", b"PLONKY2_DROP_STREAM2_WAIT"):
+                 b"PLONKY2_TRANSPOSE", b"PLONKY2_COMMIT_PIPELINE", b"PLONKY2_COMMIT_CHUNK", b"PLONKY2_FUSED_LEAVES", b"PLONKY2_POSEIDON", b"PLONKY2_DROP_STREAM2_WAIT",
+                 b"PLONKY2_HIP_JIT_FUSE", b"PLONKY2_HIP_JIT_PEEPHOLE", b"PLONKY2_HIP_JIT_PREFETCH", b"PLONKY2_HIP_JIT_WAVES", b"PLONKY2_HIP_JIT_UNITS"):
         assert knob not in product, knob
-    for setting in (b"PLONKY2_HIP_KERNEL_CACHE", b"PLONKY2_HIP_JIT_UNITS", b"PLONKY2_HIP_JIT_FORK"):  # operational settings, not knobs
+    for setting in (b"PLONKY2_HIP_KERNEL_CACHE", b"PLONKY2_HIP_JIT_FORK"):  # operational settings, not knobs
         assert setting in product, setting
     debug = os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so")
     if os.path.exists(debug):
-        assert b"PLONKY2_NTT_DIRECT" in open(debug, "rb").read()
+        assert b"PLONKY2_NTT_DIRECT" in open(debug, "rb").read() and b"PLONKY2_HIP_JIT_FUSE_GATES" in open(debug, "rb").read()

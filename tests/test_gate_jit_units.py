@@ -41,8 +41,15 @@ print("seconds %.2f" % (time.perf_counter() - t))
 """
 
 
+DEBUG_LIB = os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip_debug.so")
+
+
 def run(tmp, **env):
     e = dict(os.environ, PLONKY2_HIP_KERNEL_CACHE=str(tmp), AMD_COMGR_CACHE="0", **env)
+    if any(k.startswith("PLONKY2_HIP_JIT_") and k != "PLONKY2_HIP_JIT_FORK" for k in env):
+        # the generator's switches are read by the diagnostic build only (csrc/knobs.h)
+        assert os.path.exists(DEBUG_LIB), "make -C plonky2_gpu_amd/csrc debug (done by __graft_entry__.build())"
+        e["PLONKY2_HIP_LIBRARY"] = DEBUG_LIB
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     return r.stdout
@@ -69,15 +76,24 @@ def test_fused_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp
     assert objects(a) == objects(b)
     for f in objects(a):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
-    run(c, PLONKY2_HIP_JIT_FUSE_GATES="1")  # one gate per unit
+    run(c, PLONKY2_HIP_JIT_FUSE_GATES="1")  # one gate per unit (a switch of the diagnostic build)
     assert len(objects(c)) == 6
+    d = tmp_path / "d"
+    d.mkdir()
+    e = dict(os.environ, PLONKY2_HIP_KERNEL_CACHE=str(d), PLONKY2_HIP_JIT_FUSE_GATES="1")  # the PRODUCT library does not read it
+    e.pop("PLONKY2_HIP_LIBRARY", None)
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and objects(d) == objects(a), r.stdout[-500:] + r.stderr[-1000:]
     out = run(a)
     assert float(out.split("seconds")[1]) < 2.0, out
 
 
 def test_units_are_compiled_into_the_cache_and_forking_changes_nothing(tmp_path, monkeypatch):
-    """One function per gate (PLONKY2_HIP_JIT_FUSE=0, the generator of rounds 3-4, kept for A/B): PLONKY2_HIP_JIT_UNITS units."""
+    """One function per gate (PLONKY2_HIP_JIT_FUSE=0, the generator of rounds 3-4, kept for A/B in the diagnostic build):
+    PLONKY2_HIP_JIT_UNITS units."""
     monkeypatch.setenv("PLONKY2_HIP_JIT_FUSE", "0")
+    monkeypatch.setenv("PLONKY2_HIP_LIBRARY", DEBUG_LIB)
+    assert os.path.exists(DEBUG_LIB), "make -C plonky2_gpu_amd/csrc debug (done by __graft_entry__.build())"
     a, b, c = tmp_path / "a", tmp_path / "b", tmp_path / "c"
     for d in (a, b, c):
         d.mkdir()

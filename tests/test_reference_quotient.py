@@ -164,20 +164,12 @@ def _generic(gpu, inst, bufs, log_len, kernel=None, prog=None, pih=None):
     return res
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("which", ["edges", "edges among random", "non-canonical"])
-def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_rare_paths(gpu, which):
-    """The run-time compiled kernel computes l - 3, t + 2, b - 1 ... with two-instruction forms whose wrap correction sits behind a
-    branch, and a base-4 limb's range check as (l (l - 3) + 1)^2 with the constant taken off per gate (csrc/gate_jit.hip, peephole
-    pass), once for all the gates of a unit that check the same wire (fused units). On an LDE those wraps need a wire within 3 of zero: never. Here the leaves ARE such values — every wire and constant drawn
-    from {0..5, 2^32 +- 1, 2^63, p - 4..p - 1}, the same sprinkled into random leaves (so that some lanes of a wave take a correction
-    and others do not), and representatives at and above p — and the compiled kernel, with the pass and without it, gives what the
-    interpreter gives, which executes the programs as written; on the canonical leaves, also what the oracle's gates give."""
-    import plonky2_gpu_amd as pg
-    from plonky2_gpu_amd import ed25519_circuit as ed, gate_program as gp
+EDGE_LOG_LEN = 4
 
-    log_len = 4
-    inst = random_instance(log_len, seed=9300)
+
+def edge_instance(which):
+    """the leaves of the test below (also built by its child process, tests/gate_jit_variant_child.py)"""
+    inst = random_instance(EDGE_LOG_LEN, seed=9300)
     rng = np.random.default_rng(77)
     edge = np.array(EDGE_VALUES + (NON_CANONICAL if which == "non-canonical" else []), dtype=np.uint64)
     for key in ("wires", "cs"):
@@ -186,28 +178,56 @@ def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_r
             inst[key] = np.where(rng.random(inst[key].shape) < 0.02, drawn, inst[key])
         else:
             inst[key] = drawn
-    got, bufs = run_symbol(gpu, inst)  # the compiled-in table, compiled with the pass
+    return inst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["edges", "edges among random", "non-canonical"])
+def test_compiled_gates_equal_the_interpreter_where_the_short_forms_take_their_rare_paths(gpu, which):
+    """The run-time compiled kernel computes l - 3, t + 2, b - 1 ... with two-instruction forms whose wrap correction sits behind a
+    branch, and a base-4 limb's range check as (l (l - 3) + 1)^2 with the constant taken off per gate (csrc/gate_jit.hip, peephole
+    pass), once for all the gates of a unit that check the same wire (fused units). On an LDE those wraps need a wire within 3 of
+    zero: never. Here the leaves ARE such values — every wire and constant drawn from {0..5, 2^32 +- 1, 2^63, p - 4..p - 1}, the same
+    sprinkled into random leaves (so that some lanes of a wave take a correction and others do not), and representatives at and
+    above p — and the compiled kernel gives what the interpreter gives, which executes the programs as written; on the canonical
+    leaves, also what the oracle's gates give. The generator's two earlier forms (one function per gate, with and without the
+    peephole pass: switches of the DIAGNOSTIC build, csrc/knobs.h) are run in a child process each and give the same bytes."""
+    import hashlib
+    import subprocess
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import ed25519_circuit as ed, gate_program as gp
+
+    inst = edge_instance(which)
+    got, bufs = run_symbol(gpu, inst)  # the compiled-in table: fused units
     pool = gp.ImmediatePool()
     prog = pg.GateProgram(gpu, [gp.build_gate(k, p, pool) for k, p in ed.GATES], ed.SELECTOR_INDICES, ed.GROUPS,
                           ed.REFERENCE_PUBLIC_INPUTS_HASH, immediates=pool.values)
-    interpreted = _generic(gpu, inst, bufs, log_len, prog=prog)
+    interpreted = _generic(gpu, inst, bufs, EDGE_LOG_LEN, prog=prog)
     assert (interpreted == got).all()
     if which != "non-canonical":
         assert (got == np.array(oracle_quotient(inst, ed.REFERENCE_PUBLIC_INPUTS_HASH), dtype=np.uint64)).all()
-    # the generator's three forms: one function per gate as written (round 4), the same with the peephole pass, and fused units
-    for env, check in (({"PLONKY2_HIP_JIT_FUSE": "0", "PLONKY2_HIP_JIT_PEEPHOLE": "0"},
-                        lambda src: "gl::mul_add_small<" not in src and "gl::sub_small<" not in src and "g_bias[c" not in src and "GateSum gate_8()" in src),
-                       ({"PLONKY2_HIP_JIT_FUSE": "0"},
-                        lambda src: src.count("gl::mul_add_small<1>(") == 1838 and src.count("gl::sub_small<3u>(") == 1838 and "g_bias[c * NGU + " in src),
-                       ({}, lambda src: 0 < src.count("gl::mul_add_small<1>(") < 1000 and "GateSum gate_8()" not in src and "// gate_8" in src)):
-        os.environ.update(env)
-        try:
-            prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
-        finally:
-            for k in env:
-                del os.environ[k]
-        assert check(prog.kernel_source()), env
-        assert (_generic(gpu, inst, bufs, log_len, kernel=prog.kernel) == got).all(), env
+    prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
+    src = prog.kernel_source()
+    assert 0 < src.count("gl::mul_add_small<1>(") < 1000 and "GateSum gate_8()" not in src and "// gate_8" in src
+    assert (_generic(gpu, inst, bufs, EDGE_LOG_LEN, kernel=prog.kernel) == got).all()
+    # the product library reads no switch: the same source whatever the environment says
+    os.environ["PLONKY2_HIP_JIT_FUSE"] = "0"
+    try:
+        prog.compile(ed.NUM_GATE_CONSTRAINTS, 2)
+    finally:
+        del os.environ["PLONKY2_HIP_JIT_FUSE"]
+    assert prog.kernel_source() == src
+    debug_lib = os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip_debug.so")
+    assert os.path.exists(debug_lib), "make -C plonky2_gpu_amd/csrc debug (done by __graft_entry__.build())"
+    child = os.path.join(ROOT, "tests", "gate_jit_variant_child.py")
+    want_sha = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()
+    for env, marks in (({"PLONKY2_HIP_JIT_FUSE": "0", "PLONKY2_HIP_JIT_PEEPHOLE": "0"}, "0 0 0 1 0"),  # as written, one function per gate (round 4)
+                       ({"PLONKY2_HIP_JIT_FUSE": "0"}, "1838 1838 1 1 0")):                      # + the peephole pass
+        r = subprocess.run([sys.executable, child, which], env=dict(os.environ, PLONKY2_HIP_LIBRARY=debug_lib, **env), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "sha256 " + want_sha in r.stdout and "marks " + marks in r.stdout, (env, r.stdout[-500:])
 
 
 def _poly_at(coeffs, x):

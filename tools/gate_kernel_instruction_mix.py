@@ -28,6 +28,8 @@ def compile_into(cache):
     import gen_ed25519_program as gen
 
     os.environ["PLONKY2_HIP_KERNEL_CACHE"] = cache
+    if any(k in os.environ for k in ("PLONKY2_HIP_JIT_FUSE", "PLONKY2_HIP_JIT_PEEPHOLE", "PLONKY2_HIP_JIT_FUSE_GATES", "PLONKY2_HIP_JIT_PREFETCH", "PLONKY2_HIP_JIT_WAVES")):
+        os.environ.setdefault("PLONKY2_HIP_LIBRARY", os.path.join(ROOT, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))  # switches: diagnostic build only
     os.environ.setdefault("PLONKY2_HIP_JIT_FORK", "1")  # no HIP call has been made in this process
     from plonky2_gpu_amd import _lib
 
