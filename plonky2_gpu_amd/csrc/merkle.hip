@@ -211,8 +211,30 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restri
     }
 }
 
+// poseidon::permute with the s-boxes' rare corrections executed always instead of behind a branch (gl::pow7_nb, poseidon_coop.h): for
+// the layers that leave a wave alone on its SIMD, where the permutation's latency is the layer's time.
+__device__ __forceinline__ void permute_latency(uint64_t (&s)[12], const poseidon::MdsOperands &ops) {
+    using poseidon::HALF_FULL;
+    using poseidon::N_PARTIAL;
+    constexpr int W = poseidon::W;
+    poseidon::require_full_wave();
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i]);
+#pragma unroll 1
+    for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {
+        if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
+#pragma unroll
+            for (int i = 0; i < W; i++) s[i] = gl::pow7_nb(s[i]);
+        } else {
+            s[0] = gl::pow7_nb(s[0]);
+        }
+        poseidon::mds_layer(s, ops, POSEIDON_MDS_XY + 2 * W * r);
+    }
+}
+
 // One tree layer for all cap subtrees: parent = two_to_one(left, right) (hashing.rs:65-72).
-// Thread g handles pair q = g mod pairs_per_sub of subtree g / pairs_per_sub at layer L.
+// Thread g handles pair q = g mod pairs_per_sub of subtree g / pairs_per_sub at layer L. LATENCY: the layer has at most one wave per SIMD.
+template <bool LATENCY>
 __global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ digests, uint64_t *__restrict__ cap,
                                                          uint32_t L, uint32_t log_sub_leaves, uint64_t total_pairs) {
     const poseidon::MdsOperands ops = poseidon::mds_operands();
@@ -229,7 +251,10 @@ __global__ __launch_bounds__(256) void tree_layer_kernel(uint64_t *__restrict__ 
     s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y;
     s[4] = c.x; s[5] = c.y; s[6] = d.x; s[7] = d.y;
     s[8] = s[9] = s[10] = s[11] = 0;
-    poseidon::permute(s, ops);
+    if (LATENCY)
+        permute_latency(s, ops);
+    else
+        poseidon::permute(s, ops);
     if (!live) return;
     if (log_pairs == 0)
         store_hash(cap + 4 * sub, s);
@@ -519,6 +544,8 @@ hipError_t coop_tables(poseidon_coop::Tables *tb, hipStream_t stream) {
 // layers with fewer nodes than this cannot fill the chip with one lane per node: they are latency
 // bound, and a wavefront per node shortens the latency
 constexpr uint64_t COOP_LAYER_MAX_NODES = 4096;
+// ... and up to one wave per SIMD (1024 SIMDs x 64 lanes) the lane-per-node kernel runs with the branch-free s-box
+constexpr uint64_t LATENCY_LAYER_MAX_NODES = 65536;
 
 hipError_t tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint32_t log_sub_leaves, hipStream_t stream) {
     uint64_t n_sub = n_leaves >> log_sub_leaves;
@@ -532,8 +559,10 @@ hipError_t tree_layers(uint64_t *digests, uint64_t *cap, uint64_t n_leaves, uint
             }
             hipLaunchKernelGGL(tree_layer_coop_kernel, dim3((unsigned)total), dim3(64), 0, stream, digests, cap, L, log_sub_leaves, tb);
         } else {
-            hipLaunchKernelGGL(tree_layer_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L,
-                               log_sub_leaves, total);
+            if (total <= LATENCY_LAYER_MAX_NODES)
+                hipLaunchKernelGGL(tree_layer_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L, log_sub_leaves, total);
+            else
+                hipLaunchKernelGGL(tree_layer_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, stream, digests, cap, L, log_sub_leaves, total);
         }
     }
     return hipGetLastError();

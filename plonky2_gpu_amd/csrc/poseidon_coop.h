@@ -18,6 +18,40 @@
 #pragma once
 #include "poseidon.h"
 
+// gl::mul with its rare correction executed ALWAYS instead of behind a wave-uniform branch (three more instructions: with no borrow
+// the mask is zero and they change nothing). The branch costs nothing when other waves fill the pipeline while it is resolved; the
+// kernels here — the transcript's sponge, the top layers of a tree — are one wave alone on its SIMD, where every branch drains the
+// vector pipeline (profiles/r05_mul_interleave.jsonl: 29 % of a multiplication chain at one wave per SIMD).
+namespace gl {
+__device__ __forceinline__ uint64_t mul_nb(uint64_t a, uint64_t b) {
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    uint64_t r, c1;
+    asm("v_mad_u64_u32 v[32:33], vcc, %2, %4, 0\n\t"
+        "v_mad_u64_u32 v[34:35], vcc, %2, %5, 0\n\t"
+        "v_mad_u64_u32 v[36:37], %1, %3, %4, v[34:35]\n\t"
+        "v_mad_u64_u32 v[38:39], vcc, %3, %5, 0\n\t"
+        "v_add_co_u32_e32 v33, vcc, v33, v36\n\t"
+        "v_addc_co_u32_e32 v38, vcc, v38, v37, vcc\n\t"
+        "v_addc_co_u32_e32 v39, vcc, 0, v39, vcc\n\t"
+        "v_subb_co_u32_e64 v32, vcc, v32, v39, %1\n\t"
+        "v_subbrev_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"
+        "v_sub_co_u32_e32 v32, vcc, v32, v42\n\t"
+        "v_subbrev_co_u32_e32 v33, vcc, 0, v33, vcc\n\t"
+        "v_mad_u64_u32 v[32:33], vcc, v38, -1, v[32:33]\n\t"
+        "v_cndmask_b32_e64 v42, 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, v42, 1, v[32:33]"
+        : "=&v"(r), "=&s"(c1)
+        : "v"(al), "v"(ah), "v"(bl), "v"(bh)
+        : "vcc", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v42");
+    return r;
+}
+__device__ __forceinline__ uint64_t pow7_nb(uint64_t x) {
+    const uint64_t x2 = mul_nb(x, x), x4 = mul_nb(x2, x2), x3 = mul_nb(x, x2);
+    return mul_nb(x3, x4);
+}
+}  // namespace gl
+
 namespace poseidon_coop {
 
 constexpr int LANES = 64;
@@ -84,7 +118,7 @@ __device__ __forceinline__ uint64_t permute(uint64_t x, const Tables &tb, uint64
 
     auto full_round = [&](int round_ctr) {
         x = gl::add_canonical(x, POSEIDON_ALL_ROUND_CONSTANTS[l12 + 12 * round_ctr]);
-        x = gl::pow7(x);
+        x = gl::pow7_nb(x);
         if (active) lds[lane] = x;
         __syncthreads();
         uint64_t al = 0, ah = 0;
@@ -116,7 +150,7 @@ __device__ __forceinline__ uint64_t permute(uint64_t x, const Tables &tb, uint64
         gl::dot_term(acc, tb.t0[(j - 1) * LANES + lane], sj);
     }
     __syncthreads();
-    uint64_t u = gl::add_canonical(gl::pow7(s0), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[0]);
+    uint64_t u = gl::add_canonical(gl::pow7_nb(s0), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[0]);
     uint64_t d = 0, dq = 0;
 #pragma unroll 1
     for (int q = 0; q < T_ROWS; q++) {
@@ -125,7 +159,7 @@ __device__ __forceinline__ uint64_t permute(uint64_t x, const Tables &tb, uint64
         gl::dot_term(acc, tb.t[q * LANES + lane], us);
         d = gl::dot_finish(acc);
         dq = lane_value(d, q);
-        if (q + 1 < T_ROWS) u = gl::add_canonical(gl::pow7(dq), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[q + 1]);
+        if (q + 1 < T_ROWS) u = gl::add_canonical(gl::pow7_nb(dq), POSEIDON_FAST_PARTIAL_ROUND_CONSTANTS[q + 1]);
     }
     // gather: word 0 = d_21, word i = the accumulator of lane 32+i
     if (lane > 32 && lane < 44) lds[lane - 32] = d;
