@@ -172,6 +172,28 @@ __global__ __launch_bounds__(256) void hash_leaves_chunk_kernel(const uint64_t *
 }
 
 // Same, for leaf-major input rows[i*leaf_len + j] (used by gl_merkle_tree_from_leaves).
+// poseidon::permute with the s-boxes' rare corrections executed always instead of behind a branch (gl::pow7_nb, poseidon_coop.h): for
+// the layers that leave a wave alone on its SIMD, where the permutation's latency is the layer's time.
+__device__ __forceinline__ void permute_latency(uint64_t (&s)[12], const poseidon::MdsOperands &ops) {
+    using poseidon::HALF_FULL;
+    using poseidon::N_PARTIAL;
+    constexpr int W = poseidon::W;
+    poseidon::require_full_wave();
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i]);
+#pragma unroll 1
+    for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {
+        if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
+#pragma unroll
+            for (int i = 0; i < W; i++) s[i] = gl::pow7_nb(s[i]);
+        } else {
+            s[0] = gl::pow7_nb(s[0]);
+        }
+        poseidon::mds_layer(s, ops, POSEIDON_MDS_XY + 2 * W * r);
+    }
+}
+
+template <bool LATENCY>  // at most one wave per SIMD: the permutation with the branch-free s-box (permute_latency)
 __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restrict__ rows, uint32_t leaf_len,
                                                         uint64_t n_leaves, uint64_t *__restrict__ digests,
                                                         uint64_t *__restrict__ cap, uint32_t log_sub_leaves) {
@@ -192,13 +214,13 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restri
         for (; j + 8 <= leaf_len; j += 8) {
 #pragma unroll
             for (int k = 0; k < 8; k++) s[k] = row[j + k];
-            poseidon::permute(s, ops);
+            LATENCY ? permute_latency(s, ops) : poseidon::permute(s, ops);
         }
         if (j < leaf_len) {
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (j + k < leaf_len) s[k] = row[j + k];
-            poseidon::permute(s, ops);
+            LATENCY ? permute_latency(s, ops) : poseidon::permute(s, ops);
         }
     }
     if (!live) return;
@@ -208,27 +230,6 @@ __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *__restri
         uint64_t sub = i >> log_sub_leaves, idx = i & ((1ull << log_sub_leaves) - 1);
         uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
         store_hash(digests + 4 * (sub * sub_digests + digest_slot(idx, 0)), s);
-    }
-}
-
-// poseidon::permute with the s-boxes' rare corrections executed always instead of behind a branch (gl::pow7_nb, poseidon_coop.h): for
-// the layers that leave a wave alone on its SIMD, where the permutation's latency is the layer's time.
-__device__ __forceinline__ void permute_latency(uint64_t (&s)[12], const poseidon::MdsOperands &ops) {
-    using poseidon::HALF_FULL;
-    using poseidon::N_PARTIAL;
-    constexpr int W = poseidon::W;
-    poseidon::require_full_wave();
-#pragma unroll
-    for (int i = 0; i < W; i++) s[i] = gl::add_canonical(s[i], POSEIDON_ALL_ROUND_CONSTANTS[i]);
-#pragma unroll 1
-    for (int r = 0; r < 2 * HALF_FULL + N_PARTIAL; r++) {
-        if (r < HALF_FULL || r >= HALF_FULL + N_PARTIAL) {
-#pragma unroll
-            for (int i = 0; i < W; i++) s[i] = gl::pow7_nb(s[i]);
-        } else {
-            s[0] = gl::pow7_nb(s[0]);
-        }
-        poseidon::mds_layer(s, ops, POSEIDON_MDS_XY + 2 * W * r);
     }
 }
 
@@ -511,6 +512,30 @@ static StripGeom strip_geom(uint32_t n_cols) {
 
 unsigned grid_for(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+// The leaves of a small tree (the later commit-phase trees of FRI: 2^9, 2^5 leaves of 32 elements): one wavefront per leaf, the sponge
+// of hash_rows_kernel with the cooperative permutation — four permutations of 8 us instead of four of 40.
+__global__ __launch_bounds__(64) void hash_rows_coop_kernel(const uint64_t *__restrict__ rows, uint32_t leaf_len, uint64_t *__restrict__ digests,
+                                                            uint64_t *__restrict__ cap, uint32_t log_sub_leaves, poseidon_coop::Tables tb) {
+    __shared__ uint64_t lds[12];
+    const int lane = threadIdx.x;
+    const uint64_t i = blockIdx.x;
+    const uint64_t *row = rows + i * leaf_len;
+    uint64_t x = 0;  // lane k < 12 holds state word k
+    for (uint32_t j = 0; j < leaf_len; j += 8) {  // leaf_len > 4 (hash_or_noop's other case stays with hash_rows_kernel)
+        if (lane < 8 && j + lane < leaf_len) x = row[j + lane];  // overwrite mode: a short last chunk leaves the old words
+        x = poseidon_coop::permute(x, tb, lds);
+    }
+    uint64_t *dst;
+    if (log_sub_leaves == 0) {
+        dst = cap + 4 * i;
+    } else {
+        const uint64_t sub = i >> log_sub_leaves, idx = i & ((1ull << log_sub_leaves) - 1);
+        const uint64_t sub_digests = 2 * ((1ull << log_sub_leaves) - 1);
+        dst = digests + 4 * (sub * sub_digests + digest_slot(idx, 0));
+    }
+    if (lane < 4) dst[lane] = gl::canon(x);
+}
+
 // per-device tables of the cooperative permutation, built on first use
 constexpr int MAX_DEVICES = 64;
 std::mutex g_coop_mutex;
@@ -610,8 +635,16 @@ hipError_t merkle_tree_from_rows(const uint64_t *rows, uint32_t leaf_len, uint64
     int lg = log2_exact(n_leaves);
     if (lg < 0 || (int)cap_height > lg) return hipErrorInvalidValue;
     uint32_t log_sub = lg - cap_height;
-    hipLaunchKernelGGL(hash_rows_kernel, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, rows, leaf_len, n_leaves,
-                       digests, cap, log_sub);
+    if (leaf_len > 4 && n_leaves <= COOP_LAYER_MAX_NODES) {
+        poseidon_coop::Tables tb = {};
+        hipError_t te = coop_tables(&tb, stream);
+        if (te != hipSuccess) return te;
+        hipLaunchKernelGGL(hash_rows_coop_kernel, dim3((unsigned)n_leaves), dim3(64), 0, stream, rows, leaf_len, digests, cap, log_sub, tb);
+    } else if (n_leaves <= LATENCY_LAYER_MAX_NODES) {
+        hipLaunchKernelGGL(hash_rows_kernel<true>, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, rows, leaf_len, n_leaves, digests, cap, log_sub);
+    } else {
+        hipLaunchKernelGGL(hash_rows_kernel<false>, dim3(grid_for(n_leaves, 256)), dim3(256), 0, stream, rows, leaf_len, n_leaves, digests, cap, log_sub);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return tree_layers(digests, cap, n_leaves, log_sub, stream);
