@@ -37,6 +37,18 @@ __device__ __forceinline__ uint64_t root_pow(const uint64_t *twl, const uint64_t
 
 __device__ __forceinline__ uint64_t inverse(uint64_t x) { return gl::pow(x, gl::P - 2); }
 
+// x^(p-2): with e_k = x^(2^k - 1), p - 2 = (2^31 - 1) 2^33 + (2^32 - 1)
+__device__ __forceinline__ uint64_t inverse_chain(uint64_t x) {
+    auto sqn = [](uint64_t v, int k) {
+        for (int i = 0; i < k; i++) v = gl::sqr(v);
+        return v;
+    };
+    const uint64_t e2 = gl::mul(gl::sqr(x), x), e3 = gl::mul(gl::sqr(e2), x), e6 = gl::mul(sqn(e3, 3), e3), e12 = gl::mul(sqn(e6, 6), e6);
+    const uint64_t e15 = gl::mul(sqn(e12, 3), e3), e30 = gl::mul(sqn(e15, 15), e15), e31 = gl::mul(gl::sqr(e30), x), e32 = gl::mul(gl::sqr(e31), x);
+    return gl::mul(sqn(e31, 33), e32);
+}
+
+
 // One thread per (row i, challenge c): cumulative chunk quotients c_k(i) = prod_{m<=k} q_m(i) written to
 // the partial-product slots (k < num_prods) and the row total r_i to the Z slot.
 __global__ __launch_bounds__(256) void perm_quotients_kernel(const uint64_t *__restrict__ wires, uint64_t wires_stride,
@@ -54,22 +66,54 @@ __global__ __launch_bounds__(256) void perm_quotients_kernel(const uint64_t *__r
     const uint64_t bx = gl::mul(beta, root_pow(twl, twh, log_n, i));  // beta * x, x = w_n^i (prover_data.subgroup)
     uint64_t *z_slot = out + (uint64_t)c * n;
     uint64_t *pp_base = out + ((uint64_t)num_challenges + (uint64_t)c * num_prods) * n;
-    uint64_t cum = 1;
-    uint32_t k = 0;
-    for (uint32_t j0 = 0; j0 < num_routed; j0 += degree, k++) {
-        uint64_t num = 1, den = 1;
-        uint32_t j1 = j0 + degree < num_routed ? j0 + degree : num_routed;
+    // The chunk quotients need 1 / den_k for every chunk: one inversion for all of them (the reference's batch_multiplicative_inverse,
+    // util/partial_products.rs:29-37): forward, the running products N_k of the numerators and D_k of the denominators; 1 / D_last by an
+    // addition chain; backward, 1 / D_k = (1 / D_{k+1}) den_{k+1}. Ten Fermat inversions per thread were four fifths of this kernel.
+    constexpr uint32_t MAX_CHUNKS = 16;
+    const uint32_t chunks = (num_routed + degree - 1) / degree;
+    auto chunk = [&](uint32_t k, uint64_t &num, uint64_t &den) {
+        num = den = 1;
+        const uint32_t j0 = k * degree, j1 = j0 + degree < num_routed ? j0 + degree : num_routed;
         for (uint32_t j = j0; j < j1; j++) {
             uint64_t w = wires[j * wires_stride + i];
             uint64_t wg = gl::add(w, gamma);
             num = gl::mul(num, gl::add(wg, gl::mul(bx, k_is[j])));                      // w + beta*k_j*x + gamma
             den = gl::mul(den, gl::add(wg, gl::mul(beta, sigmas[j * sigmas_stride + i])));  // w + beta*sigma + gamma
         }
-        cum = gl::mul(cum, gl::mul(num, inverse(den)));
+    };
+    auto store = [&](uint32_t k, uint64_t cum) {
         if (k < num_prods)
             pp_base[(uint64_t)k * n + i] = gl::canon(cum);
         else
             z_slot[i] = gl::canon(cum);
+    };
+    uint64_t running_n[MAX_CHUNKS], dens[MAX_CHUNKS];
+    uint64_t pn = 1, pd = 1;
+    if (chunks <= MAX_CHUNKS) {
+        for (uint32_t k = 0; k < chunks; k++) {
+            uint64_t num, den;
+            chunk(k, num, den);
+            pn = gl::mul(pn, num);
+            pd = gl::mul(pd, den);
+            running_n[k] = pn;
+            dens[k] = den;
+        }
+    }
+    if (chunks <= MAX_CHUNKS && gl::canon(pd) != 0) {
+        uint64_t inv = inverse_chain(pd);  // 1 / D_k, k = chunks - 1 downwards
+        for (uint32_t k = chunks; k-- > 0;) {
+            store(k, gl::mul(running_n[k], inv));
+            inv = gl::mul(inv, dens[k]);
+        }
+        return;
+    }
+    // a zero denominator (the reference panics there; here its chunk's quotient is 0 as before), or more chunks than the arrays hold
+    uint64_t cum = 1;
+    for (uint32_t k = 0; k < chunks; k++) {
+        uint64_t num, den;
+        chunk(k, num, den);
+        cum = gl::mul(cum, gl::mul(num, inverse(den)));
+        store(k, cum);
     }
 }
 
@@ -332,17 +376,6 @@ namespace {
 struct ZhTable {
     uint64_t zh[16], zh_inv[16];
 };
-
-// x^(p-2): with e_k = x^(2^k - 1), p - 2 = (2^31 - 1) 2^33 + (2^32 - 1)
-__device__ __forceinline__ uint64_t inverse_chain(uint64_t x) {
-    auto sqn = [](uint64_t v, int k) {
-        for (int i = 0; i < k; i++) v = gl::sqr(v);
-        return v;
-    };
-    const uint64_t e2 = gl::mul(gl::sqr(x), x), e3 = gl::mul(gl::sqr(e2), x), e6 = gl::mul(sqn(e3, 3), e3), e12 = gl::mul(sqn(e6, 6), e6);
-    const uint64_t e15 = gl::mul(sqn(e12, 3), e3), e30 = gl::mul(sqn(e15, 15), e15), e31 = gl::mul(gl::sqr(e30), x), e32 = gl::mul(gl::sqr(e31), x);
-    return gl::mul(sqn(e31, 33), e32);
-}
 
 template <int NCH>
 __global__ __launch_bounds__(128) void quotient_values_fast_kernel(const QuotientParams p, const ZhTable zt) {
