@@ -12,7 +12,8 @@ P = lambda *a: os.path.join(ROOT, *a)  # noqa: E731
 
 def other_devices():
     rows = []
-    for name, what in (("r05_bench_before_latency_forms", "before the branch-free s-boxes of the small kernels"), ("r05_bench_third_device_final_code", "same as the last"), ("r05_bench_fused_units_before_quotient_values_kernel", "before the quotient_values kernel"),
+    for name, what in (("r05_bench_final_code_another_device", "the final code — with the partial products' single inversion, which came after this table's call — on a slower device"),
+                       ("r05_bench_before_latency_forms", "before the branch-free s-boxes of the small kernels"), ("r05_bench_third_device_final_code", "same as the last"), ("r05_bench_fused_units_before_quotient_values_kernel", "before the quotient_values kernel"),
                        ("r05_bench_before_fused_units", "one function per gate"), ("r05_bench_fast_device_before_gate_codegen", "round-4 generator"),
                        ("r05_bench_another_device", "round-4 generator")):
         d = json.loads(open(P("profiles", name + ".json")).read())
