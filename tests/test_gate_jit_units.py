@@ -118,3 +118,26 @@ def test_a_program_that_cannot_be_generated_is_reported(tmp_path):
     out = run(tmp_path, BREAK="1")
     assert "error:" in out and "opcode" in out, out
     assert objects(tmp_path) == []
+
+
+def test_build_leaves_exactly_the_current_units_in_the_kernel_cache():
+    """__graft_entry__.precompile_gate_kernels() (part of build()): whatever the cache held — units of an earlier generator, a unit
+    missing — afterwards it holds the units of the current generator for the compiled-in ed25519 table, all of them and nothing else.
+    (Until round 5 it deleted every file that had been there before whenever ONE unit was new, the unchanged units included.)"""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+
+    cache = os.path.join(ROOT, "plonky2_gpu_amd", "kernel_cache")
+    g.precompile_gate_kernels()
+    good = set(os.listdir(cache))
+    assert good and len([f for f in good if f.endswith(".hsaco")]) * 2 == len(good), good  # a .hip beside every .hsaco
+    victim = sorted(f for f in good if f.endswith(".hsaco"))[0]
+    os.remove(os.path.join(cache, victim))
+    os.remove(os.path.join(cache, victim[:-6] + ".hip"))
+    for stale in ("gate_0000000000000000.hsaco", "gate_0000000000000000.hip"):
+        with open(os.path.join(cache, stale), "wb") as f:
+            f.write(b"stale")
+    g.precompile_gate_kernels()
+    assert set(os.listdir(cache)) == good
+    g.precompile_gate_kernels()  # and a third call changes nothing
+    assert set(os.listdir(cache)) == good
