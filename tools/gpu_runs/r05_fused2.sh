@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: fused units, second form of the scheduler (values wait for their consumers, stale wires are re-loaded, scalar loads are
 # not merged across gates): the rare-path parity test, then the ed25519 quotient for waves per SIMD x gates per unit, one device
 cd "$GRAFT_REPO_ROOT" || exit 1

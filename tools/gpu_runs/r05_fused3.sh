@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: fused units with the wire loads issued ahead of their use: waves per SIMD x gates per unit x statements ahead, one device
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r05fused3; mkdir -p $O

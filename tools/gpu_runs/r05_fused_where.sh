@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: where the fused gate kernels' time goes: the same arithmetic without wire loads / without the alpha table / without both
 # (experiment knobs of a scratch build, wrong results), one device
 cd "$GRAFT_REPO_ROOT" || exit 1

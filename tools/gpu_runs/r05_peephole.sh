@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: the peephole pass of the gate-kernel generator (short forms for small constants, a limb's range check as a square): parity of
 # everything that runs compiled gates, then the ed25519 quotient with the pass and without it on one device, then the prove stages
 cd "$GRAFT_REPO_ROOT" || exit 1

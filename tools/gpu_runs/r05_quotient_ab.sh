@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # A/B of the gate-kernel code generation on one device: wire loads as buffer loads (JITX_LOADS) and ACC as asm multiply-adds (JITX_ACC)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r05quotient; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: is the ed25519 quotient's gate kernel bound by its loads? (1) HBM-side and L2 counters of the unit kernels, (2) the same
 # arithmetic with every wire load redirected to 4 columns (experiment knob, wrong results), (3) units = 1 / 2 / 4 / 8
 cd "$GRAFT_REPO_ROOT" || exit 1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (a record of a run made BEFORE the generator's switches moved to the diagnostic build, some with knobs of scratch builds that no longer exist:
+# to repeat what still applies, export PLONKY2_HIP_LIBRARY=$GRAFT_REPO_ROOT/plonky2_gpu_amd/libplonky2_hip_debug.so)
 # round 5: the gate kernels with their wire loads replaced by arithmetic on the row index (experiment knob JITX_NOLOAD; wrong results,
 # same field arithmetic, nothing the compiler can merge) against the real ones; FETCH_SIZE of the real ones
 cd "$GRAFT_REPO_ROOT" || exit 1
