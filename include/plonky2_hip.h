@@ -17,21 +17,27 @@
  *     values (< p), i.e. exactly what the reference yields after `to_canonical_u64`.
  *   - All `d_*` pointers are DEVICE pointers. The callee allocates nothing for data: the caller
  *     owns every buffer (as in the reference, plonky2/src/fri/oracle.rs:94-106). The library keeps,
- *     per device, a few hundred KiB of twiddle tables and one 128 MiB workspace (created by
- *     gl_ctx_create()/init() or on first use) that the natural-order transforms, the scans
+ *     per device, a few hundred KiB of read-only twiddle tables, and per CONTEXT one workspace of
+ *     gl_workspace_bytes() = 512 MiB (allocated by gl_ctx_create(), or on the first call that sees a
+ *     caller-built context; gl_ctx_set_workspace() hands in the caller's own memory instead, for a
+ *     host that sizes all device memory up front) that the natural-order transforms, the scans
  *     (partial products, divide_by_linear), the opening partial sums, gl_sponge_absorb,
- *     gl_merkle_open_batch and gl_fri_proof_of_work stage through. That workspace (like the event
- *     pair of the commit and the constant tables of a compiled gate kernel) exists once per device.
- *     Several contexts or host threads on one device are SAFE but not concurrent: every entry point
- *     that takes a ctx serialises its enqueue phase per device and, when the stream changes from one
- *     call to the next, makes the new stream wait for what the previous one has queued, so contexts
- *     take turns. The reference's callers are single-threaded and synchronous (oracle.rs:394-422);
- *     for throughput use one context per device and one process per GPU. A circuit handle and its
- *     buffer pool (gl_circuit_create) belong to one thread at a time.
+ *     gl_merkle_open_batch and gl_fri_proof_of_work stage through, plus the commit's event pair and
+ *     its low-priority hashing stream.
+ *     Several contexts on one device run CONCURRENTLY (up to version 0.5 they took turns): nothing
+ *     mutable is shared between them, so two host threads, each with its own context, keep two
+ *     proofs in flight on one GPU and each fills the other's latency-bound phases (transcript,
+ *     small tree layers, openings). One context is used by one host thread at a time; data shared
+ *     by two contexts is the caller's to order, as with any two streams. Two things are still taken
+ *     in turns, because their constant tables exist once: launches of ONE compiled gate kernel
+ *     (gl_gate_kernel_build; proofs of one circuit handle on two contexts overlap everywhere
+ *     except in the gate kernels) and the reference symbol compute_quotient_polys per device.
+ *     A circuit handle (gl_circuit_create) may be proven with from several contexts at once; it
+ *     keeps one buffer pool per context.
  *     Three entry points do allocate device memory themselves: gl_circuit_create (the preprocessed
  *     commitment, freed by gl_circuit_destroy) and gl_prove (every buffer of one proof), because their
  *     job is to own a whole computation, and the reference symbol compute_quotient_polys (a staging
- *     buffer, see there; gl_reference_quotient_release).
+ *     buffer, unless the caller provides it: gl_reference_quotient_set_staging).
  *   - Errors are returned BY VALUE as {code, message}; code 0 = success; `message` is
  *     malloc'ed (strdup) and owned by the caller, who frees it with free() — the convention of
  *     cuda/src/lib.rs:21-35 / cuda/plonky2_gpu.cu:19-31.
@@ -76,6 +82,18 @@ int gl_device_count(void);
 void *gl_ctx_create(int device); /* NULL on failure; also makes `device` current */
 void gl_ctx_destroy(void *ctx);
 GlError gl_ctx_synchronize(void *ctx); /* waits for both streams */
+/* A caller-built context ({stream, stream2} made with the host's own HIP binding, e.g. the reference's
+ * CudaInnerContext through rustacuda_hip) gets its library-side state (workspace, events, hashing stream) on the
+ * first call that sees it, keyed by ctx->stream; gl_ctx_release() waits for both streams and gives that state back
+ * (before the caller destroys its streams). gl_ctx_destroy() = gl_ctx_release() + destroying the streams it created. */
+void gl_ctx_release(void *ctx);
+/* The workspace of a context: gl_workspace_bytes() bytes (constant for a build: 512 MiB). gl_ctx_set_workspace()
+ * replaces the library's allocation by `d_workspace` (>= gl_workspace_bytes() bytes, 16-byte aligned, on the context's
+ * device, the caller's to free after gl_ctx_release / gl_ctx_destroy) — the reference's memory contract, in which the
+ * caller sizes every device buffer once up front (fri/oracle.rs:94-106) and the callee allocates nothing.
+ * d_workspace = NULL goes back to a library-owned one. Waits for the context's stream. */
+uint64_t gl_workspace_bytes(void);
+GlError gl_ctx_set_workspace(void *ctx, void *d_workspace, uint64_t bytes);
 
 /* Thin device-memory helpers for hosts without a HIP binding (synchronous). gl_malloc allocates on the calling
  * thread's CURRENT device; gl_ctx_malloc on the device of `ctx` (and makes it current) — what a host with several
@@ -488,15 +506,23 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
  * build (__graft_entry__.build()) puts the precompiled code objects. gl_reference_quotient_prepare() does it ahead of
  * the first proof.
  * The reference also compiles in the hash of one proof's public inputs (plonky2_gpu.cu:686-689); the same value is
- * the default here, and gl_reference_set_public_inputs_hash() replaces it (process-wide; NULL restores the default).
+ * the default here; gl_reference_set_public_inputs_hash_ctx() sets the value for the calls of ONE context (two circuits in one
+ * process, each proving on its own context, do not race), gl_reference_set_public_inputs_hash() the process-wide value that
+ * contexts without their own use (NULL restores the default in both).
  * Device memory: the kernels read column-major data 2.5x faster than leaf-major rows (a 1872-byte stride between
- * the lanes of a wave), so the call first transposes the three inputs into a staging buffer the LIBRARY owns —
- * (234 + salt_size + 88 + 20) * n_ext * 8 bytes per device (5.7 GB at log_len 18), allocated on first use, kept for
- * the next proof, freed by gl_reference_quotient_release(). If it cannot be allocated, or with
- * PLONKY2_HIP_REFERENCE_IN_PLACE=1 in the environment, the rows are read in place (same result, slower). */
+ * the lanes of a wave), so the call first transposes the three inputs into a staging buffer of
+ * gl_reference_quotient_staging_bytes(log_len) = (234 + 88 + 20) * n_ext * 8 bytes per device (5.7 GB at log_len 18; salt
+ * columns add salt_size * n_ext * 8). Either the CALLER provides it — gl_reference_quotient_set_staging(d_ptr, bytes) on the
+ * current device, the reference's contract of a callee that allocates nothing; a buffer too small for a call is not used —
+ * or the library allocates it on first use, keeps it for the next proof and frees it in gl_reference_quotient_release().
+ * Without a staging buffer (allocation failed, too small, or PLONKY2_HIP_REFERENCE_IN_PLACE=1 in the environment) the
+ * rows are read in place (same result, slower). Calls of compute_quotient_polys on one device take turns. */
 GlError gl_reference_quotient_prepare(void *ctx);
 GlError gl_reference_quotient_release(void);
+uint64_t gl_reference_quotient_staging_bytes(int log_len);
+GlError gl_reference_quotient_set_staging(void *d_staging /* NULL: library-owned again */, uint64_t bytes);
 GlError gl_reference_set_public_inputs_hash(const uint64_t *h_hash /* 4, host */);
+GlError gl_reference_set_public_inputs_hash_ctx(const uint64_t *h_hash /* 4, host */, void *ctx);
 GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_num, int values_num_per_poly,
                                int log_len, const uint64_t *d_root_table2, const uint64_t *d_shift_inv_powers,
                                int rate_bits, int salt_size, const GlDataSlice *zs_partial_products_commitment_leaves,

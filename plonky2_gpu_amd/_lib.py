@@ -135,6 +135,9 @@ SIGNATURES = {
     "gl_ctx_create": (_vp, [_i]),
     "gl_ctx_destroy": (None, [_vp]),
     "gl_ctx_synchronize": (GlError, [_vp]),
+    "gl_ctx_release": (None, [_vp]),
+    "gl_workspace_bytes": (_u64, []),
+    "gl_ctx_set_workspace": (GlError, [_vp, _vp, _u64]),
     "gl_pack_leaf_ranges": (GlError, [_vp, _u64, _u32, _u64, _u32, _vp, _vp]),
     "gl_malloc": (GlError, [ctypes.POINTER(_vp), _u64]),
     "gl_ctx_malloc": (GlError, [ctypes.POINTER(_vp), _u64, _vp]),
@@ -193,6 +196,9 @@ SIGNATURES = {
     "gl_reference_quotient_prepare": (GlError, [_vp]),
     "gl_reference_quotient_release": (GlError, []),
     "gl_reference_set_public_inputs_hash": (GlError, [_vp]),
+    "gl_reference_set_public_inputs_hash_ctx": (GlError, [_vp, _vp]),
+    "gl_reference_quotient_staging_bytes": (_u64, [_i]),
+    "gl_reference_quotient_set_staging": (GlError, [_vp, _u64]),
     "cudaGetErrorString": (ctypes.c_char_p, [_i]),
 }
 

@@ -1,6 +1,7 @@
 // capi.hip — the extern "C" boundary of libplonky2_hip.so (declared in include/plonky2_hip.h).
 #include <algorithm>
 #include <list>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -50,32 +51,41 @@ struct CosetEntry {
 };
 struct DeviceState {
     bool have_tables = false;
-    NttTables tables;
+    NttTables tables;              // twl / twh only: the workspace belongs to a context (CtxState)
     std::list<CosetEntry> cosets;  // LRU cache keyed by (log_n, rate_bits, shift); addresses are stable
     uint64_t coset_tick = 0;
-    hipEvent_t ev[2] = {nullptr, nullptr};
     GateKernel *ed25519_kernel = nullptr;  // the reference symbol compute_quotient_polys' circuit, built on first use
-    // DeviceCall: contexts take turns on this device's shared state
-    std::recursive_mutex call_mu;
-    hipStream_t last_stream = nullptr;
-    hipEvent_t order_event = nullptr;
-    hipStream_t hash_stream = nullptr;     // pipelined commit: leaf hashing trails the LDE on this lower-priority stream
-    std::vector<hipEvent_t> chunk_events;  //   one event per column chunk + one for "tree done"
+    std::mutex ref_mu;                     // compute_quotient_polys calls on this device take turns (one kernel object, one staging buffer)
     uint64_t *ref_staging = nullptr;       // its column-major staging copy of the three leaf-major inputs
     uint64_t ref_staging_elems = 0;
+    bool ref_staging_owned = false;        // false: handed over by gl_reference_quotient_set_staging
 };
 constexpr size_t COSET_CACHE_ENTRIES = 64;  // a prover uses a handful (one shift, a few sizes); 80 KiB each at 2^18 x 8
 std::mutex g_mu;
 DeviceState g_dev[64];
 
-hipError_t get_tables(const NttTables **out) {
+// Everything mutable that a call touches besides the caller's buffers belongs to the CONTEXT: the workspace of the natural-order
+// multi-pass transforms (also the scans' totals, the openings' partial sums, the transcript's state), the event pair, the
+// low-priority hashing stream of the pipelined commit and its events. Two contexts on one device therefore share only read-only
+// tables, and their calls run concurrently — two proofs in flight fill each other's latency-bound phases (transcript, small tree
+// layers, openings). Keyed by the context's first stream, so that a caller-built {stream, stream2} pair (the reference's
+// CudaInnerContext, fri/oracle.rs:43-47) gets its state on first use; gl_ctx_destroy / gl_ctx_release give it back.
+struct CtxState {
     int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_mu);
+    NttTables tb;  // twl / twh of the device, scratch of this context
+    bool scratch_owned = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t hash_stream = nullptr;     // pipelined commit: leaf hashing trails the LDE on this lower-priority stream
+    std::vector<hipEvent_t> chunk_events;  //   one event per column chunk + one for "tree done"
+    bool have_pih = false;                 // gl_reference_set_public_inputs_hash_ctx
+    uint64_t pih[4] = {0, 0, 0, 0};
+};
+std::map<hipStream_t, CtxState *> g_ctx;  // g_mu
+
+hipError_t device_tables(int dev, const NttTables **out) {  // g_mu held
     DeviceState &st = g_dev[dev & 63];
     if (!st.have_tables) {
-        e = ntt_tables_create(&st.tables);
+        hipError_t e = ntt_tables_create(&st.tables);
         if (e != hipSuccess) return e;
         st.have_tables = true;
     }
@@ -83,20 +93,86 @@ hipError_t get_tables(const NttTables **out) {
     return hipSuccess;
 }
 
-hipError_t get_events(hipEvent_t *a, hipEvent_t *b) {
+void ctx_state_free(CtxState *c) {  // the caller has synchronised the context's streams
+    if (c->scratch_owned && c->tb.scratch) (void)hipFree(c->tb.scratch);
+    for (hipEvent_t e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->hash_stream) {
+        (void)hipStreamSynchronize(c->hash_stream);
+        (void)hipStreamDestroy(c->hash_stream);
+    }
+    for (hipEvent_t e : c->chunk_events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
+
+// The state of `ctx` on the current device (DeviceCall has made the context's device current), created on first use.
+hipError_t ctx_state(void *ctx, CtxState **out) {
+    if (!ctx) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_mu);
-    DeviceState &st = g_dev[dev & 63];
-    if (!st.ev[0]) {
+    auto it = g_ctx.find(S(ctx)->stream);
+    if (it != g_ctx.end() && it->second->dev != dev) {  // a stream handle of a context that was never released, reused on another device
+        ctx_state_free(it->second);
+        g_ctx.erase(it);
+        it = g_ctx.end();
+    }
+    if (it == g_ctx.end()) {
+        const NttTables *dt;
+        e = device_tables(dev, &dt);
+        if (e != hipSuccess) return e;
+        CtxState *c = new CtxState();
+        c->dev = dev;
+        c->tb = *dt;
+        c->tb.scratch_elems = NTT_SCRATCH_ELEMS;
+        e = hipMalloc(&c->tb.scratch, NTT_SCRATCH_ELEMS * sizeof(uint64_t));
+        if (e != hipSuccess) {
+            delete c;
+            return e;
+        }
+        c->scratch_owned = true;
+        it = g_ctx.emplace(S(ctx)->stream, c).first;
+    }
+    *out = it->second;
+    return hipSuccess;
+}
+
+void ctx_state_release(void *ctx) {
+    if (!ctx) return;
+    CtxState *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(S(ctx)->stream);
+        if (it == g_ctx.end()) return;
+        c = it->second;
+        g_ctx.erase(it);
+    }
+    ctx_state_free(c);
+}
+
+hipError_t get_tables(void *ctx, const NttTables **out) {
+    CtxState *c;
+    hipError_t e = ctx_state(ctx, &c);
+    if (e != hipSuccess) return e;
+    *out = &c->tb;
+    return hipSuccess;
+}
+
+hipError_t get_events(void *ctx, hipEvent_t *a, hipEvent_t *b) {
+    CtxState *c;
+    hipError_t e = ctx_state(ctx, &c);
+    if (e != hipSuccess) return e;
+    if (!c->ev[0]) {  // only the context's own caller thread gets here
         for (int i = 0; i < 2; i++) {
-            e = hipEventCreateWithFlags(&st.ev[i], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
             if (e != hipSuccess) return e;
         }
     }
-    *a = st.ev[0];
-    *b = st.ev[1];
+    *a = c->ev[0];
+    *b = c->ev[1];
     return hipSuccess;
 }
 
@@ -189,8 +265,6 @@ GlError get_ed25519_kernel(const GateKernel **out) {
     return ok();
 }
 
-Streams *S(void *ctx) { return static_cast<Streams *>(ctx); }
-
 // Device of a context = device of its first stream; makes it the calling thread's current device.
 bool ctx_device(void *ctx, int *dev) {
     if (ctx && S(ctx)->stream) {
@@ -205,44 +279,21 @@ bool ctx_device(void *ctx, int *dev) {
     return hipGetDevice(dev) == hipSuccess;
 }
 
-// The workspace, the event pair and the gate kernels' constant tables exist once per device. The reference's callers
-// are single-threaded, but a second context on the same device must not be able to corrupt results silently: every
-// entry point that takes a ctx holds this guard while it enqueues. It (1) serialises the enqueue phase of calls on
-// one device across host threads (recursive: entry points call each other), and (2) when the call's stream differs
-// from the previous call's, makes the new stream wait for everything queued on the previous one. Contexts therefore
-// take turns — correct, not concurrent; use one process per GPU, or one context, for throughput.
+// Every entry point that takes a ctx runs on the device its context's streams belong to, whatever device the calling thread
+// has current: tables, workspace and every allocation made inside the call follow it (a context created on device 1 and used
+// from a thread whose current device is still 0 must not touch device 0's state). The device comes from the stream itself, so
+// a caller-built {stream, stream2} pair (the reference's CudaInnerContext) works too. Nothing is locked and nothing is ordered
+// across contexts (up to round 5 the workspace and the event pair existed once per device and contexts took turns): a context
+// is used by one host thread at a time, different contexts by different threads at the same time; data shared between two
+// contexts is the caller's to order, as with any two streams.
 class DeviceCall {
 public:
     explicit DeviceCall(void *ctx) {
-        // The call runs on the device its context's streams belong to, whatever device the calling thread has current:
-        // tables, workspace, guard and every allocation made inside the call follow it (a context created on device 1
-        // and used from a thread whose current device is still 0 must not touch device 0's state). The device comes
-        // from the stream itself, so a caller-built {stream, stream2} pair (the reference's CudaInnerContext) works too.
         int dev = 0;
-        if (!ctx_device(ctx, &dev)) {
-            (void)hipGetLastError();
-            return;
-        }
-        st_ = &g_dev[dev & 63];
-        st_->call_mu.lock();
-        hipStream_t s = ctx ? S(ctx)->stream : nullptr;
-        if (!s) return;
-        if (st_->last_stream && st_->last_stream != s) {
-            bool ok = st_->order_event || hipEventCreateWithFlags(&st_->order_event, hipEventDisableTiming) == hipSuccess;
-            if (ok) ok = hipEventRecord(st_->order_event, st_->last_stream) == hipSuccess;
-            if (ok) ok = hipStreamWaitEvent(s, st_->order_event, 0) == hipSuccess;
-            if (!ok) (void)hipGetLastError();  // the other stream is gone: nothing of it is left to wait for
-        }
-        st_->last_stream = s;
-    }
-    ~DeviceCall() {
-        if (st_) st_->call_mu.unlock();
+        if (!ctx_device(ctx, &dev)) (void)hipGetLastError();
     }
     DeviceCall(const DeviceCall &) = delete;
     DeviceCall &operator=(const DeviceCall &) = delete;
-
-private:
-    DeviceState *st_ = nullptr;
 };
 
 __global__ void bit_reverse_columns_kernel(uint64_t *v, uint32_t log_n, uint64_t total) {
@@ -407,27 +458,25 @@ bool commit_pipeline_enabled() {
     return v;
 }
 
-hipError_t get_hash_stream(hipStream_t *hs, std::vector<hipEvent_t> **events, size_t need) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+hipError_t get_hash_stream(void *ctx, hipStream_t *hs, std::vector<hipEvent_t> **events, size_t need) {
+    CtxState *c;
+    hipError_t e = ctx_state(ctx, &c);
     if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_mu);
-    DeviceState &st = g_dev[dev & 63];
-    if (!st.hash_stream) {
+    if (!c->hash_stream) {
         int lo = 0, hi = 0;  // numerically lower = higher priority; the hashing takes the LOWEST so that the LDE runs ahead
         e = hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (e != hipSuccess) return e;
-        e = hipStreamCreateWithPriority(&st.hash_stream, hipStreamNonBlocking, lo);
+        e = hipStreamCreateWithPriority(&c->hash_stream, hipStreamNonBlocking, lo);
         if (e != hipSuccess) return e;
     }
-    while (st.chunk_events.size() < need) {
+    while (c->chunk_events.size() < need) {
         hipEvent_t ev;
         e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) return e;
-        st.chunk_events.push_back(ev);
+        c->chunk_events.push_back(ev);
     }
-    *hs = st.hash_stream;
-    *events = &st.chunk_events;
+    *hs = c->hash_stream;
+    *events = &c->chunk_events;
     return hipSuccess;
 }
 
@@ -442,7 +491,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     const uint64_t n = 1ull << log_n, n_ext = n << rate_bits;
     const NttTables *tb;
     CosetLease ct;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(s, &tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, s->stream, &ct));
     (void)sync_stream2_before_leaves;
     const uint32_t leaf_len = (uint32_t)(poly_num + salt_size);
@@ -458,7 +507,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         // the caller's back (its gl_ctx_synchronize and frees only cover its own stream): the failing path waits for both.
         auto pipelined = [&]() -> GlError {
         std::vector<hipEvent_t> *evs;
-        HIP_TRY(get_hash_stream(&hs, &evs, n_chunks + 2));
+        HIP_TRY(get_hash_stream(s, &hs, &evs, n_chunks + 2));
         // the hash stream starts behind whatever the caller has queued (the buffers may still be in use by earlier work)
         HIP_TRY(hipEventRecord((*evs)[n_chunks], s->stream));
         HIP_TRY(hipStreamWaitEvent(hs, (*evs)[n_chunks], 0));
@@ -481,7 +530,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
             // d_leaves may still be read by what the caller queued on stream2 (the reference's caller has its D2H of the
             // coefficients there, oracle.rs:403-407, and region A is overwritten by the leaves, plonky2_gpu.cu:586)
             hipEvent_t ev_a = nullptr, ev_b = nullptr;
-            HIP_TRY(get_events(&ev_a, &ev_b));
+            HIP_TRY(get_events(s, &ev_a, &ev_b));
             HIP_TRY(hipEventRecord(ev_a, s->stream2));
             if (!PLONKY2_KNOB("PLONKY2_DROP_STREAM2_WAIT"))  // diagnostic build: shows that tests/test_gpu_stream2.py notices the loss
                 HIP_TRY(hipStreamWaitEvent(hs, ev_a, 0));
@@ -507,7 +556,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         if (rows_from) HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, leaf_len, rows_from, n_ext, hs));
         hipEvent_t ev_lde2 = nullptr, ev_tr2 = nullptr;
         if (d_leaves && !fused) {
-            HIP_TRY(get_events(&ev_lde2, &ev_tr2));
+            HIP_TRY(get_events(s, &ev_lde2, &ev_tr2));
             HIP_TRY(hipEventRecord(ev_lde2, s->stream));
             HIP_TRY(hipStreamWaitEvent(s->stream2, ev_lde2, 0));
             HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, leaf_len, n_ext, n_ext, s->stream2));
@@ -530,7 +579,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
     hipEvent_t ev_lde = nullptr, ev_tr = nullptr;
     const bool fused = d_leaves && fused_leaves_enabled();
     if (fused) {
-        HIP_TRY(get_events(&ev_lde, &ev_tr));  // stream2's earlier work (see above) before d_leaves is written
+        HIP_TRY(get_events(s, &ev_lde, &ev_tr));  // stream2's earlier work (see above) before d_leaves is written
         HIP_TRY(hipEventRecord(ev_lde, s->stream2));
         if (!PLONKY2_KNOB("PLONKY2_DROP_STREAM2_WAIT")) HIP_TRY(hipStreamWaitEvent(s->stream, ev_lde, 0));
     } else if (d_leaves) {
@@ -540,7 +589,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
         // caller has its D2H of the coefficients there (oracle.rs:403-407), which is exactly what
         // must finish before region A is overwritten (plonky2_gpu.cu:586), now by stream order
         // instead of a host-side stream synchronise.
-        HIP_TRY(get_events(&ev_lde, &ev_tr));
+        HIP_TRY(get_events(s, &ev_lde, &ev_tr));
         HIP_TRY(hipEventRecord(ev_lde, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->stream2, ev_lde, 0));
         HIP_TRY(transpose_to_leaf_major(d_lde, d_leaves, (uint32_t)(poly_num + salt_size), n_ext, n_ext, s->stream2));
@@ -556,7 +605,7 @@ GlError commit_from_coeffs_impl(const uint64_t *d_coeffs, uint64_t poly_num, uin
 
 extern "C" {
 
-const char *gl_version(void) { return "plonky2_hip 0.5.0 gfx950"; }
+const char *gl_version(void) { return "plonky2_hip 0.6.0 gfx950"; }
 
 int gl_device_count(void) {
     int n = 0;
@@ -573,30 +622,57 @@ void *gl_ctx_create(int device) {
         free(s);
         return nullptr;
     }
-    const NttTables *tb;
-    if (get_tables(&tb) != hipSuccess) {
+    CtxState *c;
+    if (ctx_state(s, &c) != hipSuccess) {  // the device's tables and this context's workspace, now rather than inside the first call
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(s->stream);
+        (void)hipStreamDestroy(s->stream2);
         free(s);
         return nullptr;
     }
     return s;
 }
 
-void gl_ctx_destroy(void *ctx) {
-    {  // the device must not try to order later calls after a stream that no longer exists
-        int dev = 0;
-        if (ctx && ctx_device(ctx, &dev)) {
-            DeviceState &st = g_dev[dev & 63];
-            std::lock_guard<std::recursive_mutex> lk(st.call_mu);
-            if (st.last_stream == S(ctx)->stream) {
-                (void)hipStreamSynchronize(st.last_stream);
-                st.last_stream = nullptr;
-            }
-        }
-    }
+void gl_ctx_release(void *ctx) {
     if (!ctx) return;
+    int dev = 0;
+    if (!ctx_device(ctx, &dev)) (void)hipGetLastError();
+    (void)hipStreamSynchronize(S(ctx)->stream);
+    (void)hipStreamSynchronize(S(ctx)->stream2);
+    ctx_state_release(ctx);
+}
+
+void gl_ctx_destroy(void *ctx) {
+    if (!ctx) return;
+    gl_ctx_release(ctx);
     (void)hipStreamDestroy(S(ctx)->stream);
     (void)hipStreamDestroy(S(ctx)->stream2);
     free(ctx);
+}
+
+uint64_t gl_workspace_bytes(void) { return NTT_SCRATCH_ELEMS * sizeof(uint64_t); }
+
+GlError gl_ctx_set_workspace(void *ctx, void *d_workspace, uint64_t bytes) {
+    DeviceCall device_call(ctx);
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    if (d_workspace && (bytes < gl_workspace_bytes() || ((uintptr_t)d_workspace & 15)))
+        return fail(GL_E_INVALID, "a caller-provided workspace holds at least gl_workspace_bytes() bytes, 16-byte aligned");
+    CtxState *c;
+    HIP_TRY(ctx_state(ctx, &c));
+    HIP_TRY(hipStreamSynchronize(S(ctx)->stream));  // nothing of this context may still use the old one
+    if (c->hash_stream) HIP_TRY(hipStreamSynchronize(c->hash_stream));
+    if (c->scratch_owned && c->tb.scratch) HIP_TRY(hipFree(c->tb.scratch));
+    c->tb.scratch = nullptr;
+    c->scratch_owned = false;
+    if (d_workspace) {
+        c->tb.scratch = static_cast<uint64_t *>(d_workspace);
+        c->tb.scratch_elems = bytes / 8;
+    } else {
+        HIP_TRY(hipMalloc(&c->tb.scratch, NTT_SCRATCH_ELEMS * sizeof(uint64_t)));
+        c->tb.scratch_elems = NTT_SCRATCH_ELEMS;
+        c->scratch_owned = true;
+    }
+    return ok();
 }
 
 GlError gl_ctx_synchronize(void *ctx) {
@@ -709,7 +785,7 @@ GlError gl_ntt_batch(uint64_t *d_values, uint64_t poly_num, uint32_t log_n, uint
     if ((stride & 1) && log_n > 0 && poly_num > 1) return fail(GL_E_INVALID, "stride must be even (16-byte accesses)");
     if ((uintptr_t)d_values & 15) return fail(GL_E_INVALID, "d_values must be 16-byte aligned");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     HIP_TRY(ntt_batch(*tb, d_values, d_values, poly_num, log_n, stride, stride,
                       bit_reversed ? NttOrder::BitReversed : NttOrder::Natural, inverse != 0, S(ctx)->stream));
     return ok();
@@ -726,7 +802,7 @@ GlError gl_coset_lde_batch(const uint64_t *d_coeffs, uint64_t *d_out, uint64_t p
     if (log_n > 0 && ((src_stride | dst_stride) & 1)) return fail(GL_E_INVALID, "strides must be even");
     const NttTables *tb;
     CosetLease ct;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     HIP_TRY(get_coset_tables(log_n, rate_bits, shift, S(ctx)->stream, &ct));
     HIP_TRY(coset_lde_batch(*tb, *ct, d_coeffs, d_out, poly_num, src_stride, dst_stride, S(ctx)->stream));
     return ok();
@@ -764,7 +840,7 @@ GlError gl_permutation_partial_products(const uint64_t *d_wires, uint64_t wires_
         return fail(GL_E_INVALID, "quotient_degree_factor must be smaller than num_routed_wires (prover.rs:102-105)");
     if (log_n > 24) return fail(GL_E_INVALID, "log_n > 24");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     HIP_TRY(permutation_partial_products(*tb, d_wires, wires_stride, d_sigmas, sigmas_stride, d_k_is, h_betas, h_gammas,
                                          num_challenges, num_routed, quotient_degree_factor, log_n, d_out, S(ctx)->stream));
     return ok();
@@ -843,7 +919,7 @@ GlError gl_compute_quotient_polys(const GlQuotientArgs *args, uint64_t *d_quotie
     if (a.quotient_degree_factor < 2 || qdb > a.rate_bits)
         return fail(GL_E_INVALID, "constraints of degree higher than the rate are not supported (prover.rs:807-811)");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     hipError_t e = quotient_values(*tb, a, d_quotient_polys, S(ctx)->stream);
     if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "inconsistent GlQuotientArgs (leaf lengths / counts / sizes)");
     HIP_TRY(e);
@@ -860,7 +936,7 @@ GlError gl_eval_polys_ext2(const uint64_t *d_coeffs, uint64_t poly_num, uint32_t
     if (poly_num > 65535) return fail(GL_E_INVALID, "poly_num > 65535");
     if (stride < (1ull << log_n)) return fail(GL_E_INVALID, "stride smaller than the polynomial");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     hipError_t e = eval_polys_ext2(*tb, d_coeffs, poly_num, log_n, stride, h_points, num_points, d_out, S(ctx)->stream);
     if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "unsupported size for gl_eval_polys_ext2");
     HIP_TRY(e);
@@ -873,7 +949,7 @@ GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t nu
     if (!ctx || !d_poly_ptrs || !h_alpha || !d_out) return fail(GL_E_INVALID, "null pointer");
     if (num_polys == 0 || num_polys > (1u << 20) || n == 0) return fail(GL_E_INVALID, "bad sizes");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     HIP_TRY(fri_reduce_polys_base(*tb, d_poly_ptrs, num_polys, n, h_alpha, d_out, S(ctx)->stream));
     return ok();
 }
@@ -884,7 +960,7 @@ GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint6
     if (!ctx || !d_composition || !h_point || !h_scale || !d_final) return fail(GL_E_INVALID, "null pointer");
     if (n < 2 || n > (1ull << 30)) return fail(GL_E_INVALID, "bad length");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     hipError_t e = fri_divide_by_linear_accumulate(*tb, d_composition, n, h_point, h_scale, accumulate, d_final, S(ctx)->stream);
     if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "point has no inverse / workspace too small");
     HIP_TRY(e);
@@ -912,7 +988,7 @@ GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint
     if (!ctx || !h_state || !h_witness) return fail(GL_E_INVALID, "null pointer");
     if (witness_pos >= 8 || min_leading_zeros > 40) return fail(GL_E_INVALID, "bad witness position / difficulty");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     HIP_TRY(fri_proof_of_work(*tb, h_state, witness_pos, min_leading_zeros, h_witness, S(ctx)->stream));
     return ok();
 }
@@ -928,7 +1004,7 @@ GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n
     DeviceCall device_call(ctx);
     if (!ctx || !h_state || (!h_inputs && n_blocks)) return fail(GL_E_INVALID, "null pointer");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     if (12 + 8ull * n_blocks > tb->scratch_elems) return fail(GL_E_INVALID, "too many blocks");
     hipStream_t st = S(ctx)->stream;
     uint64_t *d_state = tb->scratch, *d_in = tb->scratch + 12;
@@ -956,7 +1032,7 @@ GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint
     const uint64_t layers = lg - cap_height, need = (uint64_t)count * (1 + leaf_len + 4 * layers);
     if (layers && !d_digests) return fail(GL_E_INVALID, "null pointer");
     const NttTables *tb;
-    HIP_TRY(get_tables(&tb));
+    HIP_TRY(get_tables(ctx, &tb));
     if (need > tb->scratch_elems) return fail(GL_E_INVALID, "too many openings for the workspace");
     hipStream_t st = S(ctx)->stream;
     uint64_t *d_idx = tb->scratch, *d_ol = d_idx + count, *d_os = d_ol + (uint64_t)count * leaf_len;
@@ -1096,8 +1172,9 @@ GlError gl_debug_field_op(int op, const uint64_t *d_a, const uint64_t *d_b, uint
 
 void init(void) {
     if (hipSetDevice(0) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_mu);
     const NttTables *tb;
-    (void)get_tables(&tb);
+    (void)device_tables(0, &tb);
 }
 
 GlError ifft(uint64_t *d_values_flatten, int poly_num, int values_num_per_poly, int log_len,
@@ -1183,15 +1260,14 @@ GlError build_merkle_tree(uint64_t *d_ext_values_flatten, int poly_num, int valu
 // Column-major staging for compute_quotient_polys: the reference's contract hands over LEAF-MAJOR rows, which the
 // quotient kernels read with the row length (1872 B for the wires) as the stride between the lanes of a wave;
 // transposing first (streaming, through LDS tiles) and reading column-major is 2x faster end to end. One buffer per
-// device, grown on demand, given back by gl_reference_quotient_release(). nullptr = could not allocate, or
-// PLONKY2_HIP_REFERENCE_IN_PLACE=1: read the rows in place.
-static uint64_t *get_ref_staging(uint64_t elems) {
+// device — the library's own, grown on demand and given back by gl_reference_quotient_release(), or the CALLER'S
+// (gl_reference_quotient_set_staging: a host that sizes all device memory up front, fri/oracle.rs:94-106, keeps doing so and
+// the library allocates nothing here). nullptr = could not allocate / the caller's buffer is too small, or
+// PLONKY2_HIP_REFERENCE_IN_PLACE=1: read the rows in place. Called with the device's ref_mu held.
+static uint64_t *get_ref_staging(DeviceState &st, uint64_t elems) {
     if (const char *v = getenv("PLONKY2_HIP_REFERENCE_IN_PLACE"))
         if (v[0] && v[0] != '0') return nullptr;  // the caller would rather not have the staging buffer
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_ref_mu);
-    DeviceState &st = g_dev[dev & 63];
+    if (st.ref_staging && !st.ref_staging_owned) return st.ref_staging_elems >= elems ? st.ref_staging : nullptr;
     if (st.ref_staging_elems < elems) {
         if (st.ref_staging) (void)hipFree(st.ref_staging);  // synchronises the device: nothing in flight reads it
         st.ref_staging = nullptr;
@@ -1202,18 +1278,39 @@ static uint64_t *get_ref_staging(uint64_t elems) {
             return nullptr;
         }
         st.ref_staging_elems = elems;
+        st.ref_staging_owned = true;
     }
     return st.ref_staging;
+}
+
+uint64_t gl_reference_quotient_staging_bytes(int log_len) {
+    if (log_len < 0 || log_len + (int)ED25519_RATE_BITS > 24) return 0;
+    const uint64_t n_ext = (1ull << log_len) << ED25519_RATE_BITS;
+    return 8ull * (ED25519_NUM_WIRES + ED25519_CONSTANTS_SIGMAS_LEAF_LEN + ED25519_ZS_PARTIAL_PRODUCTS_LEAF_LEN) * n_ext;
+}
+
+GlError gl_reference_quotient_set_staging(void *d_staging, uint64_t bytes) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (d_staging && ((uintptr_t)d_staging & 15)) return fail(GL_E_INVALID, "the staging buffer must be 16-byte aligned");
+    DeviceState &st = g_dev[dev & 63];
+    std::lock_guard<std::mutex> lk(st.ref_mu);  // no compute_quotient_polys is running on this device
+    if (st.ref_staging && st.ref_staging_owned) HIP_TRY(hipFree(st.ref_staging));
+    st.ref_staging = static_cast<uint64_t *>(d_staging);
+    st.ref_staging_elems = d_staging ? bytes / 8 : 0;
+    st.ref_staging_owned = false;
+    return ok();
 }
 
 GlError gl_reference_quotient_release(void) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_ref_mu);
     DeviceState &st = g_dev[dev & 63];
-    if (st.ref_staging) HIP_TRY(hipFree(st.ref_staging));
+    std::lock_guard<std::mutex> lk(st.ref_mu);
+    if (st.ref_staging && st.ref_staging_owned) HIP_TRY(hipFree(st.ref_staging));
     st.ref_staging = nullptr;
     st.ref_staging_elems = 0;
+    st.ref_staging_owned = false;
     return ok();
 }
 
@@ -1227,6 +1324,16 @@ GlError gl_reference_quotient_prepare(void *ctx) {
 GlError gl_reference_set_public_inputs_hash(const uint64_t *h_hash) {
     std::lock_guard<std::mutex> lk(g_ref_mu);
     for (int k = 0; k < 4; k++) g_ref_pih[k] = h_hash ? h_hash[k] : ED25519_REFERENCE_PUBLIC_INPUTS_HASH[k];
+    return ok();
+}
+
+GlError gl_reference_set_public_inputs_hash_ctx(const uint64_t *h_hash, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx) return fail(GL_E_INVALID, "null ctx");
+    CtxState *c;
+    HIP_TRY(ctx_state(ctx, &c));
+    c->have_pih = h_hash != nullptr;
+    for (int k = 0; k < 4; k++) c->pih[k] = h_hash ? h_hash[k] : 0;
     return ok();
 }
 
@@ -1265,11 +1372,21 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
     const GlDataSlice *src[3] = {alphas, betas, gammas};
     for (int i = 0; i < 3; i++) HIP_TRY(hipMemcpyAsync(ch[i], src[i]->ptr, sizeof(ch[i]), hipMemcpyDeviceToHost, S(ctx)->stream));
     HIP_TRY(hipStreamSynchronize(S(ctx)->stream));
+    // The circuit's public-inputs hash has no slot in the reference's signature (its kernel has the proof's value compiled in,
+    // plonky2_gpu_impl.cuh:600-685): the context's own (gl_reference_set_public_inputs_hash_ctx) if it has one, else the process's.
     uint64_t pih[4];
-    {
+    CtxState *cst;
+    HIP_TRY(ctx_state(ctx, &cst));
+    if (cst->have_pih) {
+        for (int k = 0; k < 4; k++) pih[k] = cst->pih[k];
+    } else {
         std::lock_guard<std::mutex> lk(g_ref_mu);
         for (int k = 0; k < 4; k++) pih[k] = g_ref_pih[k];
     }
+    // one gate-kernel object (its constant tables) and one staging buffer per device: calls of this symbol on one device take
+    // turns, held to the stream synchronisation that ends the call
+    DeviceState &dst = g_dev[cst->dev & 63];
+    std::lock_guard<std::mutex> ref_turn(dst.ref_mu);
     GlQuotientArgs a = {};
     a.d_wires_leaves = d_ext_values_flatten;  // leaf-major, leaf t = point bitrev(t) (plonky2_gpu_impl.cuh:537-541)
     a.d_constants_sigmas_leaves = static_cast<const uint64_t *>(cs->ptr);
@@ -1288,7 +1405,7 @@ GlError compute_quotient_polys(const uint64_t *d_ext_values_flatten, int poly_nu
     a.quotient_degree_factor = ED25519_QUOTIENT_DEGREE_FACTOR;
     a.coset_shift = 7;
     a.column_stride = 0;
-    if (uint64_t *stage = get_ref_staging((uint64_t)(a.wires_leaf_len + a.constants_sigmas_leaf_len + a.zs_partial_products_leaf_len) * n_ext)) {
+    if (uint64_t *stage = get_ref_staging(dst, (uint64_t)(a.wires_leaf_len + a.constants_sigmas_leaf_len + a.zs_partial_products_leaf_len) * n_ext)) {
         uint64_t *w = stage, *c = w + (uint64_t)a.wires_leaf_len * n_ext, *z = c + (uint64_t)a.constants_sigmas_leaf_len * n_ext;
         HIP_TRY(transpose_to_column_major(a.d_wires_leaves, w, a.wires_leaf_len, n_ext, n_ext, S(ctx)->stream));
         HIP_TRY(transpose_to_column_major(a.d_constants_sigmas_leaves, c, a.constants_sigmas_leaf_len, n_ext, n_ext, S(ctx)->stream));

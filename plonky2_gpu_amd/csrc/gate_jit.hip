@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 #include <vector>
@@ -95,6 +96,17 @@ struct GateKernel {
     bool fused = false;  // fused units read g_apow as pairs {alpha^k, alpha^k * 2^32}
     uint32_t wires_needed = 0, constants_needed = 0;  // 1 + the largest wire / constant column any gate loads
     std::string source;  // all units, for inspection
+    // A launch rewrites the units' __constant__ tables (alpha powers, biases, public-inputs hash, LDE pointers) in stream order in
+    // front of its kernels. Launches of ONE GateKernel from several streams / host threads (two proofs of one circuit in flight)
+    // therefore take turns: the next launch's stream waits for the previous launch's kernels before its copies may overwrite what
+    // they read. Launches of different GateKernels run concurrently. The host tables stay alive until the next launch has seen
+    // the previous one's event, so that no launch has to drain its stream for the copies' sake.
+    std::mutex launch_mu;
+    hipEvent_t done = nullptr;
+    bool launched = false;
+    std::vector<uint64_t> h_table;
+    std::vector<std::vector<uint64_t>> h_bias;
+    uint64_t h_pih[4], h_par[6];
 };
 
 // What every consumer of gate programs checks before running them (the compiled kernel when it is generated, the
@@ -1231,6 +1243,8 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
 
 void gate_kernel_destroy(GateKernel *k) {
     if (!k) return;
+    if (k->launched) (void)hipEventSynchronize(k->done);
+    if (k->done) (void)hipEventDestroy(k->done);
     for (GateUnit &u : k->units)
         if (u.module) (void)hipModuleUnload(u.module);
     delete k;
@@ -1242,9 +1256,22 @@ uint32_t gate_kernel_wires_needed(const GateKernel *k) { return k->wires_needed;
 uint32_t gate_kernel_constants_needed(const GateKernel *k) { return k->constants_needed; }
 const char *gate_kernel_source(const GateKernel *k) { return k->source.c_str(); }
 
-hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64_t w_rs, uint64_t w_es, const uint64_t *cs,
+hipError_t gate_kernel_launch(const GateKernel *kc, const uint64_t *wires, uint64_t w_rs, uint64_t w_es, const uint64_t *cs,
                               uint64_t c_rs, uint64_t c_es, const uint64_t *alphas, const uint64_t pih[4], uint64_t lde_size,
                               uint64_t *out, hipStream_t stream) {
+    GateKernel *k = const_cast<GateKernel *>(kc);  // the launch state is the object's own (see GateKernel)
+    std::lock_guard<std::mutex> turn(k->launch_mu);
+    hipError_t e = hipSuccess;
+    if (!k->done) {
+        e = hipEventCreateWithFlags(&k->done, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    if (k->launched) {
+        // the previous launch (normally the previous proof's, long finished): its copies have left the host tables and its kernels
+        // have read the constant tables once this event has fired; other streams wait for it on the device, the host only here
+        e = hipEventSynchronize(k->done);
+        if (e != hipSuccess) return e;
+    }
     std::vector<uint64_t> apow((size_t)k->num_challenges * k->num_constraints);
     for (uint32_t c = 0; c < k->num_challenges; c++) {
         uint64_t a = alphas[c] % glh::P, p = 1;
@@ -1253,14 +1280,17 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
             p = glh::mul(p, a);
         }
     }
-    std::vector<uint64_t> table = apow;  // what the units' g_apow holds
+    std::vector<uint64_t> &table = k->h_table;  // what the units' g_apow holds
+    table = apow;
     if (k->fused) {
         table.resize(apow.size() * 2);
         for (size_t i = 0; i < apow.size(); i++) table[2 * i] = apow[i], table[2 * i + 1] = glh::mul(apow[i], 1ull << 32);
     }
-    const uint64_t pi[4] = {pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
+    for (int i = 0; i < 4; i++) k->h_pih[i] = pih[i] % glh::P;
     const uint64_t par[6] = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es};
-    std::vector<std::vector<uint64_t>> unit_bias(k->units.size());
+    for (int i = 0; i < 6; i++) k->h_par[i] = par[i];
+    std::vector<std::vector<uint64_t>> &unit_bias = k->h_bias;
+    unit_bias.assign(k->units.size(), {});
     for (size_t ui = 0; ui < k->units.size(); ui++) {
         const GateUnit &u = k->units[ui];
         if (!u.d_bias) continue;
@@ -1274,20 +1304,17 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
     }
     for (size_t ui = 0; ui < k->units.size(); ui++) {
         const GateUnit &u = k->units[ui];
-        // pageable source: the copy has left the host buffer when hipMemcpyAsync returns
-        hipError_t e = hipMemcpyAsync(u.d_apow, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+        e = hipMemcpyAsync(u.d_apow, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
         if (u.d_bias) {
             e = hipMemcpyAsync(u.d_bias, unit_bias[ui].data(), unit_bias[ui].size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) return e;
         }
-        e = hipMemcpyAsync(u.d_pih, pi, sizeof pi, hipMemcpyHostToDevice, stream);
+        e = hipMemcpyAsync(u.d_pih, k->h_pih, sizeof k->h_pih, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
-        e = hipMemcpyAsync(u.d_par, par, sizeof par, hipMemcpyHostToDevice, stream);
+        e = hipMemcpyAsync(u.d_par, k->h_par, sizeof k->h_par, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
     }
-    hipError_t e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)((lde_size + 127) / 128);
     int accumulate = 0;
     for (const GateUnit &u : k->units) {
@@ -1296,6 +1323,9 @@ hipError_t gate_kernel_launch(const GateKernel *k, const uint64_t *wires, uint64
         if (e != hipSuccess) return e;
         accumulate = 1;
     }
+    e = hipEventRecord(k->done, stream);
+    if (e != hipSuccess) return e;
+    k->launched = true;
     return hipSuccess;
 }
 

@@ -13,8 +13,9 @@ struct NttTables {
     uint64_t *twl = nullptr;
     uint64_t *twh = nullptr;
     // Workspace for natural-order multi-pass transforms (the last pass writes transposed, so the
-    // intermediate cannot live in the caller's buffer). 128 MiB = 16 columns of 2^20: small enough
-    // to stay in the 256 MiB Infinity Cache between the two passes of a chunk.
+    // intermediate cannot live in the caller's buffer), 512 MiB = 64 columns of 2^20: one launch pair
+    // per batch. One per CONTEXT (capi.hip CtxState holds a copy of the device's tables with its own
+    // scratch), so that two contexts on one device never meet in it.
     uint64_t *scratch = nullptr;
     uint64_t scratch_elems = 0;
 };

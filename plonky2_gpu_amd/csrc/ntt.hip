@@ -1132,9 +1132,8 @@ hipError_t ntt_tables_create(NttTables *tb) {
     tb->twh = tb->twl + 4096;
     e = hipMemcpy(tb->twl, h, 2 * 4096 * sizeof(uint64_t), hipMemcpyHostToDevice);
     free(h);
-    if (e != hipSuccess) return e;
-    tb->scratch_elems = NTT_SCRATCH_ELEMS;
-    return hipMalloc(&tb->scratch, tb->scratch_elems * sizeof(uint64_t));
+    // the workspace (`scratch`) belongs to a context, not to the device: capi.hip CtxState
+    return e;
 }
 
 void ntt_tables_destroy(NttTables *tb) {

@@ -52,7 +52,9 @@ E2 e2_pow(E2 x, uint64_t e) {
 // Device buffers of one circuit's proofs are recycled: every proof of a circuit allocates the same ~50
 // sizes, hipMalloc/hipFree of multi-GiB buffers cost milliseconds and hipFree synchronises the device.
 // Handing a buffer back while kernels that use it are still in flight is safe here because everything
-// gl_prove launches is ordered on ONE stream: the next user's kernels queue behind them.
+// gl_prove launches is ordered on ONE stream: the next user's kernels queue behind them. That argument
+// holds per CONTEXT, so a circuit keeps one pool per context that proves with it (two proofs of one
+// circuit in flight on two contexts never hand each other a buffer whose kernels are still queued).
 struct Pool {
     std::mutex m;
     std::multimap<uint64_t, uint64_t *> free_;  // bytes -> buffer
@@ -200,7 +202,12 @@ struct Circuit {
     DevBuf d_instrs, d_gates, d_imms;
     uint32_t num_gates = 0, num_selectors = 0;
     void *gate_kernel = nullptr;
-    mutable Pool pool;  // the working buffers of this circuit's proofs, recycled from proof to proof
+    mutable std::mutex pools_m;
+    mutable std::map<void *, Pool> pools;  // context -> the working buffers of this circuit's proofs there, recycled from proof to proof
+    Pool *pool_of(void *ctx) const {
+        std::lock_guard<std::mutex> lock(pools_m);
+        return &pools[ctx];  // std::map: the address is stable
+    }
     ~Circuit() {
         if (gate_kernel) gl_gate_kernel_destroy(gate_kernel);
     }
@@ -368,10 +375,14 @@ void gl_circuit_destroy(void *circuit) { delete static_cast<Circuit *>(circuit);
 
 GlError gl_circuit_trim(void *circuit) {
     if (!circuit) return fail("null pointer");
-    Pool &pool = static_cast<Circuit *>(circuit)->pool;
-    std::lock_guard<std::mutex> lock(pool.m);
-    for (auto &kv : pool.free_) TRY(gl_free(kv.second));
-    pool.free_.clear();
+    Circuit *c = static_cast<Circuit *>(circuit);
+    std::lock_guard<std::mutex> all(c->pools_m);
+    for (auto &cp : c->pools) {
+        Pool &pool = cp.second;
+        std::lock_guard<std::mutex> lock(pool.m);
+        for (auto &kv : pool.free_) TRY(gl_free(kv.second));
+        pool.free_.clear();
+    }
     return ok();
 }
 
@@ -391,7 +402,7 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
     const Circuit &c = *static_cast<const Circuit *>(circuit);
     if (c.hiding && !d_salts) return fail("the circuit's FRI parameters are hiding (zero_knowledge): prove it with gl_prove_zk and salt columns");
     if (!c.hiding && d_salts) return fail("gl_prove_zk on a circuit whose FRI parameters are not hiding");
-    PoolScope pool_scope(&c.pool);  // every DevBuf below comes from / returns to the circuit's pool
+    PoolScope pool_scope(c.pool_of(ctx));  // every DevBuf below comes from / returns to the circuit's pool
     const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf;
     const uint64_t n = 1ull << db, n_ext = n << c.rate_bits;
     const uint32_t npp = num_partial_products(c.num_routed, qdf);

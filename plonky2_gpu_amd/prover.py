@@ -315,19 +315,22 @@ class NativeCircuit:
         self.circuit_digest = [int(x) for x in dg]
         self.constants_sigmas_cap = cap.reshape(-1, 4).tolist()
 
-    def prove_bytes(self, wires, public_inputs, timing=None, salts=None):
+    def prove_bytes(self, wires, public_inputs, timing=None, salts=None, ctx=None):
         """gl_prove: the proof in the reference's wire format. `wires`: host [num_wires][n] or a DeviceBuffer.
+        `ctx`: prove on another context than the one the circuit was created with (same device) — several host threads, each
+        with its own context, may prove with one circuit handle at the same time (the handle keeps a buffer pool per context).
         `salts` (a circuit with fri_params["hiding"], i.e. zero_knowledge): [3][4][n_ext] uniform field elements, host or DeviceBuffer —
         the blinding of the wires, Zs / partial products and quotient commitments in leaf order (gl_prove_zk)."""
-        d_w = wires if isinstance(wires, DeviceBuffer) else DeviceBuffer.from_host(self.ctx, _host_u64(wires))
+        ctx = ctx or self.ctx
+        d_w = wires if isinstance(wires, DeviceBuffer) else DeviceBuffer.from_host(ctx, _host_u64(wires))
         pis = _host_u64(public_inputs)
         out, ln = ctypes.c_void_p(), ctypes.c_uint64()
         ms = np.zeros(_lib.GL_PROVE_STAGES, dtype=np.float64) if timing is not None else None
         if salts is not None:
-            d_s = salts if isinstance(salts, DeviceBuffer) else DeviceBuffer.from_host(self.ctx, _host_u64(salts))
-            _lib.call("gl_prove_zk", self.ptr, d_w.ptr, pis, pis.size, d_s.ptr, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
+            d_s = salts if isinstance(salts, DeviceBuffer) else DeviceBuffer.from_host(ctx, _host_u64(salts))
+            _lib.call("gl_prove_zk", self.ptr, d_w.ptr, pis, pis.size, d_s.ptr, ctypes.byref(out), ctypes.byref(ln), ms, ctx.ptr)
         else:
-            _lib.call("gl_prove", self.ptr, d_w.ptr, pis, pis.size, ctypes.byref(out), ctypes.byref(ln), ms, self.ctx.ptr)
+            _lib.call("gl_prove", self.ptr, d_w.ptr, pis, pis.size, ctypes.byref(out), ctypes.byref(ln), ms, ctx.ptr)
         data = ctypes.string_at(out.value, ln.value)
         _lib.load().gl_bytes_free(out.value)
         if timing is not None:

@@ -22,7 +22,7 @@ def lib():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "plonky2_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:GlError|void|int|const char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:GlError|void|int|uint64_t|const char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 

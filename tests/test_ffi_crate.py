@@ -24,7 +24,7 @@ def _extern_fns(path):
 def _header_fns():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "plonky2_hip.h")).read(), flags=re.S)
     out = {}
-    for m in re.finditer(r"^\s*(?:GlError|void|int|const char)\s*\*?\s*(\w+)\s*\(([^;]*)\);", text, flags=re.M):
+    for m in re.finditer(r"^\s*(?:GlError|void|int|uint64_t|const char)\s*\*?\s*(\w+)\s*\(([^;]*)\);", text, flags=re.M):
         args = " ".join(m.group(2).split())
         out[m.group(1)] = 0 if args == "void" else len(args.split(","))
     return out
