@@ -42,6 +42,9 @@ using poseidon_vector::W;
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef int v16i32 __attribute__((ext_vector_type(16)));
 
+#ifdef POSEIDON_MDS_NATURAL
+#include POSEIDON_MDS_NATURAL  // tools/experiments/mds_natural.h: the A/B build of round 6 (state fed as it lies, 18 matrix instructions per layer)
+#else
 struct MdsOperands {
     v4i32 A;   // this lane's row of the A operand: a row of the MDS matrix in its own half's sixteen k, or zero
     v16i32 C;  // 128 * (row sum) in every element
@@ -129,6 +132,8 @@ __device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const MdsOperands &o
 #pragma unroll
     for (int r = 0; r < W; r++) s[r] = gl::fold96(al[r], ah[r]);  // al + ah 2^32 mod p; al < 2^41 + X 2^32, ah < 2^41 + Y 2^32: X, Y leave the room
 }
+
+#endif  // POSEIDON_MDS_NATURAL
 
 // s-box layer + MDS layer; the round's own constants were added by the previous layer
 __device__ __forceinline__ void full_round(uint64_t (&s)[W], const MdsOperands &ops, const uint32_t *__restrict__ xy) {
