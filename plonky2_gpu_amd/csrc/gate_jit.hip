@@ -118,6 +118,10 @@ bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const u
                             uint32_t num_selectors, uint32_t ngc, uint32_t *wires_needed, uint32_t *constants_needed,
                             std::string *error) {
     uint32_t wn = 0, cn = num_selectors;
+    if (num_gates == 0) {
+        *error = "a gate table holds at least one gate";
+        return false;
+    }
     for (uint32_t g = 0; g < num_gates; g++) {
         const uint32_t *d = gates + 6 * g;
         const uint32_t si = d[1], gs = d[2], ge = d[3], ps = d[4], pl = d[5];
@@ -126,8 +130,18 @@ bool gate_programs_validate(const uint16_t *instrs, uint32_t num_instrs, const u
             return false;
         }
         uint32_t emitted = 0;
+        // One rule for the interpreter, the per-gate generator and the fused generator: a register is written before it is read, in
+        // program order (a program that leans on registers starting at zero would build under one generator setting and not the other).
+        bool written[MAX_REGS] = {};
         for (uint32_t pc = ps; pc < ps + pl; pc++) {
-            const uint16_t op = instrs[4 * pc], a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
+            const uint16_t op = instrs[4 * pc], dst = instrs[4 * pc + 1], a = instrs[4 * pc + 2], b = instrs[4 * pc + 3];
+            const bool reads_a = op == GP_ADD || op == GP_SUB || op == GP_MUL || op == GP_EMIT || op == GP_MULK || op == GP_ACC;
+            const bool reads_b = op == GP_ADD || op == GP_SUB || op == GP_MUL;
+            if ((reads_a && !written[a & (MAX_REGS - 1)]) || (reads_b && !written[b & (MAX_REGS - 1)])) {
+                *error = "gate " + std::to_string(g) + ": register read before any write (instruction " + std::to_string(pc - ps) + ")";
+                return false;
+            }
+            if (op != GP_EMIT && op != GP_ACC && op <= GP_ACCR) written[dst & (MAX_REGS - 1)] = true;  // ACC's dst names an accumulator
             if (op == GP_LOAD_WIRE && (uint32_t)a + 1 > wn) wn = (uint32_t)a + 1;
             if (op == GP_LOAD_CONST && num_selectors + a + 1 > cn) cn = num_selectors + a + 1;
             if (op == GP_LOAD_IMM && a >= num_imms) {
@@ -1111,6 +1125,14 @@ GateKernel *gate_kernel_build(const uint16_t *instrs, uint32_t num_instrs, const
         k->source += u.source;
         cache_paths.push_back(unit_cache_path(dir, u.source));
     }
+    // $PLONKY2_HIP_KERNEL_CACHE_LIST=<file>: the cache entries this build uses, one path per line (appended) — how build() tells the
+    // current generator's units from whatever else the cache directory holds without compiling anything twice (__graft_entry__.py)
+    if (const char *lf = getenv("PLONKY2_HIP_KERNEL_CACHE_LIST"))
+        if (FILE *f = fopen(lf, "a")) {
+            for (const std::string &cp : cache_paths)
+                if (!cp.empty()) fprintf(f, "%s\n", cp.c_str());
+            fclose(f);
+        }
     auto from_cache = [&](size_t i) {
         if (cache_paths[i].empty()) return false;
         std::ifstream f(cache_paths[i] + ".hsaco", std::ios::binary);

@@ -120,24 +120,41 @@ def test_a_program_that_cannot_be_generated_is_reported(tmp_path):
     assert objects(tmp_path) == []
 
 
-def test_build_leaves_exactly_the_current_units_in_the_kernel_cache():
+def test_build_leaves_exactly_the_current_units_in_the_kernel_cache(tmp_path):
     """__graft_entry__.precompile_gate_kernels() (part of build()): whatever the cache held — units of an earlier generator, a unit
-    missing — afterwards it holds the units of the current generator for the compiled-in ed25519 table, all of them and nothing else.
-    (Until round 5 it deleted every file that had been there before whenever ONE unit was new, the unchanged units included.)"""
-    sys.path.insert(0, ROOT)
-    import __graft_entry__ as g
+    missing — afterwards it holds the units of the current generator for the compiled-in ed25519 table, all of them and nothing else,
+    and a unit that is already there is not compiled again. Run in a FRESH process on a COPY of the shipped cache: the function forks
+    hiprtc workers, which a process that has initialised HIP (this pytest process, on a GPU box) must not do, and the shipped cache
+    is a build product that a test has no business rewriting."""
+    import shutil
+    import subprocess
 
-    cache = os.path.join(ROOT, "plonky2_gpu_amd", "kernel_cache")
-    g.precompile_gate_kernels()
+    shipped = os.path.join(ROOT, "plonky2_gpu_amd", "kernel_cache")
+    cache = str(tmp_path / "kernel_cache")
+    if os.path.isdir(shipped):
+        shutil.copytree(shipped, cache)
+
+    def precompile():
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PLONKY2_HIP_")}
+        r = subprocess.run([sys.executable, "-c", "import sys, os, __graft_entry__ as g; g.precompile_gate_kernels(cache=sys.argv[1]); "
+                            "assert 'PLONKY2_HIP_JIT_FORK' not in os.environ and 'PLONKY2_HIP_KERNEL_CACHE' not in os.environ", cache],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    precompile()
     good = set(os.listdir(cache))
     assert good and len([f for f in good if f.endswith(".hsaco")]) * 2 == len(good), good  # a .hip beside every .hsaco
+    stamp = {f: os.stat(os.path.join(cache, f)).st_mtime_ns for f in good}
     victim = sorted(f for f in good if f.endswith(".hsaco"))[0]
     os.remove(os.path.join(cache, victim))
     os.remove(os.path.join(cache, victim[:-6] + ".hip"))
     for stale in ("gate_0000000000000000.hsaco", "gate_0000000000000000.hip"):
         with open(os.path.join(cache, stale), "wb") as f:
             f.write(b"stale")
-    g.precompile_gate_kernels()
-    assert set(os.listdir(cache)) == good
-    g.precompile_gate_kernels()  # and a third call changes nothing
+    out = precompile()
+    assert set(os.listdir(cache)) == good and victim in out, out
+    for f in good - {victim, victim[:-6] + ".hip"}:  # the units that were there were used as they were
+        assert os.stat(os.path.join(cache, f)).st_mtime_ns == stamp[f], f
+    assert "already compiled" in precompile()  # and a third call changes nothing
     assert set(os.listdir(cache)) == good
