@@ -317,8 +317,15 @@ GlError gl_fri_reduce_polys_base(const uint64_t *const *d_poly_ptrs, uint32_t nu
 GlError gl_fri_divide_by_linear(uint64_t *d_composition, uint64_t n, const uint64_t *h_point, const uint64_t *h_scale, int accumulate,
                                 uint64_t *d_final, void *ctx);
 GlError gl_fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *h_beta, uint64_t *d_out, void *ctx);
+/* The same with beta read from device memory (two canonical words, e.g. where gl_challenger_step wrote them): the FRI commit phase
+ * (fri/prover.rs:77-120) runs without a host synchronisation per layer. */
+GlError gl_fri_fold_device(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *d_beta, uint64_t *d_out, void *ctx);
 GlError gl_ext2_interleave(const uint64_t *d_planes, uint64_t len, uint64_t *d_rows, void *ctx);
 GlError gl_fri_proof_of_work(const uint64_t *h_state, uint32_t witness_pos, uint32_t min_leading_zeros, uint64_t *h_witness, void *ctx);
+/* The same against a device-resident Challenger: the duplex state is the challenger's (its input buffer written over the state's
+ * first words, the candidate behind it, fri/prover.rs:137-147); the witness lands in *d_witness (from where gl_challenger_step can
+ * observe it) and in *h_witness. Synchronous like gl_fri_proof_of_work. */
+GlError gl_fri_proof_of_work_device(const uint64_t *d_challenger, uint32_t min_leading_zeros, uint64_t *d_witness, uint64_t *h_witness, void *ctx);
 
 /* count Poseidon permutations in place, states[count][12] (plonky2/src/hash/poseidon.rs:602-616). */
 GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx);
@@ -328,6 +335,26 @@ GlError gl_poseidon_permute_batch(uint64_t *d_states, uint64_t count, void *ctx)
  * repeated, and hash_n_to_hash_no_pad (hash/hashing.rs:81-108) for whole blocks. SYNCHRONOUS. */
 GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n_blocks, void *ctx);
 
+/* The Challenger with its state in DEVICE memory (plonky2/src/iop/challenger.rs:19-149): d_challenger = 32 u64 the caller owns
+ * (sponge state, input buffer, the two buffer lengths). One call = one launch, asynchronous on ctx->stream, no host round trip:
+ * observe_elements over up to eight device sources in order — read where the producing kernels left them: a cap straight from
+ * gl_commit_* / gl_merkle_tree_*, openings from gl_eval_polys_ext2, a planar extension vector (planar_len != 0: element i is
+ * d_ptr[(i & 1) * planar_len + (i >> 1)], i.e. observe_extension_elements) — then get_n_challenges(n_challenges) into d_out
+ * (canonical). GL_CHALLENGER_RESET starts from the empty transcript (Challenger::new) before observing. GL_CHALLENGER_HASH:
+ * instead of challenges, d_out[0..4) = hash_n_to_hash_no_pad of everything observed since the reset (hash/hashing.rs:81-108; use it
+ * with GL_CHALLENGER_RESET on a scratch challenger). Values a host holds (circuit digest, public inputs) are observed from a device
+ * copy. The host fetches the challenges it needs itself with one gl_memcpy_d2h per step; kernels that can read a challenge from
+ * device memory need no fetch at all (gl_fri_fold_device, gl_merkle_open_batch_device, gl_fri_proof_of_work_device). */
+typedef struct GlObserveSrc {
+    const uint64_t *d_ptr;
+    uint64_t count;      /* field elements observed from this source */
+    uint64_t planar_len; /* 0: d_ptr[i]; else the plane length of an extension vector kept as [2][planar_len] */
+} GlObserveSrc;
+#define GL_CHALLENGER_RESET 1u
+#define GL_CHALLENGER_HASH 2u
+GlError gl_challenger_step(uint64_t *d_challenger, const GlObserveSrc *h_srcs, uint32_t n_srcs, uint32_t n_challenges, uint64_t *d_out,
+                           uint32_t flags, void *ctx);
+
 /* MerkleTree::prove (plonky2/src/hash/merkle_tree.rs:392-440) and the leaf itself for `count` leaf
  * indices in one launch and one copy — what fri_prover_query_round (fri/prover.rs:199-260) does per
  * query and tree. Element j of leaf i is read at d_leaves[i*row_stride + j*elem_stride] (leaf-major rows:
@@ -336,6 +363,12 @@ GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n
 GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
                              uint32_t cap_height, const uint64_t *d_digests, const uint64_t *h_indices, uint32_t count,
                              uint64_t *h_out_leaves, uint64_t *h_out_siblings, void *ctx);
+/* The same with everything in device memory and nothing synchronised: leaf of query q = (d_indices[q] mod (n_leaves << index_shift))
+ * >> index_shift — d_indices may be raw challenges (fri/prover.rs:186-190: x_index = challenge mod lde size) and index_shift the
+ * sum of the FRI arities before this layer's tree (:213-236). Outputs [count][leaf_len] and [count][layers][4] in device memory. */
+GlError gl_merkle_open_batch_device(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                                    uint32_t cap_height, const uint64_t *d_digests, const uint64_t *d_indices, uint32_t count,
+                                    uint32_t index_shift, uint64_t *d_out_leaves, uint64_t *d_out_siblings, void *ctx);
 
 /* MerkleTree::new (plonky2/src/hash/merkle_tree.rs:283-319) over n_leaves (power of two) leaves of
  * leaf_len elements; leaf hash = hash_or_noop (plonk/config.rs:56-67).

@@ -18,6 +18,10 @@ class GlDataSlice(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("len", ctypes.c_int)]
 
 
+class GlObserveSrc(ctypes.Structure):
+    _fields_ = [("d_ptr", ctypes.c_void_p), ("count", ctypes.c_uint64), ("planar_len", ctypes.c_uint64)]
+
+
 class GlGateProgram(ctypes.Structure):
     _fields_ = [
         ("d_instrs", ctypes.c_void_p),
@@ -179,6 +183,10 @@ SIGNATURES = {
     "gl_fri_proof_of_work": (GlError, [_vp, _u32, _u32, _vp, _vp]),
     "gl_poseidon_permute_batch": (GlError, [_vp, _u64, _vp]),
     "gl_sponge_absorb": (GlError, [_vp, _vp, _u32, _vp]),
+    "gl_challenger_step": (GlError, [_vp, _vp, _u32, _u32, _vp, _u32, _vp]),
+    "gl_fri_fold_device": (GlError, [_vp, _u64, _u32, _vp, _vp, _vp]),
+    "gl_fri_proof_of_work_device": (GlError, [_vp, _u32, _vp, _vp, _vp]),
+    "gl_merkle_open_batch_device": (GlError, [_vp, _u64, _u64, _u32, _u64, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "gl_merkle_open_batch": (GlError, [_vp, _u64, _u64, _u32, _u64, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_columns": (GlError, [_vp, _u32, _u64, _u64, _u32, _vp, _vp, _vp]),
     "gl_merkle_tree_from_leaves": (GlError, [_vp, _u32, _u64, _u32, _vp, _vp, _vp]),

@@ -1016,6 +1016,60 @@ GlError gl_sponge_absorb(uint64_t *h_state, const uint64_t *h_inputs, uint32_t n
     return ok();
 }
 
+GlError gl_challenger_step(uint64_t *d_challenger, const GlObserveSrc *h_srcs, uint32_t n_srcs, uint32_t n_challenges, uint64_t *d_out,
+                           uint32_t flags, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx || !d_challenger || (n_srcs && !h_srcs)) return fail(GL_E_INVALID, "null pointer");
+    if (n_srcs > 8) return fail(GL_E_INVALID, "at most eight sources per step");
+    if (flags & ~(uint32_t)(GL_CHALLENGER_RESET | GL_CHALLENGER_HASH)) return fail(GL_E_INVALID, "unknown flag");
+    if (((flags & GL_CHALLENGER_HASH) || n_challenges) && !d_out) return fail(GL_E_INVALID, "null output");
+    const uint64_t *ptrs[8];
+    uint64_t counts[8], planar[8];
+    for (uint32_t i = 0; i < n_srcs; i++) {
+        if (h_srcs[i].count && !h_srcs[i].d_ptr) return fail(GL_E_INVALID, "null source");
+        if (h_srcs[i].planar_len && h_srcs[i].count > 2 * h_srcs[i].planar_len) return fail(GL_E_INVALID, "a planar source holds 2 * planar_len elements");
+        ptrs[i] = h_srcs[i].d_ptr, counts[i] = h_srcs[i].count, planar[i] = h_srcs[i].planar_len;
+    }
+    HIP_TRY(challenger_step(d_challenger, ptrs, counts, planar, n_srcs, n_challenges, flags, d_out, S(ctx)->stream));
+    return ok();
+}
+
+GlError gl_fri_fold_device(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t *d_beta, uint64_t *d_out, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx || !d_coeffs || !d_beta || !d_out) return fail(GL_E_INVALID, "null pointer");
+    const uint64_t zero[2] = {0, 0};
+    hipError_t e = fri_fold(d_coeffs, len, arity_bits, zero, d_out, S(ctx)->stream, d_beta);
+    if (e == hipErrorInvalidValue) return fail(GL_E_INVALID, "bad arity / length");
+    HIP_TRY(e);
+    return ok();
+}
+
+GlError gl_fri_proof_of_work_device(const uint64_t *d_challenger, uint32_t min_leading_zeros, uint64_t *d_witness, uint64_t *h_witness, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx || !d_challenger || !d_witness || !h_witness) return fail(GL_E_INVALID, "null pointer");
+    if (min_leading_zeros > 40) return fail(GL_E_INVALID, "bad difficulty");
+    const NttTables *tb;
+    HIP_TRY(get_tables(ctx, &tb));
+    const uint64_t unused[12] = {0};
+    HIP_TRY(fri_proof_of_work(*tb, unused, 0, min_leading_zeros, h_witness, S(ctx)->stream, d_challenger, d_witness));
+    return ok();
+}
+
+GlError gl_merkle_open_batch_device(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
+                                    uint32_t cap_height, const uint64_t *d_digests, const uint64_t *d_indices, uint32_t count,
+                                    uint32_t index_shift, uint64_t *d_out_leaves, uint64_t *d_out_siblings, void *ctx) {
+    DeviceCall device_call(ctx);
+    if (!ctx || !d_leaves || !d_indices || !d_out_leaves || (!d_out_siblings && (n_leaves >> cap_height) > 1)) return fail(GL_E_INVALID, "null pointer");
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || cap_height > 63 || (1ull << cap_height) > n_leaves || index_shift > 32 ||
+        (n_leaves << index_shift) >> index_shift != n_leaves)
+        return fail(GL_E_INVALID, "bad tree shape");
+    if (count == 0) return ok();
+    if ((n_leaves >> cap_height) > 1 && !d_digests) return fail(GL_E_INVALID, "null pointer");
+    HIP_TRY(merkle_open_batch(d_leaves, row_stride, elem_stride, leaf_len, n_leaves, cap_height, d_digests, d_indices, count, d_out_leaves,
+                              d_out_siblings, S(ctx)->stream, (n_leaves << index_shift) - 1, index_shift));
+    return ok();
+}
+
 GlError gl_merkle_open_batch(const uint64_t *d_leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
                              uint32_t cap_height, const uint64_t *d_digests, const uint64_t *h_indices, uint32_t count,
                              uint64_t *h_out_leaves, uint64_t *h_out_siblings, void *ctx) {

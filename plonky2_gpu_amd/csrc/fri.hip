@@ -183,10 +183,13 @@ __global__ __launch_bounds__(256) void divide_finish_kernel(const uint64_t *suf,
 }
 
 // out[k] = sum_{i < arity} c[k*arity + i] * beta^i   (reduce_with_powers, plonk_common.rs:116-128)
-__global__ __launch_bounds__(256) void fold_kernel(const uint64_t *c, uint64_t len, uint32_t arity_bits, Ext2 beta, uint64_t *out) {
+// d_beta != null: beta is read where the device-resident transcript left it (two canonical words)
+__global__ __launch_bounds__(256) void fold_kernel(const uint64_t *c, uint64_t len, uint32_t arity_bits, Ext2 beta, uint64_t *out,
+                                                   const uint64_t *__restrict__ d_beta) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t out_len = len >> arity_bits;
     if (k >= out_len) return;
+    if (d_beta) beta = Ext2{d_beta[0], d_beta[1]};
     Ext2 s{0, 0};
     for (int64_t i = (1ll << arity_bits) - 1; i >= 0; i--) {
         uint64_t idx = (k << arity_bits) + i;
@@ -209,16 +212,24 @@ struct PowState {
 };
 
 // candidates base .. base + count: smallest one whose response has enough leading zeros (atomicMin)
+// T != null: the transcript lives on the device (merkle.hip challenger_step_kernel): state T[0..12) with the input buffer T[12..) of
+// length T[28] written over its first words, the candidate behind it (fri/prover.rs:137-147)
 __global__ __launch_bounds__(256) void pow_kernel(PowState st, uint32_t pos, uint32_t min_leading_zeros, uint64_t base, uint64_t count,
-                                                  unsigned long long *best) {
+                                                  unsigned long long *best, const uint64_t *__restrict__ T) {
     const poseidon::MdsOperands ops = poseidon::mds_operands();
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g < count;  // whole waves to the end (poseidon.h): lanes past the end try the last candidate once more
     if (!live) g = count - 1;
     uint64_t cand = base + g;
     uint64_t s[12];
+    if (T) {
+        pos = (uint32_t)T[28];
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = st.s[k];
+        for (int k = 0; k < 12; k++) s[k] = gl::canon(((uint32_t)k < pos && k < 8) ? T[12 + k] : T[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; k++) s[k] = st.s[k];
+    }
 #pragma unroll
     for (int k = 0; k < 12; k++)
         if ((uint32_t)k == pos) s[k] = cand;
@@ -265,10 +276,10 @@ hipError_t fri_divide_by_linear_accumulate(const NttTables &tb, uint64_t *d_comp
 }
 
 hipError_t fri_fold(const uint64_t *d_coeffs, uint64_t len, uint32_t arity_bits, const uint64_t beta[2], uint64_t *d_out,
-                    hipStream_t stream) {
+                    hipStream_t stream, const uint64_t *d_beta) {
     if (arity_bits == 0 || arity_bits > 8 || (len >> arity_bits) == 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_kernel, dim3(grid_for(len >> arity_bits, 256)), dim3(256), 0, stream, d_coeffs, len, arity_bits,
-                       Ext2{beta[0] % glh::P, beta[1] % glh::P}, d_out);
+                       d_beta ? Ext2{0, 0} : Ext2{beta[0] % glh::P, beta[1] % glh::P}, d_out, d_beta);
     return hipGetLastError();
 }
 
@@ -279,11 +290,12 @@ hipError_t fri_interleave(const uint64_t *d_planes, uint64_t len, uint64_t *d_ro
 }
 
 hipError_t fri_proof_of_work(const NttTables &tb, const uint64_t state[12], uint32_t pos, uint32_t min_leading_zeros, uint64_t *witness,
-                             hipStream_t stream) {
+                             hipStream_t stream, const uint64_t *d_challenger, uint64_t *d_witness) {
     if (pos >= 12 || !tb.scratch) return hipErrorInvalidValue;
-    PowState st;
-    for (int k = 0; k < 12; k++) st.s[k] = state[k] % glh::P;
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(tb.scratch);
+    PowState st = {};
+    if (!d_challenger)
+        for (int k = 0; k < 12; k++) st.s[k] = state[k] % glh::P;
+    unsigned long long *best = d_witness ? reinterpret_cast<unsigned long long *>(d_witness) : reinterpret_cast<unsigned long long *>(tb.scratch);
     // Batches are scanned in order, so the first batch that holds a witness holds the smallest one. The
     // expected search length is 2^min_leading_zeros' (16 proof-of-work bits -> 2^16 candidates): the batch
     // starts at 2^17 (one launch ~ one permutation latency) and doubles while nothing is found.
@@ -293,7 +305,7 @@ hipError_t fri_proof_of_work(const NttTables &tb, const uint64_t state[12], uint
         if (e != hipSuccess) return e;
         const uint64_t this_batch = batch;
         uint64_t count = glh::P - base < this_batch ? glh::P - base : this_batch;
-        hipLaunchKernelGGL(pow_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, st, pos, min_leading_zeros, base, count, best);
+        hipLaunchKernelGGL(pow_kernel, dim3(grid_for(count, 256)), dim3(256), 0, stream, st, pos, min_leading_zeros, base, count, best, d_challenger);
         unsigned long long h = ~0ull;
         e = hipMemcpyAsync(&h, best, 8, hipMemcpyDeviceToHost, stream);
         if (e != hipSuccess) return e;

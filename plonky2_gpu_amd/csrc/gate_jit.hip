@@ -80,13 +80,11 @@ struct GateUnit {
     std::vector<char> code;
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
-    uint64_t *d_apow = nullptr;  // the module's g_apow[num_challenges][num_constraints]
-    uint64_t *d_pih = nullptr;  // the module's g_pih[4]
-    uint64_t *d_par = nullptr;  // the module's g_par[6]: where the LDE lives
+    uint64_t *d_tab = nullptr;  // the module's g_tab: par[6] (where the LDE lives) | pih[4] | apow[num_challenges][num_constraints] (x 2 when fused) | bias
     // Constraints the generated code emits with a known constant added (the peephole pass below): bias[i] lists (k, b) for the
     // i-th gate of the unit — the code accumulates alpha^k (c_k + b), the launch supplies sum alpha^k b in g_bias to take off.
     std::vector<std::vector<std::pair<uint32_t, uint64_t>>> bias;
-    uint64_t *d_bias = nullptr;  // the module's g_bias[num_challenges][gates of the unit], if any gate has a bias
+    bool biased = false;  // any gate of the unit has a bias
     std::string error;
 };
 
@@ -104,9 +102,7 @@ struct GateKernel {
     std::mutex launch_mu;
     hipEvent_t done = nullptr;
     bool launched = false;
-    std::vector<uint64_t> h_table;
-    std::vector<std::vector<uint64_t>> h_bias;
-    uint64_t h_pih[4], h_par[6];
+    std::vector<std::vector<uint64_t>> h_tab;  // per unit: the host image of its GateTab
 };
 
 // What every consumer of gate programs checks before running them (the compiled kernel when it is generated, the
@@ -682,8 +678,10 @@ static std::string generate_fused_source(const uint16_t *instrs, uint32_t num_in
     o << "#define GL_JIT 1\n" << GL_FIELD_SRC << "\n" << GL_JIT_FIELD_SRC << "\n";
     o << "#define NGU " << unit_gates.size() << "\n#define NCH " << nch << "\n#define NGC " << ngc << "\n";
     // g_apow[c][k] = {alpha_c^k, alpha_c^k * 2^32}: the two-column accumulators of gate_jit_field.h (gl::DotCol2)
-    o << "__constant__ uint64_t g_apow[NCH * NGC * 2];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n"
-         "__constant__ uint64_t g_par[6];\n"
+    // ONE constant object per unit — LDE pointers and strides, public-inputs hash, alpha powers, biases — so that a launch uploads
+    // one piece per unit (round 5: four pieces per unit, 24 small copies per quotient); the names the generated code uses are macros
+    o << "struct GateTab { uint64_t par[6]; uint64_t pih[4]; uint64_t apow[NCH * NGC * 2]; uint64_t bias[NCH * NGU]; };\n__constant__ GateTab g_tab;\n"
+         "#define g_apow g_tab.apow\n#define g_pih g_tab.pih\n#define g_bias g_tab.bias\n#define g_par g_tab.par\n"
          "typedef const __attribute__((address_space(4))) uint64_t* apow_t;\n"
          "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
          "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
@@ -742,15 +740,15 @@ static std::string generate_source(const uint16_t *instrs, uint32_t num_instrs, 
     o << "struct GateSum { uint64_t v[NCH]; };\n";
     // alpha powers and the public-inputs hash live at link-time-constant addresses, so every read is a scalar
     // load (a pointer ARGUMENT of a non-inlined device function arrives in VGPRs and would be read per lane)
-    o << "__constant__ uint64_t g_apow[NCH * NGC];\n__constant__ uint64_t g_pih[4];\n__constant__ uint64_t g_bias[NCH * NGU];\n";
+    o << "struct GateTab { uint64_t par[6]; uint64_t pih[4]; uint64_t apow[NCH * NGC]; uint64_t bias[NCH * NGU]; };\n__constant__ GateTab g_tab;\n"
+         "#define g_apow g_tab.apow\n#define g_pih g_tab.pih\n#define g_bias g_tab.bias\n#define g_par g_tab.par\n";
     // Where the LDE lives: {wires, row stride, element stride, constants/sigmas, row stride, element stride} (strides in elements), as
     // link-time-constant scalars for the same reason: the element stride that every wire load multiplies by is then a scalar, not a
     // vector register of a function argument. (Measured in round 5, profiles/r05_quotient_codegen_ab.jsonl: going further — a BUFFER
     // load per wire whose descriptor carries the uniform part of the address, zero vector instructions per load, 16 k of 165 k fewer —
     // made the ed25519 quotient 2 % SLOWER: the scalar chain that rebuilds the descriptor in front of every load keeps the compiler from
     // issuing a gate's loads in one batch, and four waves per SIMD do not hide the latency that exposes.)
-    o << "__constant__ uint64_t g_par[6];\n"
-         "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
+    o << "static __device__ __forceinline__ void gj_acc(uint64_t &al, uint64_t &ah, uint64_t x, uint32_t k) {\n"
          "  asm(\"v_mad_u64_u32 %0, vcc, %2, %4, %0\\n\\tv_mad_u64_u32 %1, vcc, %3, %4, %1\" : \"+v\"(al), \"+v\"(ah) : \"v\"((uint32_t)x), \"v\"((uint32_t)(x >> 32)), \"s\"(k) : \"vcc\");\n}\n";
     for (size_t gi = 0; gi < unit_gates.size(); gi++) {
         const uint32_t g = unit_gates[gi];
@@ -969,12 +967,9 @@ static hipError_t load_unit(GateUnit &u) {
     hipError_t e = hipModuleLoadData(&u.module, u.code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&u.fn, u.module, "gate_constraints_kernel");
     size_t bytes = 0;
-    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_apow), &bytes, u.module, "g_apow");
-    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_pih), &bytes, u.module, "g_pih");
-    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_par), &bytes, u.module, "g_par");
-    bool biased = false;
-    for (const auto &b : u.bias) biased |= !b.empty();
-    if (e == hipSuccess && biased) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_bias), &bytes, u.module, "g_bias");
+    if (e == hipSuccess) e = hipModuleGetGlobal(reinterpret_cast<hipDeviceptr_t *>(&u.d_tab), &bytes, u.module, "g_tab");
+    u.biased = false;
+    for (const auto &b : u.bias) u.biased |= !b.empty();
     return e;
 }
 
@@ -1302,39 +1297,29 @@ hipError_t gate_kernel_launch(const GateKernel *kc, const uint64_t *wires, uint6
             p = glh::mul(p, a);
         }
     }
-    std::vector<uint64_t> &table = k->h_table;  // what the units' g_apow holds
-    table = apow;
+    std::vector<uint64_t> table = apow;  // what the units' g_apow holds
     if (k->fused) {
         table.resize(apow.size() * 2);
         for (size_t i = 0; i < apow.size(); i++) table[2 * i] = apow[i], table[2 * i + 1] = glh::mul(apow[i], 1ull << 32);
     }
-    for (int i = 0; i < 4; i++) k->h_pih[i] = pih[i] % glh::P;
-    const uint64_t par[6] = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es};
-    for (int i = 0; i < 6; i++) k->h_par[i] = par[i];
-    std::vector<std::vector<uint64_t>> &unit_bias = k->h_bias;
-    unit_bias.assign(k->units.size(), {});
+    // one image of GateTab per unit: par | pih | apow | bias
+    k->h_tab.assign(k->units.size(), {});
     for (size_t ui = 0; ui < k->units.size(); ui++) {
         const GateUnit &u = k->units[ui];
-        if (!u.d_bias) continue;
-        unit_bias[ui].assign((size_t)k->num_challenges * u.gates.size(), 0);
-        for (uint32_t c = 0; c < k->num_challenges; c++)
-            for (size_t gi = 0; gi < u.gates.size(); gi++) {
-                uint64_t b = 0;
-                for (const auto &kb : u.bias[gi]) b = glh::add(b, glh::mul(apow[(size_t)c * k->num_constraints + kb.first], kb.second));
-                unit_bias[ui][(size_t)c * u.gates.size() + gi] = b;
-            }
-    }
-    for (size_t ui = 0; ui < k->units.size(); ui++) {
-        const GateUnit &u = k->units[ui];
-        e = hipMemcpyAsync(u.d_apow, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) return e;
-        if (u.d_bias) {
-            e = hipMemcpyAsync(u.d_bias, unit_bias[ui].data(), unit_bias[ui].size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
-            if (e != hipSuccess) return e;
-        }
-        e = hipMemcpyAsync(u.d_pih, k->h_pih, sizeof k->h_pih, hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) return e;
-        e = hipMemcpyAsync(u.d_par, k->h_par, sizeof k->h_par, hipMemcpyHostToDevice, stream);
+        std::vector<uint64_t> &img = k->h_tab[ui];
+        img.reserve(10 + table.size() + (size_t)k->num_challenges * u.gates.size());
+        img = {(uint64_t)(uintptr_t)wires, w_rs, w_es, (uint64_t)(uintptr_t)cs, c_rs, c_es, pih[0] % glh::P, pih[1] % glh::P, pih[2] % glh::P, pih[3] % glh::P};
+        img.insert(img.end(), table.begin(), table.end());
+        const size_t b0 = img.size();
+        img.resize(b0 + (size_t)k->num_challenges * u.gates.size(), 0);
+        if (u.biased)
+            for (uint32_t c = 0; c < k->num_challenges; c++)
+                for (size_t gi = 0; gi < u.gates.size(); gi++) {
+                    uint64_t b = 0;
+                    for (const auto &kb : u.bias[gi]) b = glh::add(b, glh::mul(apow[(size_t)c * k->num_constraints + kb.first], kb.second));
+                    img[b0 + (size_t)c * u.gates.size() + gi] = b;
+                }
+        e = hipMemcpyAsync(u.d_tab, img.data(), img.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
     }
     const unsigned grid = (unsigned)((lde_size + 127) / 128);

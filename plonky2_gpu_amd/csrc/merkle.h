@@ -30,7 +30,11 @@ hipError_t sponge_absorb(uint64_t *d_state, const uint64_t *d_inputs, uint32_t n
 // leaves + Merkle paths of `count` leaf indices: element j of leaf i at leaves[i*row_stride + j*elem_stride].
 hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
                              uint32_t cap_height, const uint64_t *digests, const uint64_t *d_idx, uint32_t count, uint64_t *out_leaves,
-                             uint64_t *out_sib, hipStream_t stream);
+                             uint64_t *out_sib, hipStream_t stream, uint64_t idx_mask = ~0ull, uint32_t idx_shift = 0);
+// One step of the device-resident Challenger (merkle.hip challenger_step_kernel): d_challenger = 32 u64 (flags & 1: start from the
+// empty transcript); observes the sources in order, then writes n_out challenges (flags & 2: the 4-word hash_no_pad instead) to d_out.
+hipError_t challenger_step(uint64_t *d_challenger, const uint64_t *const *src_ptrs, const uint64_t *src_counts, const uint64_t *src_planar,
+                           uint32_t n_src, uint32_t n_out, uint32_t flags, uint64_t *d_out, hipStream_t stream);
 // cols[c*col_stride + r] -> rows[r*n_cols + c]
 hipError_t transpose_to_leaf_major(const uint64_t *cols, uint64_t *rows, uint32_t n_cols, uint64_t n_rows,
                                    uint64_t col_stride, hipStream_t stream);

@@ -307,6 +307,81 @@ __global__ __launch_bounds__(64) void sponge_absorb_kernel(uint64_t *state, cons
     if (lane < 12) state[lane] = gl::canon(x);
 }
 
+// The Challenger with its state in DEVICE memory (iop/challenger.rs:19-149): T[0..12) sponge state, T[12..20) input buffer,
+// T[28] its length, T[29] the number of unread outputs (the output buffer itself is state[0..8) while that is non-zero: the state
+// does not change between a duplexing and the next one). One launch = observe_elements over up to eight sources, in order, read
+// where the producing kernels left them (a cap, the openings, planar extension coefficients), then get_n_challenges — no host
+// round trip inside a transcript step; the host fetches only the challenges it needs itself.
+struct ChallengerSrc {
+    const uint64_t *p;
+    uint64_t count;       // elements of this source
+    uint64_t planar_len;  // != 0: element i is p[(i & 1) * planar_len + (i >> 1)] (an extension vector kept as two planes)
+};
+struct ChallengerArgs {
+    ChallengerSrc src[8];
+    uint32_t n_src, n_out, flags;
+};
+constexpr uint32_t CH_RESET = 1, CH_HASH = 2;
+
+__global__ __launch_bounds__(64) void challenger_step_kernel(uint64_t *__restrict__ T, ChallengerArgs a, uint64_t *__restrict__ out,
+                                                             poseidon_coop::Tables tb) {
+    __shared__ uint64_t lds[12];
+    const int lane = threadIdx.x;
+    const bool reset = a.flags & CH_RESET;
+    uint64_t x = (lane < 12 && !reset) ? T[lane] : 0;           // lane k < 12: state word k
+    uint64_t inb = (lane < 8 && !reset) ? T[12 + lane] : 0;     // lane k < 8: input buffer slot k
+    uint32_t in_len = reset ? 0u : (uint32_t)T[28], out_len = reset ? 0u : (uint32_t)T[29];
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < a.n_src; i++) total += a.src[i].count;
+    auto fetch = [&](uint64_t g) -> uint64_t {  // element g of the concatenated sources, canonical (observe_element takes field elements)
+        for (uint32_t i = 0; i < a.n_src; i++) {
+            if (g < a.src[i].count) {
+                const ChallengerSrc &sr = a.src[i];
+                return gl::canon(sr.planar_len ? sr.p[(g & 1) * sr.planar_len + (g >> 1)] : sr.p[g]);
+            }
+            g -= a.src[i].count;
+        }
+        return 0;
+    };
+    uint64_t pos = 0;
+    // observe_element (challenger.rs:43-53) for every element: the buffer fills, duplexing() overwrites the state's first words with it
+    // and permutes (:131-149); every observation clears the output buffer, the eighth of a block refills it
+    while (in_len + (total - pos) >= 8) {
+        if (lane < 8) x = (uint32_t)lane < in_len ? inb : fetch(pos + lane - in_len);
+        x = poseidon_coop::permute(x, tb, lds);
+        pos += 8 - in_len;
+        in_len = 0;
+        out_len = 8;
+    }
+    if (pos < total) {
+        const uint32_t r = (uint32_t)(total - pos);
+        if ((uint32_t)lane >= in_len && (uint32_t)lane < in_len + r) inb = fetch(pos + lane - in_len);
+        in_len += r;
+        out_len = 0;
+    }
+    auto duplexing = [&]() {
+        if ((uint32_t)lane < in_len) x = inb;
+        x = poseidon_coop::permute(x, tb, lds);
+        in_len = 0;
+        out_len = 8;
+    };
+    if (a.flags & CH_HASH) {
+        // hash_n_to_hash_no_pad (hash/hashing.rs:81-108): a short last chunk overwrites its own words and is permuted; out = state[0..4)
+        if (in_len) duplexing();
+        if (lane < 4) out[lane] = gl::canon(x);
+    } else {
+        for (uint32_t c = 0; c < a.n_out; c++) {  // get_challenge (:87-97): the output buffer is popped from the back
+            if (in_len || !out_len) duplexing();
+            const uint64_t v = poseidon_coop::lane_value(x, (int)out_len - 1);
+            if (lane == 0) out[c] = gl::canon(v);
+            out_len--;
+        }
+    }
+    if (lane < 12) T[lane] = gl::canon(x);
+    if (lane < 8) T[12 + lane] = inb;
+    if (lane == 0) T[28] = in_len, T[29] = out_len;
+}
+
 // A tree layer with few nodes: one wavefront per node (latency ~6x shorter than a lane per node).
 __global__ __launch_bounds__(64) void tree_layer_coop_kernel(uint64_t *__restrict__ digests, uint64_t *__restrict__ cap, uint32_t L,
                                                              uint32_t log_sub_leaves, poseidon_coop::Tables tb) {
@@ -328,9 +403,11 @@ __global__ __launch_bounds__(64) void tree_layer_coop_kernel(uint64_t *__restric
 // block q copies leaf idx[q] (leaf-major rows or column-major columns) and its sibling digests.
 __global__ __launch_bounds__(64) void merkle_open_kernel(const uint64_t *__restrict__ leaves, uint64_t row_stride, uint64_t elem_stride,
                                                          uint32_t leaf_len, const uint64_t *__restrict__ digests, uint32_t num_layers,
-                                                         uint64_t subtree_digests, const uint64_t *__restrict__ idx,
-                                                         uint64_t *__restrict__ out_leaves, uint64_t *__restrict__ out_sib) {
-    const uint64_t q = blockIdx.x, leaf = idx[q];
+                                                         uint64_t subtree_digests, const uint64_t *__restrict__ idx, uint64_t idx_mask,
+                                                         uint32_t idx_shift, uint64_t *__restrict__ out_leaves, uint64_t *__restrict__ out_sib) {
+    // the leaf of query q: (idx[q] & idx_mask) >> idx_shift — a query index is a challenge reduced to the LDE's size, and the index
+    // into a FRI layer's tree is that shifted by the arities so far (fri/prover.rs:186-236); callers with plain indices pass ~0, 0
+    const uint64_t q = blockIdx.x, leaf = (idx[q] & idx_mask) >> idx_shift;
     for (uint32_t j = threadIdx.x; j < leaf_len; j += blockDim.x) out_leaves[q * leaf_len + j] = leaves[leaf * row_stride + j * elem_stride];
     const uint64_t base = subtree_digests * (leaf >> num_layers);
     for (uint32_t t = threadIdx.x; t < 4 * num_layers; t += blockDim.x) {
@@ -676,14 +753,27 @@ hipError_t sponge_absorb(uint64_t *d_state, const uint64_t *d_inputs, uint32_t n
 
 hipError_t merkle_open_batch(const uint64_t *leaves, uint64_t row_stride, uint64_t elem_stride, uint32_t leaf_len, uint64_t n_leaves,
                              uint32_t cap_height, const uint64_t *digests, const uint64_t *d_idx, uint32_t count, uint64_t *out_leaves,
-                             uint64_t *out_sib, hipStream_t stream) {
+                             uint64_t *out_sib, hipStream_t stream, uint64_t idx_mask, uint32_t idx_shift) {
     if (count == 0) return hipSuccess;
     uint32_t lg = 0;
     while ((1ull << lg) < n_leaves) lg++;
     const uint32_t num_layers = lg - cap_height;
     const uint64_t subtree_digests = 2 * ((n_leaves >> cap_height) - 1);
     hipLaunchKernelGGL(merkle_open_kernel, dim3(count), dim3(64), 0, stream, leaves, row_stride, elem_stride, leaf_len, digests, num_layers,
-                       subtree_digests, d_idx, out_leaves, out_sib);
+                       subtree_digests, d_idx, idx_mask, idx_shift, out_leaves, out_sib);
+    return hipGetLastError();
+}
+
+hipError_t challenger_step(uint64_t *d_challenger, const uint64_t *const *src_ptrs, const uint64_t *src_counts, const uint64_t *src_planar,
+                           uint32_t n_src, uint32_t n_out, uint32_t flags, uint64_t *d_out, hipStream_t stream) {
+    if (n_src > 8) return hipErrorInvalidValue;
+    ChallengerArgs a = {};
+    for (uint32_t i = 0; i < n_src; i++) a.src[i] = ChallengerSrc{src_ptrs[i], src_counts[i], src_planar ? src_planar[i] : 0};
+    a.n_src = n_src, a.n_out = n_out, a.flags = flags;
+    poseidon_coop::Tables tb;
+    hipError_t e = coop_tables(&tb, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(challenger_step_kernel, dim3(1), dim3(64), 0, stream, d_challenger, a, d_out, tb);
     return hipGetLastError();
 }
 

@@ -7,7 +7,7 @@
 // the serial glue a Rust host would otherwise write against those entry points — the transcript's
 // buffers, challenge arithmetic on single field elements, buffer management, serialisation — so that a
 // host in any language needs exactly two calls. No polynomial, LDE, tree or witness column is touched
-// by the CPU; the transcript's permutations run on the device (gl_sponge_absorb).
+// by the CPU; the transcript lives on the device (gl_challenger_step): its sponge state, input buffer and challenges.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -58,8 +58,25 @@ E2 e2_pow(E2 x, uint64_t e) {
 struct Pool {
     std::mutex m;
     std::multimap<uint64_t, uint64_t *> free_;  // bytes -> buffer
+    // page-locked host staging of this context's proofs: what the host sends (circuit digest, public inputs) and everything it
+    // fetches (challenges, caps, openings, query answers) goes through it, so that the copies are truly asynchronous
+    uint64_t *pinned = nullptr;
+    uint64_t pinned_words = 0;
     ~Pool() {
         for (auto &kv : free_) (void)gl_free(kv.second);
+        if (pinned) (void)gl_free_host(pinned);
+    }
+    GlError staging(uint64_t words, uint64_t **out) {
+        if (pinned_words < words) {
+            if (pinned) (void)gl_free_host(pinned);
+            pinned = nullptr, pinned_words = 0;
+            void *q = nullptr;
+            GlError e = gl_malloc_host(&q, words * 8);
+            if (e.code != 0) return e;
+            pinned = static_cast<uint64_t *>(q), pinned_words = words;
+        }
+        *out = pinned;
+        return GlError{0, nullptr};
     }
     uint64_t *get(uint64_t bytes) {
         std::lock_guard<std::mutex> lock(m);
@@ -125,54 +142,7 @@ struct Batch {
     std::vector<uint64_t> cap;  // host copy, 4 << cap_height
 };
 
-// ---- transcript ----------------------------------------------------------------------------------
-struct Challenger {  // iop/challenger.rs:19-149, overwrite-mode duplex sponge over Poseidon
-    uint64_t state[12] = {0};
-    std::vector<uint64_t> in, out;
-    void *ctx;
-    explicit Challenger(void *c) : ctx(c) {}
-
-    GlError observe(const uint64_t *es, size_t n) {  // observe_element for each (challenger.rs:43-59)
-        if (!n) return ok();
-        std::vector<uint64_t> buf(in);
-        for (size_t i = 0; i < n; i++) buf.push_back(es[i] % P);
-        const size_t full = buf.size() / 8 * 8;
-        out.clear();
-        if (full) {
-            // all full rate blocks in one device call; only the last duplexing's output can be read
-            TRY(gl_sponge_absorb(state, buf.data(), (uint32_t)(full / 8), ctx));
-            if (full == buf.size()) out.assign(state, state + 8);
-        }
-        in.assign(buf.begin() + full, buf.end());
-        return ok();
-    }
-    GlError observe(const std::vector<uint64_t> &v) { return observe(v.data(), v.size()); }
-    GlError duplexing() {  // challenger.rs:131-149
-        for (size_t i = 0; i < in.size(); i++) state[i] = in[i];
-        in.clear();
-        uint64_t block[8];
-        memcpy(block, state, sizeof block);
-        TRY(gl_sponge_absorb(state, block, 1, ctx));
-        out.assign(state, state + 8);
-        return ok();
-    }
-    GlError challenge(uint64_t *c) {  // challenger.rs:87-97
-        if (!in.empty() || out.empty()) TRY(duplexing());
-        *c = out.back();
-        out.pop_back();
-        return ok();
-    }
-    GlError challenges(uint32_t n, std::vector<uint64_t> *v) {
-        v->resize(n);
-        for (uint32_t i = 0; i < n; i++) TRY(challenge(&(*v)[i]));
-        return ok();
-    }
-    GlError ext_challenge(E2 *e) {
-        TRY(challenge(&e->a));
-        return challenge(&e->b);
-    }
-};
-
+// ---- transcript: device-resident (gl_challenger_step), see prove_impl; gl_circuit_create hashes a few host words once ----
 GlError hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4], void *ctx) {  // hash/hashing.rs:81-108
     uint64_t st[12] = {0};
     std::vector<uint64_t> v(n);
@@ -230,7 +200,8 @@ GlError canon_copy(uint64_t *d_dst, const uint64_t *d_src, uint64_t n, void *ctx
 }
 
 // d_salt: SALT_SIZE columns of n_ext caller-provided random elements in leaf order (a blinded commitment, prover.rs:84, 125, 174), or null
-GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx, const uint64_t *d_salt = nullptr) {
+GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, const Circuit &c, void *ctx, const uint64_t *d_salt = nullptr,
+              bool fetch_cap = true) {
     const uint64_t n_ext = 1ull << (c.degree_bits + c.rate_bits);
     const uint32_t salt = d_salt ? SALT_SIZE : 0;
     b->coeffs = std::move(polys);
@@ -250,6 +221,7 @@ GlError commit(Batch *b, DevBuf &&polys, bool from_values, uint32_t n_polys, con
         TRY(gl_commit_from_coeffs(b->coeffs.p, n_polys, c.degree_bits, c.rate_bits, c.cap_height, salt, 7, b->lde.p, nullptr, b->digests.p,
                                   b->cap_d.p, ctx));
     b->cap.resize(4ull << c.cap_height);
+    if (!fetch_cap) return ok();  // gl_prove: the transcript reads the cap where it lies; the host copy is fetched with the rest of the proof
     return gl_memcpy_d2h(b->cap.data(), b->cap_d.p, b->cap.size() * 8, ctx);
 }
 
@@ -396,37 +368,119 @@ GlError gl_circuit_info(const void *circuit, uint64_t h_digest[4], uint64_t *h_c
 
 void gl_bytes_free(uint8_t *p) { free(p); }
 
+// Asynchronous copies between device memory and the pool's page-locked staging, on the context's first stream.
+static GlError copy_async(void *dst, const void *src, uint64_t bytes, bool to_host, void *ctx) {
+    if (!bytes) return ok();
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, *reinterpret_cast<hipStream_t *>(ctx));
+    if (e != hipSuccess) return fail(std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    return ok();
+}
+static GlError stream_sync(void *ctx) {
+    const hipError_t e = hipStreamSynchronize(*reinterpret_cast<hipStream_t *>(ctx));
+    if (e != hipSuccess) return fail(std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return ok();
+}
+
+// The transcript of a proof lives on the device (gl_challenger_step): every observation reads its source where the producing kernel
+// left it (caps, openings, the final polynomial, the proof-of-work witness), the FRI betas, the query indices and the proof-of-work
+// state are consumed there, and the host fetches exactly the challenges it computes with — betas / gammas (with the public-inputs
+// hash), alphas, zeta, the FRI alpha — one small copy and one stream synchronisation each, then the proof-of-work witness, then
+// everything that goes into the proof bytes in one go. Round 5 paid a host round trip per Challenger call (sixteen per proof, each
+// an upload, a launch, a download and a synchronisation) and one per cap, opening batch and query batch.
 static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
                           const uint64_t *d_salts, uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
     if (!circuit || !d_wires || !proof || !proof_len || !ctx || (num_public_inputs && !h_public_inputs)) return fail("null pointer");
     const Circuit &c = *static_cast<const Circuit *>(circuit);
     if (c.hiding && !d_salts) return fail("the circuit's FRI parameters are hiding (zero_knowledge): prove it with gl_prove_zk and salt columns");
     if (!c.hiding && d_salts) return fail("gl_prove_zk on a circuit whose FRI parameters are not hiding");
-    PoolScope pool_scope(c.pool_of(ctx));  // every DevBuf below comes from / returns to the circuit's pool
-    const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf;
-    const uint64_t n = 1ull << db, n_ext = n << c.rate_bits;
+    Pool *pool = c.pool_of(ctx);
+    PoolScope pool_scope(pool);  // every DevBuf below comes from / returns to the circuit's pool of this context
+    const uint32_t db = c.degree_bits, nch = c.num_challenges, qdf = c.qdf, nq = c.num_queries, npi = num_public_inputs;
+    const uint64_t n = 1ull << db, n_ext = n << c.rate_bits, cap_words = 4ull << c.cap_height;
     const uint32_t npp = num_partial_products(c.num_routed, qdf);
+    const uint32_t lg_ext = db + c.rate_bits, init_layers = lg_ext - c.cap_height, n_fri = (uint32_t)c.arity_bits.size();
     if (h_stage_ms) memset(h_stage_ms, 0, sizeof(double) * GL_PROVE_STAGES);
     Stages st(h_stage_ms, ctx);
 
-    uint64_t pih[4];
-    TRY(hash_no_pad(h_public_inputs, num_public_inputs, pih, ctx));  // prover.rs:52
+    // ---- the small-data side of the proof: one device buffer, one page-locked mirror -------------------------------------------
+    const uint32_t n_polys[4] = {c.num_constants + c.num_routed, c.num_wires, nch * (1 + npp), nch * qdf};
+    const uint32_t salt = d_salts ? SALT_SIZE : 0;
+    const uint32_t leaf_len[4] = {n_polys[0], n_polys[1] + salt, n_polys[2] + salt, n_polys[3] + salt};
+    struct FriShape {
+        uint64_t n_leaves;
+        uint32_t leaf_len, layers, shift;
+    };
+    std::vector<FriShape> fs(n_fri);
+    uint64_t final_len = n;
+    {
+        uint64_t len = n;
+        uint32_t shift = 0;
+        for (uint32_t li = 0; li < n_fri; li++) {
+            const uint32_t ab = c.arity_bits[li];
+            fs[li].n_leaves = (len << c.rate_bits) >> ab, fs[li].leaf_len = 2u << ab;
+            if (fs[li].n_leaves < (1ull << c.cap_height)) return fail("FRI layer smaller than the Merkle cap");
+            uint32_t lg = 0;
+            while ((1ull << lg) < fs[li].n_leaves) lg++;
+            fs[li].layers = lg - c.cap_height;
+            shift += ab;
+            fs[li].shift = shift;
+            len >>= ab;
+        }
+        final_len = len;
+    }
+    struct Span {
+        uint64_t off = 0, words = 0;
+    };
+    uint64_t top = 0;
+    auto take = [&](uint64_t words) {
+        Span sp{top, words};
+        top += (words + 1) & ~1ull;  // 16-byte granules
+        return sp;
+    };
+    const Span T = take(32), HP = take(32), hostin = take(4 + (uint64_t)npi);
+    const Span fetch0 = take(0);  // from here on: what the host fetches
+    const Span pih_s = take(4), bg = take(2ull * nch), alphas_s = take(nch), zeta_s = take(2), alpha_fri_s = take(2), fri_betas = take(2ull * n_fri);
+    const Span pow_w = take(1), resp_idx = take(1 + (uint64_t)nq);
+    Span opens[4], caps[3], fri_caps = take(cap_words * n_fri), final_s = take(2 * final_len);
+    for (int o = 0; o < 4; o++) opens[o] = take(2ull * (o == 2 ? 2 : 1) * n_polys[o]);
+    for (int o = 0; o < 3; o++) caps[o] = take(cap_words);
+    Span q_leaves[4], q_sib[4];
+    for (int o = 0; o < 4; o++) q_leaves[o] = take((uint64_t)nq * leaf_len[o]), q_sib[o] = take((uint64_t)nq * init_layers * 4);
+    std::vector<Span> s_leaves(n_fri), s_sib(n_fri);
+    for (uint32_t li = 0; li < n_fri; li++) s_leaves[li] = take((uint64_t)nq * fs[li].leaf_len), s_sib[li] = take((uint64_t)nq * fs[li].layers * 4);
+    DevBuf small;
+    TRY(small.alloc(top));
+    uint64_t *const D = small.p;
+    uint64_t *H = nullptr;
+    TRY(pool->staging(top, &H));
+    auto fetch = [&](const Span &sp) { return copy_async(H + sp.off, D + sp.off, sp.words * 8, true, ctx); };
+    auto step = [&](std::initializer_list<GlObserveSrc> srcs, uint32_t n_out, const Span &out, uint32_t flags = 0, const Span *which = nullptr) {
+        return gl_challenger_step(D + (which ? which->off : T.off), srcs.begin(), (uint32_t)srcs.size(), n_out, n_out || (flags & GL_CHALLENGER_HASH) ? D + out.off : nullptr,
+                                  flags, ctx);
+    };
+
+    // circuit digest and public inputs go up once; hash_no_pad(public inputs) (prover.rs:52) on a scratch challenger
+    memcpy(H + hostin.off, c.digest, 32);
+    for (uint32_t i = 0; i < npi; i++) H[hostin.off + 4 + i] = h_public_inputs[i];
+    TRY(copy_async(D + hostin.off, H + hostin.off, hostin.words * 8, false, ctx));
+    TRY(step({GlObserveSrc{D + hostin.off + 4, npi, 0}}, 0, pih_s, GL_CHALLENGER_RESET | GL_CHALLENGER_HASH, &HP));
     // wires commitment (prover.rs:66-90); the caller's witness stays intact for the partial products
     Batch wires;
     {
         DevBuf w;
         TRY(w.alloc((uint64_t)c.num_wires * n));
         TRY(gl_memcpy_d2d(w.p, d_wires, 8ull * c.num_wires * n, ctx));
-        TRY(commit(&wires, std::move(w), true, c.num_wires, c, ctx, d_salts));
+        TRY(commit(&wires, std::move(w), true, c.num_wires, c, ctx, d_salts, false));
     }
     TRY(st.mark(0));
-    Challenger ch(ctx);
-    TRY(ch.observe(c.digest, 4));
-    TRY(ch.observe(pih, 4));
-    TRY(ch.observe(wires.cap));
-    std::vector<uint64_t> betas, gammas, alphas;
-    TRY(ch.challenges(nch, &betas));
-    TRY(ch.challenges(nch, &gammas));
+    // challenger.observe_hash(circuit digest), observe_hash(public inputs hash), observe_cap(wires cap); betas, gammas (prover.rs:92-97)
+    TRY(step({GlObserveSrc{D + hostin.off, 4, 0}, GlObserveSrc{D + pih_s.off, 4, 0}, GlObserveSrc{wires.cap_d.p, cap_words, 0}}, 2 * nch, bg, GL_CHALLENGER_RESET));
+    TRY(fetch(Span{pih_s.off, bg.off + bg.words - pih_s.off}));
+    TRY(stream_sync(ctx));
+    uint64_t pih[4];
+    memcpy(pih, H + pih_s.off, 32);
+    const std::vector<uint64_t> betas(H + bg.off, H + bg.off + nch), gammas(H + bg.off + nch, H + bg.off + 2 * nch);
+    std::vector<uint64_t> alphas;
     // partial products and Z (prover.rs:99-117), committed in place
     Batch zs;
     {
@@ -435,11 +489,13 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
         TRY(gl_permutation_partial_products(d_wires, n, c.sigmas.p, n, c.k_is.p, betas.data(), gammas.data(), nch, c.num_routed, qdf, db, z.p,
                                             ctx));
         TRY(st.mark(1));
-        TRY(commit(&zs, std::move(z), true, nch * (1 + npp), c, ctx, d_salts ? d_salts + (uint64_t)SALT_SIZE * n_ext : nullptr));
+        TRY(commit(&zs, std::move(z), true, nch * (1 + npp), c, ctx, d_salts ? d_salts + (uint64_t)SALT_SIZE * n_ext : nullptr, false));
     }
     TRY(st.mark(2));
-    TRY(ch.observe(zs.cap));
-    TRY(ch.challenges(nch, &alphas));
+    TRY(step({GlObserveSrc{zs.cap_d.p, cap_words, 0}}, nch, alphas_s));
+    TRY(fetch(alphas_s));
+    TRY(stream_sync(ctx));
+    alphas.assign(H + alphas_s.off, H + alphas_s.off + nch);
     // quotient polynomials (prover.rs:137-151)
     uint32_t qdb = 0;
     while ((1u << qdb) < qdf) qdb++;
@@ -489,43 +545,33 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
                 TRY(gl_memcpy_d2d(chunks.p + (uint64_t)k * qdf * n, quotient.p + ((uint64_t)k << (db + qdb)), 8ull * qdf * n, ctx));
             }
         }
-        TRY(commit(&quot, std::move(chunks), false, nch * qdf, c, ctx, d_salts ? d_salts + 2ull * SALT_SIZE * n_ext : nullptr));
+        TRY(commit(&quot, std::move(chunks), false, nch * qdf, c, ctx, d_salts ? d_salts + 2ull * SALT_SIZE * n_ext : nullptr, false));
     }
     TRY(st.mark(4));
-    TRY(ch.observe(quot.cap));
-    E2 zeta;
-    TRY(ch.ext_challenge(&zeta));
+    TRY(step({GlObserveSrc{quot.cap_d.p, cap_words, 0}}, 2, zeta_s));
+    TRY(fetch(zeta_s));
+    TRY(stream_sync(ctx));
+    const E2 zeta{H[zeta_s.off], H[zeta_s.off + 1]};
     if (E2 zn = e2_pow(zeta, n); zn.a == 1 && zn.b == 0) return fail("Opening point is in the subgroup.");
     const uint64_t g = glh::root_of_unity(db);
     const E2 g_zeta = e2_mul(E2{g, 0}, zeta);
-    // OpeningSet::new (plonk/proof.rs:305-334)
+    // OpeningSet::new (plonk/proof.rs:305-334): every oracle's polynomials at zeta, the Zs also at g * zeta, left in device memory
     const Batch *oracles[4] = {&c.cs, &wires, &zs, &quot};
-    std::vector<uint64_t> ev[4], zs_next;
     {
-        DevBuf out;
         const uint64_t pts[4] = {zeta.a, zeta.b, g_zeta.a, g_zeta.b};
-        for (int o = 0; o < 4; o++) {
-            const uint32_t np = o == 2 ? 2 : 1;
-            TRY(out.alloc(2ull * np * oracles[o]->n_polys));
-            TRY(gl_eval_polys_ext2(oracles[o]->coeffs.p, oracles[o]->n_polys, db, n, pts, np, out.p, ctx));
-            std::vector<uint64_t> h(2ull * np * oracles[o]->n_polys);
-            TRY(gl_memcpy_d2h(h.data(), out.p, h.size() * 8, ctx));
-            ev[o].assign(h.begin(), h.begin() + 2ull * oracles[o]->n_polys);
-            if (o == 2) zs_next.assign(h.begin() + 2ull * oracles[o]->n_polys, h.begin() + 2ull * oracles[o]->n_polys + 2ull * nch);
-        }
+        for (int o = 0; o < 4; o++)
+            TRY(gl_eval_polys_ext2(oracles[o]->coeffs.p, oracles[o]->n_polys, db, n, pts, o == 2 ? 2 : 1, D + opens[o].off, ctx));
     }
     TRY(st.mark(5));
-    // to_fri_openings (proof.rs:336-356): [constants, sigmas, wires, zs, partial products, quotient], then zs_next
-    {
-        std::vector<uint64_t> batch0;
-        for (int o = 0; o < 4; o++) batch0.insert(batch0.end(), ev[o].begin(), ev[o].end());
-        TRY(ch.observe(batch0));
-        TRY(ch.observe(zs_next));
-    }
-
+    // to_fri_openings (proof.rs:336-356): [constants, sigmas, wires, zs, partial products, quotient], then zs_next; then the FRI alpha
     // ---- PolynomialBatch::prove_openings (fri/oracle.rs:1047-1112) ----
-    E2 alpha;
-    TRY(ch.ext_challenge(&alpha));
+    TRY(step({GlObserveSrc{D + opens[0].off, 2ull * n_polys[0], 0}, GlObserveSrc{D + opens[1].off, 2ull * n_polys[1], 0},
+              GlObserveSrc{D + opens[2].off, 2ull * n_polys[2], 0}, GlObserveSrc{D + opens[3].off, 2ull * n_polys[3], 0},
+              GlObserveSrc{D + opens[2].off + 2ull * n_polys[2], 2ull * nch, 0}},
+             2, alpha_fri_s));
+    TRY(fetch(alpha_fri_s));
+    TRY(stream_sync(ctx));
+    const E2 alpha{H[alpha_fri_s.off], H[alpha_fri_s.off + 1]};
     DevBuf final_poly;  // planar [2][n]
     TRY(final_poly.alloc(2 * n));
     {
@@ -554,15 +600,12 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
         // d_ptrs / comp return to the pool here while their kernels may still be queued: stream order
     }
     TRY(st.mark(6));
-    // ---- fri_committed_trees (fri/prover.rs:77-120) ----
+    // ---- fri_committed_trees (fri/prover.rs:77-120): no host synchronisation inside — the betas stay on the device ----
     struct Layer {
         DevBuf rows, digests, cap_d;
-        std::vector<uint64_t> cap;
-        uint64_t n_leaves;
-        uint32_t leaf_len;
     };
-    std::vector<Layer> layers(c.arity_bits.size());
-    std::vector<uint64_t> final_coeffs;
+    std::vector<Layer> layers(n_fri);
+    DevBuf final_coeffs_d;
     {
         DevBuf coeffs = std::move(final_poly), vals;
         uint64_t len = n, shift = 7;
@@ -573,108 +616,79 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
             return gl_coset_lde_batch(coeffs.p, dst->p, 2, lg, c.rate_bits, shift, len, len << c.rate_bits, ctx);
         };
         if (!layers.empty()) TRY(lde(&vals));
-        for (size_t li = 0; li < layers.size(); li++) {
+        for (uint32_t li = 0; li < n_fri; li++) {
             const uint32_t ab = c.arity_bits[li];
             const uint64_t lde_len = len << c.rate_bits;
             Layer &L = layers[li];
-            L.n_leaves = lde_len >> ab, L.leaf_len = 2u << ab;
-            if (L.n_leaves < (1ull << c.cap_height)) return fail("FRI layer smaller than the Merkle cap");
             TRY(L.rows.alloc(2 * lde_len));
             TRY(gl_ext2_interleave(vals.p, lde_len, L.rows.p, ctx));
-            TRY(L.digests.alloc(8 * (L.n_leaves - (1ull << c.cap_height)) + 4));
-            TRY(L.cap_d.alloc(4ull << c.cap_height));
-            TRY(gl_merkle_tree_from_leaves(L.rows.p, L.leaf_len, L.n_leaves, c.cap_height, L.digests.p, L.cap_d.p, ctx));
-            L.cap.resize(4ull << c.cap_height);
-            TRY(gl_memcpy_d2h(L.cap.data(), L.cap_d.p, L.cap.size() * 8, ctx));
-            TRY(ch.observe(L.cap));
-            E2 beta;
-            TRY(ch.ext_challenge(&beta));
+            TRY(L.digests.alloc(8 * (fs[li].n_leaves - (1ull << c.cap_height)) + 4));
+            TRY(L.cap_d.alloc(cap_words));
+            TRY(gl_merkle_tree_from_leaves(L.rows.p, fs[li].leaf_len, fs[li].n_leaves, c.cap_height, L.digests.p, L.cap_d.p, ctx));
+            TRY(gl_memcpy_d2d(D + fri_caps.off + li * cap_words, L.cap_d.p, cap_words * 8, ctx));
+            TRY(step({GlObserveSrc{L.cap_d.p, cap_words, 0}}, 2, Span{fri_betas.off + 2ull * li, 2}));
             DevBuf next;
             TRY(next.alloc(2 * (len >> ab)));
-            const uint64_t be[2] = {beta.a, beta.b};
-            TRY(gl_fri_fold(coeffs.p, len, ab, be, next.p, ctx));
+            TRY(gl_fri_fold_device(coeffs.p, len, ab, D + fri_betas.off + 2ull * li, next.p, ctx));
             coeffs = std::move(next);  // the old coefficients return to the pool (stream order keeps them valid)
             len >>= ab;
             shift = glh::pow(shift, 1ull << ab);
-            if (li + 1 < layers.size()) TRY(lde(&vals));
+            if (li + 1 < n_fri) TRY(lde(&vals));
         }
-        std::vector<uint64_t> planes(2 * len);
-        TRY(gl_memcpy_d2h(planes.data(), coeffs.p, planes.size() * 8, ctx));
-        final_coeffs.resize(2 * len);
-        for (uint64_t i = 0; i < len; i++) final_coeffs[2 * i] = planes[i], final_coeffs[2 * i + 1] = planes[len + i];
-        TRY(ch.observe(final_coeffs));
+        // observe_extension_elements(final_poly.coeffs) (fri/prover.rs:117): the two planes read interleaved
+        TRY(step({GlObserveSrc{coeffs.p, 2 * len, len}}, 0, Span{}));
+        final_coeffs_d = std::move(coeffs);
     }
     TRY(st.mark(7));
     // ---- fri_proof_of_work (fri/prover.rs:122-171) ----
     uint64_t pow_witness = 0;
-    {
-        const uint32_t min_lz = c.pow_bits + 0;  // F::order() has 64 bits: leading zeros of the u64 response
-        uint64_t s[12];
-        memcpy(s, ch.state, sizeof s);
-        for (size_t i = 0; i < ch.in.size(); i++) s[i] = ch.in[i];
-        TRY(gl_fri_proof_of_work(s, (uint32_t)ch.in.size(), min_lz, &pow_witness, ctx));
-        TRY(ch.observe(&pow_witness, 1));
-        uint64_t resp;
-        TRY(ch.challenge(&resp));
-        if (min_lz && (resp >> (64 - min_lz)) != 0) return fail("proof-of-work response does not have the required leading zeros");
-    }
+    TRY(gl_fri_proof_of_work_device(D + T.off, c.pow_bits, D + pow_w.off, &pow_witness, ctx));  // F::order() has 64 bits: leading zeros of the u64 response
+    // observe the witness, draw the response, then the query indices (fri/prover.rs:163-170, 181-190)
+    TRY(step({GlObserveSrc{D + pow_w.off, 1, 0}}, 1 + nq, resp_idx));
     TRY(st.mark(8));
-    // ---- fri_prover_query_rounds (fri/prover.rs:173-260) ----
-    std::vector<uint64_t> idx;
-    TRY(ch.challenges(c.num_queries, &idx));
-    for (auto &x : idx) x %= n_ext;
-    uint32_t lg_ext = db + c.rate_bits;
-    const uint32_t init_layers = lg_ext - c.cap_height;
-    std::vector<uint64_t> init_leaves[4], init_sib[4];
-    for (int o = 0; o < 4; o++) {
-        init_leaves[o].resize((uint64_t)c.num_queries * oracles[o]->leaf_len);  // salted leaves go into the proof whole (fri/prover.rs:203-210)
-        init_sib[o].resize((uint64_t)c.num_queries * init_layers * 4 + 4);
-        TRY(gl_merkle_open_batch(oracles[o]->lde.p, 1, n_ext, oracles[o]->leaf_len, n_ext, c.cap_height, oracles[o]->digests.p, idx.data(),
-                                 c.num_queries, init_leaves[o].data(), init_sib[o].data(), ctx));
-    }
-    std::vector<std::vector<uint64_t>> step_leaves(layers.size()), step_sib(layers.size());
-    std::vector<uint32_t> step_layers(layers.size());
-    {
-        std::vector<uint64_t> cur(idx);
-        for (size_t li = 0; li < layers.size(); li++) {
-            for (auto &x : cur) x >>= c.arity_bits[li];
-            uint32_t lg = 0;
-            while ((1ull << lg) < layers[li].n_leaves) lg++;
-            step_layers[li] = lg - c.cap_height;
-            step_leaves[li].resize((uint64_t)c.num_queries * layers[li].leaf_len);
-            step_sib[li].resize((uint64_t)c.num_queries * step_layers[li] * 4 + 4);
-            TRY(gl_merkle_open_batch(layers[li].rows.p, layers[li].leaf_len, 1, layers[li].leaf_len, layers[li].n_leaves, c.cap_height,
-                                     layers[li].digests.p, cur.data(), c.num_queries, step_leaves[li].data(), step_sib[li].data(), ctx));
-        }
-    }
+    // ---- fri_prover_query_rounds (fri/prover.rs:173-260): the indices never leave the device ----
+    const uint64_t *d_idx = D + resp_idx.off + 1;
+    for (int o = 0; o < 4; o++)  // salted leaves go into the proof whole (fri/prover.rs:203-210)
+        TRY(gl_merkle_open_batch_device(oracles[o]->lde.p, 1, n_ext, oracles[o]->leaf_len, n_ext, c.cap_height, oracles[o]->digests.p, d_idx, nq, 0,
+                                        D + q_leaves[o].off, D + q_sib[o].off, ctx));
+    for (uint32_t li = 0; li < n_fri; li++)
+        TRY(gl_merkle_open_batch_device(layers[li].rows.p, fs[li].leaf_len, 1, fs[li].leaf_len, fs[li].n_leaves, c.cap_height, layers[li].digests.p,
+                                        d_idx, nq, fs[li].shift, D + s_leaves[li].off, D + s_sib[li].off, ctx));
+    // everything the proof consists of, in one go
+    TRY(gl_memcpy_d2d(D + caps[0].off, wires.cap_d.p, cap_words * 8, ctx));
+    TRY(gl_memcpy_d2d(D + caps[1].off, zs.cap_d.p, cap_words * 8, ctx));
+    TRY(gl_memcpy_d2d(D + caps[2].off, quot.cap_d.p, cap_words * 8, ctx));
+    TRY(gl_memcpy_d2d(D + final_s.off, final_coeffs_d.p, 2 * final_len * 8, ctx));
+    TRY(fetch(Span{fetch0.off, top - fetch0.off}));
+    TRY(gl_ctx_synchronize(ctx));
     TRY(st.mark(9));
+    if (c.pow_bits && (H[resp_idx.off] >> (64 - c.pow_bits)) != 0) return fail("proof-of-work response does not have the required leading zeros");
+    if (H[pow_w.off] != pow_witness) return fail("proof-of-work witness changed between the search and the transcript");
     // ---- write_proof_with_public_inputs (util/serialization.rs:641-689) ----
     Bytes out;
-    out.fields(wires.cap);
-    out.fields(zs.cap);
-    out.fields(quot.cap);
+    for (int o = 0; o < 3; o++) out.fields(H + caps[o].off, cap_words);  // wires, zs / partial products, quotient
     // write_opening_set (:557-571): constants, sigmas, wires, zs, zs_next, partial products, quotient
-    out.fields(ev[0]);                                                       // constants then sigmas: contiguous
-    out.fields(ev[1]);                                                       // wires
-    out.fields(ev[2].data(), 2ull * nch);                                    // plonk_zs
-    out.fields(zs_next);                                                     // plonk_zs_next
-    out.fields(ev[2].data() + 2ull * nch, ev[2].size() - 2ull * nch);        // partial_products
-    out.fields(ev[3]);                                                       // quotient_polys
-    for (auto &L : layers) out.fields(L.cap);
-    for (uint32_t q = 0; q < c.num_queries; q++) {
+    const uint64_t *ev[4] = {H + opens[0].off, H + opens[1].off, H + opens[2].off, H + opens[3].off};
+    out.fields(ev[0], 2ull * n_polys[0]);                                   // constants then sigmas: contiguous
+    out.fields(ev[1], 2ull * n_polys[1]);                                   // wires
+    out.fields(ev[2], 2ull * nch);                                          // plonk_zs
+    out.fields(ev[2] + 2ull * n_polys[2], 2ull * nch);                      // plonk_zs_next
+    out.fields(ev[2] + 2ull * nch, 2ull * n_polys[2] - 2ull * nch);         // partial_products
+    out.fields(ev[3], 2ull * n_polys[3]);                                   // quotient_polys
+    for (uint32_t li = 0; li < n_fri; li++) out.fields(H + fri_caps.off + li * cap_words, cap_words);
+    for (uint32_t q = 0; q < nq; q++) {
         for (int o = 0; o < 4; o++) {
-            out.fields(init_leaves[o].data() + (uint64_t)q * oracles[o]->leaf_len, oracles[o]->leaf_len);
-            out.merkle_proof(init_sib[o].data() + (uint64_t)q * init_layers * 4, init_layers);
+            out.fields(H + q_leaves[o].off + (uint64_t)q * leaf_len[o], leaf_len[o]);
+            out.merkle_proof(H + q_sib[o].off + (uint64_t)q * init_layers * 4, init_layers);
         }
-        for (size_t li = 0; li < layers.size(); li++) {
-            out.fields(step_leaves[li].data() + (uint64_t)q * layers[li].leaf_len, layers[li].leaf_len);
-            out.merkle_proof(step_sib[li].data() + (uint64_t)q * step_layers[li] * 4, step_layers[li]);
+        for (uint32_t li = 0; li < n_fri; li++) {
+            out.fields(H + s_leaves[li].off + (uint64_t)q * fs[li].leaf_len, fs[li].leaf_len);
+            out.merkle_proof(H + s_sib[li].off + (uint64_t)q * fs[li].layers * 4, fs[li].layers);
         }
     }
-    out.fields(final_coeffs);
+    for (uint64_t i = 0; i < final_len; i++) out.field(H[final_s.off + i]), out.field(H[final_s.off + final_len + i]);  // interleaved (a_i, b_i)
     out.field(pow_witness);
     out.fields(h_public_inputs, num_public_inputs);
-    TRY(gl_ctx_synchronize(ctx));
     uint8_t *buf = static_cast<uint8_t *>(malloc(out.v.size() ? out.v.size() : 1));
     if (!buf) return fail("out of memory");
     memcpy(buf, out.v.data(), out.v.size());

@@ -161,3 +161,138 @@ def test_fold_and_interleave(gpu, log_len, ab):
     d_r = DeviceBuffer(gpu, 2 * n)
     _lib.call("gl_ext2_interleave", d_c.ptr, n, d_r.ptr, gpu.ptr)
     assert d_r.download().tolist() == fri_ref.flatten(coeffs)
+
+
+# ---- the device-resident Challenger and the entry points that read its outputs from device memory (round 6) ----
+
+def _step(pg, gpu, d_ch, srcs, n_out, flags=0):
+    """gl_challenger_step; srcs = [(DeviceBuffer or address, count, planar_len)]; returns the n_out challenges (or the 4-word hash)"""
+    import ctypes
+
+    import numpy as np
+    from plonky2_gpu_amd import _lib
+
+    arr = (_lib.GlObserveSrc * max(1, len(srcs)))()
+    for i, (p, count, planar) in enumerate(srcs):
+        arr[i] = _lib.GlObserveSrc(p if isinstance(p, int) else p.ptr, count, planar)
+    words = 4 if flags & 2 else n_out
+    d_out = pg.DeviceBuffer(gpu, max(words, 1))
+    _lib.call("gl_challenger_step", d_ch.ptr, ctypes.addressof(arr), len(srcs), n_out, d_out.ptr if words else None, flags, gpu.ptr)
+    out = d_out.download()[:words].tolist() if words else []
+    d_out.free()
+    return [int(v) for v in out]
+
+
+@pytest.mark.gpu
+def test_device_challenger_equals_the_reference_transcript(gpu):
+    """gl_challenger_step against the oracle's Challenger (iop/challenger.rs) over a script that crosses every state the buffers can
+    be in: observations that end inside a block, exactly on a block, spanning several; challenges drawn from a fresh duplexing, from
+    what an earlier draw left, after a partial observation; several sources per step, a planar extension source, non-canonical inputs;
+    and hash_n_to_hash_no_pad of lengths 0..17 (hashing.rs:81-108: the short last chunk leaves the old words)."""
+    import random
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    from oracle import fri_ref, pyref
+
+    rnd = random.Random(77)
+    P = pyref.P
+    ref = fri_ref.Challenger()
+    d_ch = pg.DeviceBuffer(gpu, 32)
+    first = True
+    script = [([3], 0), ([5], 2), ([], 7), ([8], 1), ([16, 1], 0), ([], 9), ([7, 9, 3], 3), ([64], 4), ([1], 1), ([1], 1), ([0], 8), ([23], 0), ([], 1)]
+    for counts, n_out in script:
+        srcs, keep = [], []
+        for cnt in counts:
+            vals = [rnd.randrange(1 << 64) if rnd.random() < 0.2 else rnd.randrange(P) for _ in range(cnt)]  # some >= p: observed mod p
+            buf = pg.DeviceBuffer.from_host(gpu, np.array(vals or [0], dtype=np.uint64))
+            keep.append(buf)
+            srcs.append((buf, cnt, 0))
+            ref.observe_elements(vals)
+        got = _step(pg, gpu, d_ch, srcs, n_out, flags=1 if first else 0)
+        first = False
+        assert got == ref.get_n_challenges(n_out), (counts, n_out)
+        for b in keep:
+            b.free()
+    # a planar extension vector [2][len] is observed interleaved (observe_extension_elements)
+    ln = 5
+    planes = [rnd.randrange(P) for _ in range(2 * ln)]
+    buf = pg.DeviceBuffer.from_host(gpu, np.array(planes, dtype=np.uint64))
+    ref.observe_extension_elements([(planes[i], planes[ln + i]) for i in range(ln)])
+    assert _step(pg, gpu, d_ch, [(buf, 2 * ln, ln)], 3) == ref.get_n_challenges(3)
+    buf.free()
+    # the state in device memory is the transcript's: sponge state, input buffer, lengths
+    T = d_ch.download()
+    assert [int(v) for v in T[:12]] == ref.sponge_state and int(T[28]) == len(ref.input_buffer) and int(T[29]) == len(ref.output_buffer)
+    # hash_no_pad on a scratch challenger
+    d_scratch = pg.DeviceBuffer(gpu, 32)
+    for ln in list(range(0, 18)) + [135]:
+        vals = [rnd.randrange(P) for _ in range(ln)]
+        buf = pg.DeviceBuffer.from_host(gpu, np.array(vals or [0], dtype=np.uint64))
+        assert _step(pg, gpu, d_scratch, [(buf, ln, 0)], 0, flags=3) == pyref.hash_no_pad(vals), ln
+        buf.free()
+    d_scratch.free()
+    d_ch.free()
+
+
+@pytest.mark.gpu
+def test_fold_open_and_proof_of_work_read_the_transcript_from_device_memory(gpu):
+    """gl_fri_fold_device = gl_fri_fold with the same beta; gl_merkle_open_batch_device with raw challenges and a shift = gl_merkle_open_batch
+    with the reduced indices; gl_fri_proof_of_work_device on a device challenger = gl_fri_proof_of_work on the same duplex state."""
+    import ctypes
+    import random
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    from oracle import fri_ref, pyref
+    from plonky2_gpu_amd import _lib
+
+    rnd = random.Random(78)
+    P = pyref.P
+    # fold
+    ln, ab = 1 << 10, 3
+    coeffs = np.array([rnd.randrange(P) for _ in range(2 * ln)], dtype=np.uint64)
+    beta = np.array([rnd.randrange(P), rnd.randrange(P)], dtype=np.uint64)
+    d_c, d_b = pg.DeviceBuffer.from_host(gpu, coeffs), pg.DeviceBuffer.from_host(gpu, beta)
+    d_o1, d_o2 = pg.DeviceBuffer(gpu, 2 * (ln >> ab)), pg.DeviceBuffer(gpu, 2 * (ln >> ab))
+    _lib.call("gl_fri_fold", d_c.ptr, ln, ab, beta, d_o1.ptr, gpu.ptr)
+    _lib.call("gl_fri_fold_device", d_c.ptr, ln, ab, d_b.ptr, d_o2.ptr, gpu.ptr)
+    assert (d_o1.download() == d_o2.download()).all()
+    # openings: a tree over 2^9 leaves of 6 elements, cap height 2; queries are raw 64-bit challenges, the tree is the one after a shift of 3
+    n_leaves, leaf_len, cap_h, shift, count = 1 << 9, 6, 2, 3, 11
+    rows = np.array([rnd.randrange(P) for _ in range(n_leaves * leaf_len)], dtype=np.uint64)
+    d_rows = pg.DeviceBuffer.from_host(gpu, rows)
+    d_dig, d_cap = pg.DeviceBuffer(gpu, 8 * (n_leaves - (1 << cap_h)) + 4), pg.DeviceBuffer(gpu, 4 << cap_h)
+    _lib.call("gl_merkle_tree_from_leaves", d_rows.ptr, leaf_len, n_leaves, cap_h, d_dig.ptr, d_cap.ptr, gpu.ptr)
+    raw = np.array([rnd.randrange(1 << 64) for _ in range(count)], dtype=np.uint64)
+    reduced = np.array([(int(x) % (n_leaves << shift)) >> shift for x in raw], dtype=np.uint64)
+    layers = 9 - cap_h
+    h_l, h_s = np.zeros(count * leaf_len, dtype=np.uint64), np.zeros(count * layers * 4, dtype=np.uint64)
+    _lib.call("gl_merkle_open_batch", d_rows.ptr, leaf_len, 1, leaf_len, n_leaves, cap_h, d_dig.ptr, reduced, count, h_l, h_s, gpu.ptr)
+    d_raw = pg.DeviceBuffer.from_host(gpu, raw)
+    d_ol, d_os = pg.DeviceBuffer(gpu, count * leaf_len), pg.DeviceBuffer(gpu, count * layers * 4)
+    _lib.call("gl_merkle_open_batch_device", d_rows.ptr, leaf_len, 1, leaf_len, n_leaves, cap_h, d_dig.ptr, d_raw.ptr, count, shift, d_ol.ptr, d_os.ptr, gpu.ptr)
+    assert (d_ol.download() == h_l).all() and (d_os.download() == h_s).all()
+    # proof of work: a transcript with three elements waiting in its input buffer
+    ref = fri_ref.Challenger()
+    obs = [rnd.randrange(P) for _ in range(19)]
+    ref.observe_elements(obs)
+    d_ch = pg.DeviceBuffer(gpu, 32)
+    d_obs = pg.DeviceBuffer.from_host(gpu, np.array(obs, dtype=np.uint64))
+    assert _step(pg, gpu, d_ch, [(d_obs, len(obs), 0)], 0, flags=1) == []
+    state = list(ref.sponge_state)
+    for i, x in enumerate(ref.input_buffer):
+        state[i] = x
+    w_host, w_dev = ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.call("gl_fri_proof_of_work", np.array(state, dtype=np.uint64), len(ref.input_buffer), 12, ctypes.byref(w_host), gpu.ptr)
+    d_w = pg.DeviceBuffer(gpu, 2)
+    _lib.call("gl_fri_proof_of_work_device", d_ch.ptr, 12, d_w.ptr, ctypes.byref(w_dev), gpu.ptr)
+    assert w_dev.value == w_host.value and int(d_w.download()[0]) == w_host.value
+    ref.observe_element(w_host.value)
+    resp = ref.get_challenge()
+    assert resp >> (64 - 12) == 0
+    assert _step(pg, gpu, d_ch, [(d_w, 1, 0)], 1) == [resp]
+    for b in (d_c, d_b, d_o1, d_o2, d_rows, d_dig, d_cap, d_raw, d_ol, d_os, d_ch, d_obs, d_w):
+        b.free()
