@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prove", action="store_true", help="skip the configs[3]/[4]-shaped prove() measurement")
     ap.add_argument("--no-reference", action="store_true", help="skip timing the reference's own kernels (oracle/_ref) on this GPU")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="N > 1 ranks on whatever devices there are, over a HOST backend, through the code the RCCL route takes (device tensors over the "
+                         "library's pointers, staged through host memory for transport only), with the invariants of the N-rank line checked: see dry_ranks_checks")
     ap.add_argument("--reference-leg-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--prove-degree-bits", type=int, default=18)
     ap.add_argument("--prove-wires", type=int, default=234)
@@ -510,12 +513,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    ndev = pg.load().gl_device_count()
+    # ORDER MATTERS at N > 1: torch carries its own copy of the HIP runtime, and a process in which libplonky2_hip (the system's
+    # runtime) has made the first HIP call can no longer bring torch's up ("No HIP GPUs are available" — found by --dry-ranks in
+    # round 6; the other order works, tests/dist_nccl_self.py). So the devices are counted through torch (which does not initialise
+    # anything) and the process group — RCCL, or the dry device path — is formed BEFORE the library is loaded.
+    if world > 1:
+        import torch
+
+        ndev = torch.cuda.device_count()
+    else:
+        ndev = pg.load().gl_device_count()
     if ndev <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # barrier / max-reduce / cap gather only (no data-path collective exists): over RCCL/xGMI when each rank has its
     # own GPU, over gloo when the ranks share one (the one-GPU box)
-    dist = ProverGroup(backend=pick_backend(world, ndev), device_index=int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+    dist = ProverGroup(backend="gloo" if args.dry_ranks else pick_backend(world, ndev), device_index=int(os.environ.get("LOCAL_RANK", "0")) % ndev,
+                       dry_device_path=args.dry_ranks)
+    if pg.load().gl_device_count() != ndev:
+        raise SystemExit("bench.py: torch and libplonky2_hip see different numbers of devices")
     ctx = pg.Context(dist.local_rank % ndev)
     log_n, batch = args.log_n, args.batch
     n = 1 << log_n
@@ -743,6 +758,8 @@ def main():
         # scalars: the LAST keys of the line (a reader that keeps only the tail of the line still has them), and once more inside
         # `roofline` / `cpu_baseline`, which readers that keep the contract's objects keep whole. Stage names follow the reference's
         # timing labels (plonk/prover.rs:66-233: "to compute wire polynomials / wires commitment / partial products / quotient ...").
+        if args.dry_ranks:
+            out["dry_ranks"] = dry_ranks_checks(pg, _lib, ctx, args, out, extra)
         pr, fl = extra.get("prove") or {}, extra.get("prove_in_flight") or {}
         head = {
             "ntts_per_s": out["value"],
@@ -840,6 +857,51 @@ def bench_prove(pg, ctx, dist, degree_bits, num_wires, reps):
     nc.close()  # the circuit's working buffers (one proof's worth of HBM) go back before the next leg
     # rank 0 at N = 1 hands its circuit, witness and proof to the CPU leg (cpu_baseline_prove), which proves the same thing
     return res, ((circuit, wires, pis, data) if dist.rank == 0 and dist.world == 1 else None)
+
+
+def dry_ranks_checks(pg, _lib, ctx, args, out, extra):
+    """--dry-ranks, rank 0, after the group's measurements: the N-rank line against what ONE rank computes alone. Raises (non-zero
+    exit, no line) when an invariant fails. No RCCL claim is attached: the transport was a host backend; what ran is everything else
+    — rank launch and rendezvous, sharding, device tensors over library-owned pointers, the exchange's bookkeeping, the gathers."""
+    import hashlib
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_circuit
+    from plonky2_gpu_amd.challenger import hash_no_pad
+    from plonky2_gpu_amd.dist import shard_range
+
+    W = args.gpus
+    checks = {"ranks": out["config"]["ranks"], "transport": out["config"]["rank_sync_backend"]}
+    if out["config"]["ranks"] != W or out["n_gpus"] != W:
+        raise SystemExit(f"dry-ranks: the line reports {out['config']['ranks']} ranks, {W} were asked for")
+    if not args.no_prove:
+        pr = extra["prove"]
+        if len(pr["wires_cap0_per_rank"]) != W or len(pr["proofs_per_s_per_rank"]) != W:
+            raise SystemExit("dry-ranks: the prove leg did not gather one entry per rank")
+        table = "ed25519" if args.prove_wires == 234 else "mini"
+        for r in range(W):  # rank r proved the circuit of seed 1 + r: the same proof made here, alone, starts with the same cap
+            circuit, wires, pis = synth_circuit.make(args.prove_degree_bits, num_wires=args.prove_wires, num_routed=80, num_constants=8, seed=1 + r, gate_table=table)
+            synth_circuit.set_public_input_row(wires, hash_no_pad(ctx, pis))
+            nc = pg.NativeCircuit(ctx, dict(circuit, circuit_digest=None))
+            data = nc.prove_bytes(np.ascontiguousarray(wires), pis)
+            nc.close()
+            alone = [hex(int(x)) for x in np.frombuffer(data[:32], dtype="<u8")]
+            if alone != pr["wires_cap0_per_rank"][r]:
+                raise SystemExit(f"dry-ranks: rank {r}'s wires cap {pr['wires_cap0_per_rank'][r]} differs from the one-rank proof's {alone}")
+        checks["per_rank_wires_caps_equal_the_one_rank_proofs"] = True
+    if not args.no_commit and "sharded_commit" in extra and "exchange" in extra["sharded_commit"]:
+        sc, cols, log_n = extra["sharded_commit"], args.commit_cols, args.commit_log_n
+        if sc["cap0"] != extra["cap0"] or not sc["deterministic"]:
+            raise SystemExit("dry-ranks: the column-sharded commit's cap differs from the one-GPU commit's")
+        n_ext = (1 << log_n) << 3
+        lo, hi = shard_range(cols, W, 0)
+        want = 8 * (hi - lo) * (n_ext // W) * (W - 1)  # DESIGN.md 4: 8 * (my columns) * (leaves per rank) * (W - 1)
+        if sc["exchange"]["bytes_sent_per_rank"] != want or sc["exchange"]["links_used_per_rank"] != W - 1:
+            raise SystemExit(f"dry-ranks: bytes_sent_per_rank {sc['exchange']['bytes_sent_per_rank']} != {want}")
+        checks["sharded_commit_cap_equals_the_one_gpu_commit"] = True
+        checks["bytes_sent_per_rank_equals_8_cols_leaves_peers"] = want
+    checks["line_sha256_prefix"] = hashlib.sha256(json.dumps(extra.get("prove", {}).get("wires_cap0_per_rank", [])).encode()).hexdigest()[:16]
+    return checks
 
 
 def bench_prove_in_flight(pg, device, dist, degree_bits, num_wires, in_flight, reps):

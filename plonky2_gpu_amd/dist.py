@@ -19,8 +19,12 @@ def shard_range(n_units, world, rank):
 
 
 class ProverGroup:
-    def __init__(self, backend=None, device_index=None, force=False):
-        """`force` creates the process group even for one rank (how the RCCL route is exercised on a one-GPU box)."""
+    def __init__(self, backend=None, device_index=None, force=False, dry_device_path=False):
+        """`force` creates the process group even for one rank (how the RCCL route is exercised on a one-GPU box).
+        `dry_device_path` (with a host backend such as gloo, ranks sharing a device): the exchange builds its send and receive
+        tensors over the library's own device pointers exactly as the RCCL route does (device_tensor) and stages them through
+        host memory only for the transport itself — everything but the backend string is the code a node with a device per rank runs."""
+        self.dry_device_path = bool(dry_device_path)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -34,8 +38,14 @@ class ProverGroup:
             os.environ.setdefault("MASTER_PORT", "29511")
             self.backend = backend or "gloo"
             self.device_index = self.local_rank if device_index is None else int(device_index)
-            if self.backend == "nccl":
-                torch.cuda.set_device(self.device_index)
+            if self.backend == "nccl" or self.dry_device_path:
+                # torch brings its own copy of the HIP runtime; it must come up BEFORE the first HIP call of libplonky2_hip in this
+                # process (the other order fails with "No HIP GPUs are available"): form the group first, create contexts after
+                try:
+                    torch.cuda.set_device(self.device_index)
+                except RuntimeError as e:
+                    raise RuntimeError("torch could not initialise the GPU; if libplonky2_hip was used first in this process, create the "
+                                       "ProverGroup before the first library call (plonky2_gpu_amd.dist): %s" % e) from e
             # gloo announces its connections on the C++ stdout; rank 0's stdout carries the one JSON line of bench.py, so
             # the file descriptor (not just sys.stdout) points at stderr while the group is being formed
             import sys
@@ -167,6 +177,7 @@ class ShardedCommitPlan:
         else:
             td, torch = g.td, g.torch
             on_device = g.backend == "nccl"
+            dry = g.dry_device_path and not on_device  # device tensors over the library's pointers, transported through host memory
             reqs, staged = [], []
             # The path's ONE exchange, chunk by chunk: LDE of sixteen of my columns -> one pack launch groups, for every rank,
             # the leaf range it hashes of those columns (slice for rank q contiguous at packed[q][c0:c1][L]) -> the sends of
@@ -195,6 +206,8 @@ class ShardedCommitPlan:
                             continue
                         if on_device:  # zero copy: RCCL sends from the pack buffer
                             send = device_tensor(torch, self.d_packed.at(base + q * k * L), k * L, g.device_index)
+                        elif dry:  # the same tensor over the pack buffer, copied to the host by torch for the host transport
+                            send = device_tensor(torch, self.d_packed.at(base + q * k * L), k * L, g.device_index).cpu()
                         else:  # gloo: staged through host memory
                             send = self._host_tensor(("s", q, c0), k * L)
                             _lib.call("gl_memcpy_d2h", send.data_ptr(), self.d_packed.at(base + q * k * L), 8 * k * L, ctx.ptr)
@@ -221,7 +234,12 @@ class ShardedCommitPlan:
                 for item in staged:
                     if isinstance(item, tuple):
                         _, col, recv, cnt = item
-                        _lib.call("gl_memcpy_h2d", self.d_leaves.at(col * L), recv.data_ptr(), 8 * cnt, ctx.ptr)
+                        if dry:  # into the tensor the RCCL route receives into: the leaf block of that rank's columns
+                            device_tensor(torch, self.d_leaves.at(col * L), cnt, g.device_index).copy_(recv)
+                        else:
+                            _lib.call("gl_memcpy_h2d", self.d_leaves.at(col * L), recv.data_ptr(), 8 * cnt, ctx.ptr)
+                if dry:
+                    torch.cuda.synchronize()
             ctx.synchronize()
         _lib.call("gl_merkle_tree_from_columns", self.d_leaves.ptr, self.total_cols, L, L, self.local_cap_height, self.d_digests.ptr,
                   self.d_cap.ptr, ctx.ptr)

@@ -121,3 +121,33 @@ def test_bench_on_two_devices_synchronises_over_rccl(gpu):
     assert d["n_gpus"] == 2 and d["config"]["rank_sync_backend"] == "nccl" and d["config"]["devices_visible"] >= 2
     pr = d["extra"]["prove"]
     assert len(pr["proofs_per_s_per_rank"]) == 2 and len(pr["wires_cap0_per_rank"]) == 2
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dry_ranks_line_holds_its_invariants(gpu, world):
+    """`bench.py --gpus N --dry-ranks`: N ranks on the one device there is, over gloo, through the code a node with
+    a device per rank runs except for the backend string — the ranks are started by bench.py itself before anything touches the GPU,
+    every rank proves its own circuit, the column-sharded commit builds its send / receive tensors over the library's own device
+    pointers (dist.device_tensor) and only the transport goes through host memory — and rank 0 then checks the line against what one
+    rank computes alone: ranks == N, every rank's wires cap equals the cap of the same proof made alone, the sharded commit's cap
+    equals the one-GPU commit's, bytes_sent_per_rank = 8 x (my columns) x (leaves per rank) x (N - 1). A failed invariant is a
+    non-zero exit and no line. Small shapes: the point is the path, not the rate. No RCCL claim is attached to this mode."""
+    import json
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PLONKY2_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-ranks", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--log-n", "16", "--windows", "0", "--commit-cols", "40", "--commit-log-n", "12", "--prove-degree-bits", "12", "--prove-reps", "2",
+           "--prove-in-flight", "0", "--prove-larger", ""]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    dr = d["dry_ranks"]
+    assert d["n_gpus"] == world and dr["ranks"] == world and dr["transport"] == "gloo"
+    assert dr["per_rank_wires_caps_equal_the_one_rank_proofs"] is True and dr["sharded_commit_cap_equals_the_one_gpu_commit"] is True
+    lo, hi = 0, 40 // world + (1 if 40 % world else 0)
+    assert dr["bytes_sent_per_rank_equals_8_cols_leaves_peers"] == 8 * (hi - lo) * ((1 << 15) // world) * (world - 1)
+    assert len(set(tuple(c) for c in d["extra"]["prove"]["wires_cap0_per_rank"])) == world  # every rank proved its own circuit

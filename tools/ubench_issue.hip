@@ -10,7 +10,7 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR, CND32, ADD32, SUB32, ADDE64, MAD1, DOT4, MAD24, PERM, ADD3, LSHLADD32, ALIGNBIT, BFE, PLSWAP32, MADI64, MADU16 };
+enum Kind { MOV, ADD, ADDC, CND, LSHLADD64, MULLO, MULHI, XOR, CND32, ADD32, SUB32, ADDE64, MAD1, DOT4, MAD24, PERM, ADD3, LSHLADD32, ALIGNBIT, BFE, PLSWAP32, MADI64, MADU16, LSHLOR, SDWA_PACK, XOR_LIT, OR_SDWA, SDWA_BYTE };
 
 template <int KIND>
 __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
@@ -36,6 +36,12 @@ __device__ __forceinline__ void cheap(uint32_t &c, uint64_t &w, uint32_t x) {
     if constexpr (KIND == PLSWAP32) { uint32_t t = x; asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(t)); }
     if constexpr (KIND == MADI64) asm volatile("v_mad_i64_i32 %0, vcc, %1, %1, %0" : "+v"(w) : "v"(x) : "vcc");
     if constexpr (KIND == MADU16) asm volatile("v_mad_u32_u16 %0, %1, %1, %0" : "+v"(c) : "v"(x));
+    // round 6: the MDS layer's packing (P0 | P2 << 16) as the VOP3 instruction it uses, and as sub-dword forms of VOP1 / VOP2 (SDWA)
+    if constexpr (KIND == LSHLOR) asm volatile("v_lshl_or_b32 %0, %1, 16, %0" : "+v"(c) : "v"(x));
+    if constexpr (KIND == SDWA_PACK) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(c) : "v"(x));
+    if constexpr (KIND == OR_SDWA) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(c) : "v"(x));
+    if constexpr (KIND == SDWA_BYTE) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(c) : "v"(x));
+    if constexpr (KIND == XOR_LIT) asm volatile("v_xor_b32_e32 %0, 0x80808080, %0" : "+v"(c));   // VOP2 + 32-bit literal: an 8-byte encoding
     if constexpr (KIND == MAD1) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w) : "v"(x) : "vcc");       // multiply-add used as a 64-bit add
 }
 
@@ -108,6 +114,15 @@ int main() {
     run<0, 16, BFE>("v_bfe_u32 only");
     run<0, 16, PLSWAP32>("v_permlane32_swap_b32 only");
     run<0, 16, MADI64>("v_mad_i64_i32 only");
+    run<0, 16, LSHLOR>("v_lshl_or_b32 only");
+    run<0, 16, SDWA_PACK>("v_mov_b32_sdwa word -> word (pack) only");
+    run<0, 16, OR_SDWA>("v_or_b32_sdwa only");
+    run<0, 16, SDWA_BYTE>("v_mov_b32_sdwa byte -> byte only");
+    run<0, 16, XOR_LIT>("v_xor_b32 with a 32-bit literal only");
+    run<0, 16, LSHLOR>("v_lshl_or_b32 only", 4);
+    run<0, 16, SDWA_PACK>("v_mov_b32_sdwa word -> word (pack) only", 4);
+    run<0, 16, XOR>("v_xor_b32 only", 4);
+    run<0, 16, PERM>("v_perm_b32 only", 4);
     printf("-- the field multiplication's shape: 5 multiply-adds and 11-14 carry-chain instructions\n");
     run<5, 14, ADDC>("old gl::mul shape (5 + 14)");
     run<5, 11, ADDC>("new gl::mul shape (5 + 11)");
