@@ -322,7 +322,7 @@ def dft_point(x, log_n, k):
     return int(terms[0])
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")  # tools/pmc_summary.py over the rocprofv3 --pmc passes
 # the kernel sources whose counters the summary holds: tools/pmc_summary.py records their sha256 next to the counters
 PMC_SOURCES = ["plonky2_gpu_amd/csrc/ntt.hip", "plonky2_gpu_amd/csrc/ntt_direct.hip", "plonky2_gpu_amd/csrc/ntt_kernels.h",
                "plonky2_gpu_amd/csrc/poseidon.h", "plonky2_gpu_amd/csrc/poseidon_limb_constants.h", "plonky2_gpu_amd/csrc/gl_field.h"]

@@ -94,7 +94,8 @@ def test_the_committed_bench_line_agrees_with_itself_and_with_the_committed_kern
     steady command (profiles/r05_ntt_kernel_stats.csv, collected under the profiler on the same device in the same gpurun call,
     tools/gpu_runs/r05_pmc_and_bench.sh). Until the end of round 4 the roofline used per-pair events and read 3-6 % above the other two."""
     import csv
-    for tag, col_name in (("r04", "ntt_col_direct_kernel<2, true, false>"), ("r05", "ntt_col_direct_kernel<2, true, false, false>")):
+    for tag, col_name in (("r04", "ntt_col_direct_kernel<2, true, false>"), ("r05", "ntt_col_direct_kernel<2, true, false, false>"),
+                          ("r06", "ntt_col_direct_kernel<2, true, false, false>")):
         line = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench.json")).read())
         r = line["roofline"]
         assert "timed region" in r["ms_definition"]
@@ -114,12 +115,20 @@ def test_the_committed_bench_line_agrees_with_itself_and_with_the_committed_kern
 
 def test_the_documents_quote_the_committed_bench_line():
     """DESIGN.md / README.md quoted a commit time that was not in the artifact they cited. The figures of the current
-    round's tables are the ones of profiles/r05_bench.json (collected on one device in one call together with the kernel statistics
-    and counters), to the precision they are printed with."""
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench.json")).read())
+    round's tables are the ones of profiles/r06_bench.json (collected on one device in one call together with the kernel statistics
+    and counters), to the precision they are printed with. Since round 6 the line carries the whole metric as top-level scalars — the
+    LAST keys of the line — and they agree with the objects they summarise."""
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench.json")).read())
     e = line["extra"]
     want = ["%.1f k NTT/s" % (line["value"] / 1e3), "%.3f" % line["roofline"]["frac"], "%.1f ms" % e["commit_ms"], "%.1f ms" % e["prove"]["prove_ms"],
-            "%.0f M leaves/s" % (e["merkle_leaves_per_s"] / 1e6)]
+            "%.0f M leaves/s" % (e["merkle_leaves_per_s"] / 1e6), "%.1f proofs/s" % e["prove_in_flight"]["proofs_per_s"]]
+    tail = ["ntts_per_s", "ntt_hbm_frac", "prove_ms", "prove_proofs_per_s", "prove_proofs_per_s_in_flight", "prove_in_flight", "prove_wires_commitment_ms",
+            "prove_quotient_polys_ms", "commit_ms", "merkle_leaves_per_s", "commit_hbm_frac", "commit_cpu_baseline_ms", "prove_cpu_baseline_ms"]
+    assert list(line)[-len(tail):] == tail, list(line)[-len(tail):]
+    assert line["prove_ms"] == e["prove"]["prove_ms"] and line["commit_ms"] == e["commit_ms"] and line["merkle_leaves_per_s"] == e["merkle_leaves_per_s"]
+    assert line["prove_proofs_per_s_in_flight"] == e["prove_in_flight"]["proofs_per_s"] > line["prove_proofs_per_s"]
+    assert line["roofline"]["prove_ms"] == line["prove_ms"] and line["cpu_baseline"]["prove_ms"] == line["prove_cpu_baseline_ms"]
+    assert len(json.dumps({k: line[k] for k in tail})) < 1200  # they fit a 2 000-character tail with room to spare
     for doc in ("DESIGN.md", "README.md"):
         text = open(os.path.join(ROOT, doc)).read()
         for w in want:

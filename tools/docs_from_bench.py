@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Rewrite the measurement tables of DESIGN.md (3.1, 5) and the numbers paragraph of README.md from profiles/r05_bench.json and the
-kernel statistics collected in the same gpurun call (tools/gpu_runs/r05_pmc_and_bench.sh) — the documents quote the committed
+"""Rewrite the measurement tables of DESIGN.md (3.1, 5) and the numbers paragraph of README.md from profiles/r06_bench.json and the
+kernel statistics collected in the same gpurun call (tools/gpu_runs/r06_pmc_and_bench.sh) — the documents quote the committed
 artifact, tests/test_bench_guard.py checks that they do.   python tools/docs_from_bench.py"""
 import csv
 import json
@@ -12,10 +12,7 @@ P = lambda *a: os.path.join(ROOT, *a)  # noqa: E731
 
 def other_devices():
     rows = []
-    for name, what in (("r05_bench_final_code_another_device", "the final code — with the partial products' single inversion, which came after this table's call — on a slower device"),
-                       ("r05_bench_before_latency_forms", "before the branch-free s-boxes of the small kernels"), ("r05_bench_third_device_final_code", "same as the last"), ("r05_bench_fused_units_before_quotient_values_kernel", "before the quotient_values kernel"),
-                       ("r05_bench_before_fused_units", "one function per gate"), ("r05_bench_fast_device_before_gate_codegen", "round-4 generator"),
-                       ("r05_bench_another_device", "round-4 generator")):
+    for name, what in (("r06_bench_first", "a faster device, before the device-resident transcript: the round's first bench line"),):
         d = json.loads(open(P("profiles", name + ".json")).read())
         e = d["extra"]
         rows.append("%.1f k / %.1f ms / %.1f ms (%s)" % (d["value"] / 1e3, e["commit_ms"], e["prove"]["prove_ms"], what))
@@ -23,57 +20,61 @@ def other_devices():
 
 
 def main():
-    d = json.loads(open(P("profiles", "r05_bench.json")).read())
+    d = json.loads(open(P("profiles", "r06_bench.json")).read())
     r, e = d["roofline"], d["extra"]
     col = row = None
-    for k in csv.DictReader(open(P("profiles", "r05_ntt_kernel_stats.csv"))):
+    for k in csv.DictReader(open(P("profiles", "r06_ntt_kernel_stats.csv"))):
         if "ntt_col_direct_kernel<2, true, false, false>(" in k["Name"]:
             col = float(k["AverageNs"]) / 1e3
         if "ntt_row_natural_direct_kernel<false>" in k["Name"]:
             row = float(k["AverageNs"]) / 1e3
     pl, ref, st = e["prove_larger_traces"], e["reference_gpu_kernels_on_this_mi355x"], e["commit_stage_ms_one_at_a_time"]
-    before = json.loads(open(P("profiles", "r05_bench_before_fused_units.json")).read())["extra"]["prove"]
+    fl = e["prove_in_flight"]
+    hk = e["commit_hash_kernel_counters"]
     s = open(P("DESIGN.md")).read()
-    a = s.index("## 5. Measurement (one MI355X; `profiles/r05_*`)")
+    a = s.index("## 5. Measurement (one MI355X; `profiles/r0")
     b = s.index("`bench.py`: a step is `pairs_per_step` forward + inverse transforms")
-    new = f'''## 5. Measurement (one MI355X; `profiles/r05_*`)
+    new = f'''## 5. Measurement (one MI355X; `profiles/r06_*`)
 
-One table. The first column of values is `profiles/r05_bench.json` — ONE device, ONE `gpurun` call that also collected the kernel
-statistics and counters the line quotes (`tools/gpu_runs/r05_pmc_and_bench.sh`; `tests/test_bench_guard.py` ties this table to that
-file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 %; the other calls of this round, NTT/s / commit / prove:
-{"; ".join(other_devices())} — `profiles/r05_bench_*.json`. The second column is what the DRIVER measured at the
-end of round 4 (`BENCH_r04.json`) — the number on record; the NTT, LDE and hashing kernels are unchanged since, the quotient is not.
+One table. The first column of values is `profiles/r06_bench.json` — ONE device, ONE `gpurun` call that also collected the kernel
+statistics and counters the line quotes (`tools/gpu_runs/r06_pmc_and_bench.sh`; `tests/test_bench_guard.py` ties this table to that
+file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 % and more (this call's device clocked 2.03 GHz under the
+hashing kernel where round 5's clocked 2.08); the other call of this round, NTT/s / commit / prove: {"; ".join(other_devices())} —
+`profiles/r06_bench_first.json`. The second column is what the DRIVER measured at the end of round 5 (`BENCH_r05.json`) — the number on
+record; the NTT, LDE, hashing and gate kernels are unchanged since, what happens between them is not (§3.6, §4.1).
 
-| Quantity | `profiles/r05_bench.json` | driver, `BENCH_r04.json` | Source / note |
+| Quantity | `profiles/r06_bench.json` | driver, `BENCH_r05.json` | Source / note |
 |---|---|---|---|
-| NTTs/s at 2^20 (64-column batch, forward + inverse, natural order, HBM-resident) | **{d['value']/1e3:.1f} k NTT/s** (six windows {d['value_windows']['min']/1e3:.1f}–{d['value_windows']['max']/1e3:.1f} k) | 127.2 k | `value`, `value_windows` |
-| forward batch transform | {r['ms']:.3f} ms → **{r['frac']:.3f}** of 8 TB/s; {r['frac_of_measured_copy']:.2f} of the copy rate measured in the run ({r['measured_copy_GBps']/1e3:.1f} TB/s) | 0.503 ms, 0.267 | `roofline`; algorithmic bytes 16 B × 2^20 × 64 = 1.074 GB per launch pair |
-| the two kernels under rocprofv3 (same command) | column pass {col:.1f} µs + row pass {row:.1f} µs = {col+row:.1f} µs | 281.1 + 225.0 | `profiles/r05_ntt_kernel_stats.csv` |
-| HBM-side traffic (FETCH_SIZE × 2 + WRITE_SIZE) | {r['traffic']/1e9:.3f} GB = **{r['traffic_over_algorithmic']:.2f} ×** algorithmic (the second pass) | same | `roofline.traffic`, `profiles/r05_pmc_summary.json` |
-| vector-issue estimate (VALU instructions × 4 cycles ÷ SIMDs ÷ kernel cycles); waves parked at `s_waitcnt` / barrier | `int_alu_frac` {r['int_alu_frac']:.2f}; 0.39 in both passes; LDS bank conflicts 0 | 0.71 | `roofline.int_alu_frac`, `profiles/r05_pmc_summary.json` |
-| commit configs[2] (135 × 2^20, rate 8, cap 4, leaf-major copy included) | **{e['commit_ms']:.1f} ms** → **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, {e['commit_hbm_frac']:.3f} of the HBM roofline; without the leaf-major copy {e['commit_ms_without_leaf_major_copy']:.1f}; stages one at a time: iNTT {st['ifft (values -> coefficients)']:.1f} + LDE {st['coset LDE (bit-reversed)']:.1f} + hashing and tree {st['leaf hashing + tree layers']:.1f} | 63.2 ms, 132.7 M | `extra.commit_*`; hashing kernel: 27 056 vector + 480 matrix instructions per wavefront, issue estimate 1.03 |
-| full-width commits at north_star's trace sizes (135 columns; a device on which 2^20 takes 64.4 ms) | 2^21 133.8 ms, 2^22 280.8 ms, 2^23 574.1 ms = 125 / 119 / 117 M leaves/s, 0.020 / 0.019 / 0.019 (LDE 18 / 36 / 72 GB) | — | `profiles/r05_sweep.jsonl` |
-| `prove()` at the ed25519 shape (n = 2^18, 234 wires, whole gate table) | **{e['prove']['prove_ms']:.1f} ms** per proof (wires commitment {e['prove']['stage_ms']['wires commitment']:.1f}, quotient {e['prove']['stage_ms']['quotient polys']:.1f}) | 57.0 ms (29.3, 14.2) | `extra.prove`; the quotient: round 5's gate-kernel generator (§3.5); one function per gate, this round: {before['prove_ms']:.1f} ms ({before['stage_ms']['quotient polys']:.1f}) |
+| NTTs/s at 2^20 (64-column batch, forward + inverse, natural order, HBM-resident) | **{d['value']/1e3:.1f} k NTT/s** (six windows {d['value_windows']['min']/1e3:.1f}–{d['value_windows']['max']/1e3:.1f} k) | 131.9 k | `value`, `value_windows` |
+| forward batch transform | {r['ms']:.3f} ms → **{r['frac']:.3f}** of 8 TB/s; {r['frac_of_measured_copy']:.2f} of the copy rate measured in the run ({r['measured_copy_GBps']/1e3:.1f} TB/s) | 0.485 ms, 0.277 | `roofline`; algorithmic bytes 16 B × 2^20 × 64 = 1.074 GB per launch pair |
+| the two kernels under rocprofv3 (same command) | column pass {col:.1f} µs + row pass {row:.1f} µs = {col+row:.1f} µs | (builder's r05 device: 279.0 + 224.5) | `profiles/r06_ntt_kernel_stats.csv` |
+| HBM-side traffic (FETCH_SIZE × 2 + WRITE_SIZE) | {r['traffic']/1e9:.3f} GB = **{r['traffic_over_algorithmic']:.2f} ×** algorithmic (the second pass) | same | `roofline.traffic`, `profiles/r06_pmc_summary.json` |
+| vector-issue estimate (VALU instructions × 4 cycles ÷ SIMDs ÷ kernel cycles); waves parked at `s_waitcnt` / barrier | `int_alu_frac` {r['int_alu_frac']:.2f}; 0.39 in both passes; LDS bank conflicts 0 | 0.71 | `roofline.int_alu_frac`, `profiles/r06_pmc_summary.json` |
+| commit configs[2] (135 × 2^20, rate 8, cap 4, leaf-major copy included) | **{e['commit_ms']:.1f} ms** → **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, {e['commit_hbm_frac']:.3f} of the HBM roofline; without the leaf-major copy {e['commit_ms_without_leaf_major_copy']:.1f}; stages one at a time: iNTT {st['ifft (values -> coefficients)']:.1f} + LDE {st['coset LDE (bit-reversed)']:.1f} + hashing and tree {st['leaf hashing + tree layers']:.1f} | 61.3 ms, 137 M (from the tail's speed-up × baseline) | `extra.commit_*`, top-level `commit_ms`, `merkle_leaves_per_s`, `commit_hbm_frac`; hashing kernel: {hk['valu_insts_per_wavefront']:.0f} vector + {hk['matrix_insts_per_wavefront']:.0f} matrix instructions per wavefront at {hk['clock_GHz_during_kernel']:.2f} GHz, issue estimate {hk['valu_issue_estimate_frac_of_cycles']:.2f} |
+| full-width commits at north_star's trace sizes (135 columns; round 5, kernels unchanged; a device on which 2^20 takes 64.4 ms) | 2^21 133.8 ms, 2^22 280.8 ms, 2^23 574.1 ms = 125 / 119 / 117 M leaves/s, 0.020 / 0.019 / 0.019 (LDE 18 / 36 / 72 GB) | — | `profiles/r05_sweep.jsonl` |
+| `prove()` at the ed25519 shape (n = 2^18, 234 wires, whole gate table), one proof at a time | **{e['prove']['prove_ms']:.1f} ms** per proof = {1e3/e['prove']['prove_ms']:.1f} proofs/s (wires commitment {e['prove']['stage_ms']['wires commitment']:.1f}, quotient {e['prove']['stage_ms']['quotient polys']:.1f}) | 47.8 ms (from the tail) | top-level `prove_ms`, `extra.prove`; 47.0 ms on the faster devices of this round (`profiles/r06_bench_prove.json`), 48.9 before the device-resident transcript |
+| the same with **{fl['in_flight']} proofs in flight** (host threads × own context × own circuit handle) | **{fl['proofs_per_s']:.1f} proofs/s** = {fl['ms_per_proof']:.1f} ms per proof, {fl['proofs_per_s']*e['prove']['prove_ms']/1e3:.2f} × one at a time; every proof byte-equal to the one made alone | — (contexts took turns) | top-level `prove_proofs_per_s_in_flight`, `extra.prove_in_flight`; 23.4 (1.15 ×) with two, 24.0 (1.18 ×) with three on another device: `profiles/r06_inflight.json` |
+| a proof's timeline (kernel + copy trace of six proofs, `tools/prove_timeline.py`) | 235 launches and 14 small copies per proof, device idle 0.85 ms of 47.7 | — (round 5: 325 launches, 107 copies, 2.36 ms idle) | `profiles/r06_prove_timeline.txt`, `profiles/r06_prove_timeline_before.txt` |
 | `prove()` of the same shape at 2^19 / 2^20 rows | {pl['2^19 rows']['prove_ms']:.1f} ms / {pl['2^20 rows']['prove_ms']:.1f} ms (2^20: wires commitment {pl['2^20 rows']['stage_ms']['wires commitment']:.1f}, quotient {pl['2^20 rows']['stage_ms']['quotient polys']:.1f}) | — | `extra.prove_larger_traces`; byte-equal to the C prover at 2^18 and 2^20 (`tests/test_gpu_prove.py`) |
-| CPU baseline, NTT (C restatement of `fft_classic`) | {d['cpu_baseline']['value']:.0f} NTT/s on the 16 CPUs the container's quota grants (EPYC 9575F; round 4: 329 — the oracle is now built with `-fno-semantic-interposition`, which lets gcc inline the exported field functions as rustc does) | 329 | `cpu_baseline` |
-| CPU baseline, commit: configs[2] WHOLE | {e['commit_cpu_baseline']['ms']/1e3:.1f} s on 16 threads = {e['commit_cpu_baseline']['value']/1e3:.0f} k leaves/s → GPU {e['commit_speedup_vs_cpu_baseline']:.0f} × | (half the rows, projected 37.9 s) | `extra.commit_cpu_baseline` |
-| CPU baseline, prove: a REAL `prove()` of the bench's own circuit and witness (C restatement, `oracle/prove_oracle.c`) | {e['prove_cpu_baseline']['value']/1e3:.1f} s on 16 threads (wires commitment {e['prove_cpu_baseline']['stage_ms']['wires commitment']/1e3:.1f}, quotient {e['prove_cpu_baseline']['stage_ms']['quotient polys']/1e3:.1f}); bytes equal `gl_prove`'s → GPU {e['prove_speedup_vs_cpu_baseline']:.0f} × | (three commitments only, 20.5 s) | `extra.prove_cpu_baseline`; the reference's README: 45 s on its authors' 8 cores |
-| the reference's own kernels on the same MI355X (`oracle/_ref`, in a child process) | 64 × 2^20 fft + ifft {ref['ntt']['fft_ms']+ref['ntt']['ifft_ms']:.1f} ms = {ref['ntt']['NTT_per_s']/1e3:.2f} k NTT/s; commit {ref['commit']['commit_ms']:.0f} ms | 1.81 k; 1 259 ms | `extra.reference_gpu_kernels_on_this_mi355x` — a stated baseline, never the target |
+| CPU baseline, NTT (C restatement of `fft_classic`) | {d['cpu_baseline']['value']:.0f} NTT/s on the 16 CPUs the container's quota grants (EPYC 9575F) | 580 | `cpu_baseline` |
+| CPU baseline, commit: configs[2] WHOLE | {e['commit_cpu_baseline']['ms']/1e3:.1f} s on 16 threads = {e['commit_cpu_baseline']['value']/1e3:.0f} k leaves/s → GPU {e['commit_speedup_vs_cpu_baseline']:.0f} × | 31.5 s | `extra.commit_cpu_baseline`, `cpu_baseline.commit_ms` |
+| CPU baseline, prove: a REAL `prove()` of the bench's own circuit and witness (C restatement, `oracle/prove_oracle.c`) | {e['prove_cpu_baseline']['value']/1e3:.1f} s on 16 threads (wires commitment {e['prove_cpu_baseline']['stage_ms']['wires commitment']/1e3:.1f}, quotient {e['prove_cpu_baseline']['stage_ms']['quotient polys']/1e3:.1f}); bytes equal `gl_prove`'s → GPU {e['prove_speedup_vs_cpu_baseline']:.0f} × | 22.3 s | `extra.prove_cpu_baseline`, `cpu_baseline.prove_ms`; the reference's README: 45 s on its authors' 8 cores |
+| the reference's own kernels on the same MI355X (`oracle/_ref`, in a child process) | 64 × 2^20 fft + ifft {ref['ntt']['fft_ms']+ref['ntt']['ifft_ms']:.1f} ms = {ref['ntt']['NTT_per_s']/1e3:.2f} k NTT/s; commit {ref['commit']['commit_ms']:.0f} ms | 1.81 k; 1 261 ms | `extra.reference_gpu_kernels_on_this_mi355x` — a stated baseline, never the target |
 | host buffers (PCIe-inclusive, never `value`) | 64 × 2^20: H2D + D2H around the transform → 3.3 k NTT/s; a 468 MiB witness: 8.6 ms, hidden under the previous proof | — | `profiles/r04_pcie.json` |
 
 '''
     s = s[:a] + new + s[b:]
-    a = s.index("| 64 columns × 2^20, forward, natural order, one launch pair (`profiles/r05_bench.json`")
+    a = s.index("| 64 columns × 2^20, forward, natural order, one launch pair (`profiles/r0")
     b = s.index("**What bounds them.**")
-    s = s[:a] + f'''| 64 columns × 2^20, forward, natural order, one launch pair (`profiles/r05_bench.json`; §5 has the driver's figures and the other devices beside these) | value | source |
+    s = s[:a] + f'''| 64 columns × 2^20, forward, natural order, one launch pair (`profiles/r06_bench.json`; §5 has the driver's figures and the other devices beside these) | value | source |
 |---|---|---|
 | average duration of a launch pair = HIP events around the timed region on the launch stream ÷ the launch pairs in it | **{r['ms']:.3f} ms** | `roofline.ms` |
 | algorithmic bytes (SURVEY §8d) | 16 B × 2^20 × 64 = 1.074 GB | — |
-| achieved / fraction of 8 TB/s | {r['achieved']/1e3:.2f} TB/s = **{r['frac']:.3f}** (0.260–0.269 across the devices seen this round) | `roofline.frac` |
-| per kernel (rocprofv3 `--kernel-trace --stats`, the same steady-state command) | column pass {col:.1f} µs + row pass {row:.1f} µs = {col+row:.1f} µs under the profiler | `profiles/r05_ntt_kernel_stats.csv` |
-| HBM-side traffic (FETCH_SIZE×2 + WRITE_SIZE) | {r['traffic']/1e9:.3f} GB = **{r['traffic_over_algorithmic']:.2f} ×** algorithmic: exactly the second pass | `roofline.traffic`, `profiles/r05_pmc_summary.json` |
+| achieved / fraction of 8 TB/s | {r['achieved']/1e3:.2f} TB/s = **{r['frac']:.3f}** (0.261–0.277 across the devices seen in rounds 5 and 6; the kernels are those of round 4) | `roofline.frac` |
+| per kernel (rocprofv3 `--kernel-trace --stats`, the same steady-state command) | column pass {col:.1f} µs + row pass {row:.1f} µs = {col+row:.1f} µs under the profiler | `profiles/r06_ntt_kernel_stats.csv` |
+| HBM-side traffic (FETCH_SIZE×2 + WRITE_SIZE) | {r['traffic']/1e9:.3f} GB = **{r['traffic_over_algorithmic']:.2f} ×** algorithmic: exactly the second pass | `roofline.traffic`, `profiles/r06_pmc_summary.json` |
 | binding roof as a number: executed vector instructions × 4 cycles ÷ (1024 SIMDs × kernel cycles) | **{r['int_alu_frac']:.2f}** (column pass 28 215, row pass 22 639 instructions per wave) | `roofline.int_alu_frac` |
-| waves parked at `s_waitcnt` / barrier | 0.39 both passes; LDS bank conflicts 0 | `profiles/r05_pmc_summary.json` |
+| waves parked at `s_waitcnt` / barrier | 0.39 both passes; LDS bank conflicts 0 | `profiles/r06_pmc_summary.json` |
 
 ''' + s[b:]
     # the quotient figure of 3.5 follows the bench line's stage
@@ -82,24 +83,26 @@ end of round 4 (`BENCH_r04.json`) — the number on record; the NTT, LDE and has
     open(P("DESIGN.md"), "w").write(s)
 
     s = open(P("README.md")).read()
-    a = s.index("Round-5 numbers on one MI355X")
-    s = s[:a] + f'''Round-5 numbers on one MI355X (`profiles/r05_bench.json`, collected with its kernel statistics and counters in one call; `DESIGN.md`
-§5 has them beside the driver's figures of round 4 — devices of the pool differ by ±2.5 %: 124.0–128.0 k NTT/s, 61.9–65.2 ms for the
-commit across the devices seen this round): **{d['value']/1e3:.1f} k NTT/s** at 2^20 (64-column batches, forward + inverse, natural order;
+    a = s.index("Round-6 numbers on one MI355X") if "Round-6 numbers on one MI355X" in s else s.index("Round-5 numbers on one MI355X")
+    s = s[:a] + f'''Round-6 numbers on one MI355X (`profiles/r06_bench.json`, collected with its kernel statistics and counters in one call; `DESIGN.md`
+§5 has them beside the driver's figures of round 5 — devices of the pool differ by ±2.5 % and more: 124.5–131.9 k NTT/s, 61.3–65.3 ms for the
+commit across the devices seen in rounds 5 and 6): **{d['value']/1e3:.1f} k NTT/s** at 2^20 (64-column batches, forward + inverse, natural order;
 {r['ms']:.3f} ms per batch transform = **{r['frac']:.3f} of the 8 TB/s HBM specification**, HBM-side traffic 2.00 × the algorithmic bytes,
-vector-issue bound) through the direct passes of `csrc/ntt_direct.hip`; 2^22 forward in two passes (0.212 against 0.189 for three on the
-same device, `profiles/r05_ntt_sizes.jsonl`); `from_values` of 2^20 rows x 135 columns (rate 8, cap height 4) in **{e['commit_ms']:.1f} ms** =
+vector-issue bound) through the direct passes of `csrc/ntt_direct.hip`; 2^22 forward in two passes (0.213 against 0.19 for three,
+`profiles/r06_ntt_sizes.jsonl`); `from_values` of 2^20 rows x 135 columns (rate 8, cap height 4) in **{e['commit_ms']:.1f} ms** =
 **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, 81 % of it Poseidon leaf hashing with the MDS layers on the matrix cores (`csrc/poseidon.h`: an i8
 product per byte plane), and 117–125 M leaves/s at 2^21–2^23 rows of the same width; `prove()` at the ed25519 proof's shape (n = 2^18,
-234 wires, the whole 25-gate table) in **{e['prove']['prove_ms']:.1f} ms** through the native `gl_prove` ({pl['2^20 rows']['prove_ms']:.0f} ms at 2^20 rows), against
+234 wires, the whole 25-gate table) in **{e['prove']['prove_ms']:.1f} ms** through the native `gl_prove` ({pl['2^20 rows']['prove_ms']:.0f} ms at 2^20 rows) — its transcript
+lives on the device since round 6 (`gl_challenger_step`: 235 launches and 14 small copies per proof, 325 and 107 before) — and
+**{fl['proofs_per_s']:.1f} proofs/s with {fl['in_flight']} proofs in flight** on the one GPU (contexts on one device run concurrently since round 6; {1e3/e['prove']['prove_ms']:.1f} one at a time), against
 {e['prove_cpu_baseline']['value']/1e3:.1f} s for the C restatement of the same `prove()` on the box's 16 CPUs — same bytes. Its quotient polynomials take
-**{e['prove']['stage_ms']['quotient polys']:.1f} ms** (14.2 at the end of round 4): the run-time gate-kernel generator now fuses the gates that read the same wires and
+**{e['prove']['stage_ms']['quotient polys']:.1f} ms**: the run-time gate-kernel generator fuses the gates that read the same wires and
 computes every shared value once (`DESIGN.md` §3.5). On the same GPU the reference's own CUDA kernels, compiled unmodified for gfx950
 (`oracle/_ref`, test infrastructure: the second source of truth of the parity tests), take {ref['ntt']['fft_ms']+ref['ntt']['ifft_ms']:.1f} ms per 64-column forward + inverse pair
 (1.8 k NTT/s), {ref['commit']['commit_ms']:.0f} ms for the same commit and 312 ms for those quotient polynomials.
 '''
     open(P("README.md"), "w").write(s)
-    print("DESIGN.md and README.md follow profiles/r05_bench.json: %.1f k NTT/s, %.3f, commit %.1f ms, prove %.1f ms" % (
+    print("DESIGN.md and README.md follow profiles/r06_bench.json: %.1f k NTT/s, %.3f, commit %.1f ms, prove %.1f ms" % (
         d["value"] / 1e3, r["frac"], e["commit_ms"], e["prove"]["prove_ms"]))
 
 
