@@ -875,13 +875,15 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         return dispatch_pass<false>(log_n, p, grid, stream);
     }
 
-    if (log_n == 22 && natural && !inverse && two_pass_2p22()) {
+    if (log_n == 22 && natural && two_pass_2p22()) {
+        if (inverse && (dst_stride & (n - 1))) return hipErrorInvalidValue;
         // 2^22 = 2048 x 2048 in TWO passes, both the direct column pass with eight lane groups (tiles of 2048 rows x 8 columns,
         // 64-byte segments): pass A takes the columns L of the matrix [m][L] (stride 2048), applies w_n^(L k1) and stores its tile
         // TRANSPOSED into the workspace, mid[L * 2048 + k1]; pass B takes the columns k1 of that matrix [L][k1], has no twiddle left to
         // apply and writes X[k1 + 2048 k2] in natural order. HBM-side traffic 2 x the algorithmic bytes instead of the three-pass
         // plan's 3 x (round 4 priced this plan at the three-pass plan's time from memory-only measurements; round 5 measures it:
-        // profiles/r05_ntt_sizes.jsonl). Forward transforms only: the inverse's index flip lives in the row pass.
+        // profiles/r05_ntt_sizes.jsonl). The INVERSE (round 6) is the same plan on the index-reversed input, ifft(x) = fft(x') / n with
+        // x'[j] = x[(n - j) mod n]: pass A reads its columns backwards (ntt_direct.hip REVIN) and carries 1 / n on its twiddle chain.
         const uint64_t N1 = 2048, C = 8;
         if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
         const uint64_t chunk = tb.scratch_elems / n;
@@ -904,7 +906,9 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
             p.flags = F_NATURAL | F_WIDE | F_RAW_OUT;
             p.log_n = log_n;
             p.tw_hi = log_n;
-            hipError_t e = nttk::launch_col_direct(3, p, dim3((unsigned)(N1 / C), (unsigned)cnt, 1), stream);
+            p.chain_scale = n_inv;
+            hipError_t e = inverse ? nttk::launch_col_direct_reversed_input(p, dim3((unsigned)(N1 / C), (unsigned)cnt, 1), stream)
+                                   : nttk::launch_col_direct(3, p, dim3((unsigned)(N1 / C), (unsigned)cnt, 1), stream);
             if (e != hipSuccess) return e;
             base_params(p, tb);
             p.src = tb.scratch;

@@ -94,7 +94,15 @@ static_assert(ColGeom<3>::LDS_BYTES <= 160 * 1024 && ColGeom<2>::LDS_BYTES <= 16
 //                               for R = 256, which has no such twiddle, it is part of CU [z][w][i]),
 //   s^L                         rides on the start of the inter-pass twiddle chain (CS [z][c]; the workgroup keeps its column tile).
 // Sixteen + 16/G + 1 multiplications per lane and tile more than the plain pass; the tables are built once per workgroup.
-template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false>
+// REVIN (round 6: the first pass of the two-pass INVERSE transform of 2^22 points, 2048 x 2048): the pass reads x'[j] = x[(n - j) mod n]
+// instead of x[j] — ifft(x) = fft(x') / n (fft.rs:92-101 puts the same flip on the OUTPUT; on the input it is a load-address
+// matter and the stores stay aligned). With j = m in_m + L (row m, column L, in_m = the number of columns):
+//   L != 0:  x'[j] = x[(R - 1 - m) in_m + (in_m - L)]      L == 0:  x'[j] = x[((R - m) mod R) in_m]
+// A lane's sixteen rows m = (R/16) i + 16 g + w are then sixteen addresses DEcreasing by ld_step; the one element that wraps
+// (L = 0, m = 0 -> x[0]) is lane 0 of wave 0 of column tile 0, register 0. A tile's eight adjacent columns become a 64-byte
+// segment read backwards and misaligned by one element, which the L2 absorbs on the load side (the natural-order forward
+// plan's pass at 0.32 ms per 512 MiB runs 0.33 with it). 1 / n rides on the twiddle chain (chain_scale).
+template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false, bool REVIN = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_direct_kernel(const PassParams p, const uint32_t gx, const uint32_t gy, const uint32_t gz, const uint32_t per_b) {
     using GEO = ColGeom<LOGG>;
     constexpr int G = GEO::G, LOGC = GEO::LOGC, C = GEO::C, LOGR = GEO::LOGR;
@@ -191,6 +199,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto issue_loads = [&](uint32_t t) {
         uint32_t b, a, z;
         tile_of(DIRECT_LOAD_TILE(t), b, a, z);
+        if constexpr (REVIN) {
+            static_assert(!COSET && NATURAL, "the reversed-input pass is the first pass of a natural-order inverse transform");
+            const uint64_t *base = p.src + (a * p.in_sa + z * p.in_sz);
+            const uint32_t l = opaque_lane();
+            const uint32_t L = b * C + (l & (C - 1)), m0 = 16 * (l >> LOGC) + wave;
+            const uint32_t cols = (uint32_t)p.in_m;
+            // byte offset of register 0's element; the wrapping element keeps the VIRTUAL row R (one past the end) for the steps below
+            uint32_t off = L ? (((uint32_t)GEO::R - 1 - m0) * cols + (cols - L)) * 8 : (((uint32_t)GEO::R - m0) * cols) * 8;
+            const bool wraps = L == 0 && m0 == 0;
+            static_for<0, 16>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                if constexpr (i == 0) A[i] = g_ld<NT_LOAD_COL>(base, wraps ? 0u : off);
+                else A[i] = g_ld<NT_LOAD_COL>(base, off);
+                if constexpr (i < 15) off -= ld_step;
+            });
+            return;
+        }
         const uint64_t *base = p.src + (a * p.in_sa + b * p.in_sb + z * p.in_sz);
         uint32_t off = ld_off_of(opaque_lane());  // tile-invariant, like the sixteen offsets derived from it: left to itself the compiler keeps them all in registers
         static_for<0, 16>([&](auto I_) {
@@ -395,12 +420,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 }
 
-template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false>
+template <int LOGG, bool NATURAL, bool COSET = false, bool FINAL = false, bool REVIN = false>
 hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
     using GEO = ColGeom<LOGG>;
     const uint32_t lds_bytes = GEO::LDS_BYTES + (COSET ? GEO::coset_bytes(grid.z) : 0);
     static DynamicLds attr;
-    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL>), lds_bytes); e != hipSuccess) return e;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL, REVIN>), lds_bytes); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t pairs = (uint64_t)grid.y * grid.z, total = pairs * grid.x;
@@ -417,7 +442,7 @@ hipError_t launch_col_direct_t(const PassParams &p, dim3 grid, hipStream_t strea
         wgs = (uint32_t)cus;
     }
     if (COSET && per_b == 0) return hipErrorInvalidValue;   // col_direct_coset_ok() said otherwise
-    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL>), dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
+    hipLaunchKernelGGL((ntt_col_direct_kernel<LOGG, NATURAL, COSET, FINAL, REVIN>), dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)grid.x, (uint32_t)grid.y, (uint32_t)grid.z, per_b);
     return hipGetLastError();
 }
 
@@ -811,6 +836,12 @@ hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream
     }
 }
 
+
+// eight lane groups, natural order, the input read index-reversed (see the kernel): first pass of the inverse 2^22 two-pass plan
+hipError_t launch_col_direct_reversed_input(const PassParams &p, dim3 grid, hipStream_t stream) {
+    if (!(p.flags & F_NATURAL) || (p.flags & F_COSET) || p.in_t != 1 || p.in_m != (1u << 11) || p.in_sb != 8) return hipErrorInvalidValue;
+    return launch_col_direct_t<3, true, false, false, true>(p, grid, stream);
+}
 
 hipError_t launch_col_direct_final(const PassParams &p, dim3 grid, hipStream_t stream) {
     if (!(p.flags & F_NATURAL) || (p.flags & F_COSET)) return hipErrorInvalidValue;

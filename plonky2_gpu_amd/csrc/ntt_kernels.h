@@ -386,6 +386,7 @@ inline hipError_t allow_dynamic_lds(DynamicLds &st, const void *fn, uint32_t lds
 // Column pass of R = 2^(8 + logg) rows on tiles of 64 >> logg adjacent columns (the planner's F_WIDE geometry), logg = 0, 1, 2.
 hipError_t launch_col_direct(int logg, const PassParams &p, dim3 grid, hipStream_t stream);
 // The same pass as the LAST pass of a transform (F_FINAL_COL; logg = 3, natural order only): no twiddle chain, outputs canonical.
+hipError_t launch_col_direct_reversed_input(const PassParams &p, dim3 grid, hipStream_t stream);
 hipError_t launch_col_direct_final(const PassParams &p, dim3 grid, hipStream_t stream);
 // F_COSET passes (first pass of the coset LDE): only when this says so
 bool col_direct_coset_ok(int logg, dim3 grid);

@@ -148,7 +148,10 @@ def test_two_pass_plan_for_2e22_over_several_workspace_chunks_and_against_the_th
     """2^22 natural-order forward transforms run as 2048 x 2048 in two passes through the workspace (round 5, csrc/ntt.hip): eighteen
     columns = more than the sixteen the 512 MiB workspace holds at once (two chunks), non-canonical inputs in one column; four of them
     (first, the two either side of the chunk boundary, last) against the C oracle, ALL of them against the three-pass plan of the
-    diagnostic build (PLONKY2_NTT_TWO_PASS_22=0, a child process), and the inverse (still three passes) brings every column back."""
+    diagnostic build (PLONKY2_NTT_TWO_PASS_22=0, a child process). Round 6: the INVERSE takes the same two passes on the index-reversed
+    input (csrc/ntt_direct.hip REVIN: the column pass reads x[(n - j) mod n]; the element that wraps, x[0], is one lane's special case,
+    per polynomial and per workspace chunk): it brings every column back and equals the three-pass inverse of the diagnostic build on
+    input that is NOT a transform of anything (the raw columns x)."""
     import os
     import subprocess
     import sys
@@ -166,6 +169,7 @@ def test_two_pass_plan_for_2e22_over_several_workspace_chunks_and_against_the_th
     for k, c in enumerate(watch):
         assert (f[c] == exp[k]).all(), c
     assert (pg.ifft_with_options(gpu, f) == oracle.canon(x)).all()
+    inv = pg.ifft_with_options(gpu, x)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
         np.save(os.path.join(tmp, "x.npy"), x)
@@ -175,11 +179,13 @@ sys.path.insert(0, {root!r})
 import plonky2_gpu_amd as pg
 ctx = pg.Context(0)
 np.save({os.path.join(tmp, 'f.npy')!r}, pg.fft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r})))
+np.save({os.path.join(tmp, 'i.npy')!r}, pg.ifft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r})))
 """
         env = dict(os.environ, PLONKY2_NTT_TWO_PASS_22="0", PLONKY2_HIP_LIBRARY=os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert (np.load(os.path.join(tmp, "f.npy")) == f).all(), "the two-pass and the three-pass plan disagree"
+        assert (np.load(os.path.join(tmp, "i.npy")) == inv).all(), "the two-pass and the three-pass INVERSE disagree"
 
 
 def test_ntt_batch_with_more_than_2e32_elements(gpu, oracle):
