@@ -172,6 +172,7 @@ SIGNATURES = {
     "gl_circuit_trim": (GlError, [_vp]),
     "gl_circuit_info": (GlError, [_vp, _vp, _vp]),
     "gl_prove": (GlError, [_vp, _vp, _vp, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
+    "gl_prove_many": (GlError, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32]),
     "gl_prove_zk": (GlError, [_vp, _vp, _vp, _u32, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_u64), _vp, _vp]),
     "gl_bytes_free": (None, [_vp]),
     "gl_compute_quotient_polys": (GlError, [ctypes.POINTER(GlQuotientArgs), _vp, _vp]),

