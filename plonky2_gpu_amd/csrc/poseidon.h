@@ -82,6 +82,9 @@ __device__ __forceinline__ void require_full_wave() {
     if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
 }
 
+#ifdef POSEIDON_MDS_LAYER
+#include POSEIDON_MDS_LAYER  // an experiment's mds_layer in place of the one below (tools/experiments/mds_interleave.h)
+#else
 // MDS layer + the additive constants of whatever follows, xy = [12][X, Y] (poseidon_limb_constants.h).
 __device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const MdsOperands &ops, const uint32_t *__restrict__ xy) {
     v4i32 T[8];  // T[b] = byte b of words 0-3 | 4-7 | 8-11 | (never written: meets zero columns of A)
@@ -133,6 +136,7 @@ __device__ __forceinline__ void mds_layer(uint64_t (&s)[W], const MdsOperands &o
     for (int r = 0; r < W; r++) s[r] = gl::fold96(al[r], ah[r]);  // al + ah 2^32 mod p; al < 2^41 + X 2^32, ah < 2^41 + Y 2^32: X, Y leave the room
 }
 
+#endif  // POSEIDON_MDS_LAYER
 #endif  // POSEIDON_MDS_NATURAL
 
 // s-box layer + MDS layer; the round's own constants were added by the previous layer
