@@ -95,7 +95,7 @@ def test_the_committed_bench_line_agrees_with_itself_and_with_the_committed_kern
     tools/gpu_runs/r05_pmc_and_bench.sh). Until the end of round 4 the roofline used per-pair events and read 3-6 % above the other two."""
     import csv
     for tag, col_name in (("r04", "ntt_col_direct_kernel<2, true, false>"), ("r05", "ntt_col_direct_kernel<2, true, false, false>"),
-                          ("r06", "ntt_col_direct_kernel<2, true, false, false>")):
+                          ("r06", "ntt_col_direct_kernel<2, true, false, false, false>")):
         line = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench.json")).read())
         r = line["roofline"]
         assert "timed region" in r["ms_definition"]

@@ -24,7 +24,7 @@ def main():
     r, e = d["roofline"], d["extra"]
     col = row = None
     for k in csv.DictReader(open(P("profiles", "r06_ntt_kernel_stats.csv"))):
-        if "ntt_col_direct_kernel<2, true, false, false>(" in k["Name"]:
+        if "ntt_col_direct_kernel<2, true, false, false, false>(" in k["Name"]:
             col = float(k["AverageNs"]) / 1e3
         if "ntt_row_natural_direct_kernel<false>" in k["Name"]:
             row = float(k["AverageNs"]) / 1e3
@@ -38,8 +38,8 @@ def main():
 
 One table. The first column of values is `profiles/r06_bench.json` — ONE device, ONE `gpurun` call that also collected the kernel
 statistics and counters the line quotes (`tools/gpu_runs/r06_pmc_and_bench.sh`; `tests/test_bench_guard.py` ties this table to that
-file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 % and more (this call's device clocked 2.03 GHz under the
-hashing kernel where round 5's clocked 2.08); the other call of this round, NTT/s / commit / prove: {"; ".join(other_devices())} —
+file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 % and more (this call's device clocked {hk['clock_GHz_during_kernel']:.2f} GHz under the
+hashing kernel; one seen earlier in the round 2.03: 124.5 k NTT/s, 65.3 ms, 48.0 ms); the other call of this round, NTT/s / commit / prove: {"; ".join(other_devices())} —
 `profiles/r06_bench_first.json`. The second column is what the DRIVER measured at the end of round 5 (`BENCH_r05.json`) — the number on
 record; the NTT, LDE, hashing and gate kernels are unchanged since, what happens between them is not (§3.6, §4.1).
 
