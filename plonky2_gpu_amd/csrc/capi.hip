@@ -80,7 +80,7 @@ struct CtxState {
     bool have_pih = false;                 // gl_reference_set_public_inputs_hash_ctx
     uint64_t pih[4] = {0, 0, 0, 0};
 };
-std::map<hipStream_t, CtxState *> g_ctx;  // g_mu
+std::map<std::pair<int, hipStream_t>, CtxState *> g_ctx;  // g_mu; keyed by (device, first stream): the null stream exists on every device
 
 hipError_t device_tables(int dev, const NttTables **out) {  // g_mu held
     DeviceState &st = g_dev[dev & 63];
@@ -114,12 +114,7 @@ hipError_t ctx_state(void *ctx, CtxState **out) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_ctx.find(S(ctx)->stream);
-    if (it != g_ctx.end() && it->second->dev != dev) {  // a stream handle of a context that was never released, reused on another device
-        ctx_state_free(it->second);
-        g_ctx.erase(it);
-        it = g_ctx.end();
-    }
+    auto it = g_ctx.find({dev, S(ctx)->stream});
     if (it == g_ctx.end()) {
         const NttTables *dt;
         e = device_tables(dev, &dt);
@@ -134,7 +129,7 @@ hipError_t ctx_state(void *ctx, CtxState **out) {
             return e;
         }
         c->scratch_owned = true;
-        it = g_ctx.emplace(S(ctx)->stream, c).first;
+        it = g_ctx.emplace(std::make_pair(dev, S(ctx)->stream), c).first;
     }
     *out = it->second;
     return hipSuccess;
@@ -143,9 +138,11 @@ hipError_t ctx_state(void *ctx, CtxState **out) {
 void ctx_state_release(void *ctx) {
     if (!ctx) return;
     CtxState *c = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;  // gl_ctx_release has made the context's device current
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_ctx.find(S(ctx)->stream);
+        auto it = g_ctx.find({dev, S(ctx)->stream});
         if (it == g_ctx.end()) return;
         c = it->second;
         g_ctx.erase(it);
