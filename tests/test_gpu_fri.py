@@ -296,3 +296,44 @@ def test_fold_open_and_proof_of_work_read_the_transcript_from_device_memory(gpu)
     assert _step(pg, gpu, d_ch, [(d_w, 1, 0)], 1) == [resp]
     for b in (d_c, d_b, d_o1, d_o2, d_rows, d_dig, d_cap, d_raw, d_ol, d_os, d_ch, d_obs, d_w):
         b.free()
+
+
+@pytest.mark.gpu
+def test_device_transcript_entry_points_refuse_bad_arguments(gpu):
+    """The round-6 entry points return GL_E_INVALID (a message, no launch) for null pointers, more than eight sources, a planar source
+    longer than its two planes, unknown flags, a tree shape that is not a power of two, a shift that does not fit."""
+    import ctypes
+
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    from plonky2_gpu_amd import _lib
+
+    d = pg.DeviceBuffer(gpu, 64)
+    src = (_lib.GlObserveSrc * 9)(*[_lib.GlObserveSrc(d.ptr, 1, 0) for _ in range(9)])
+    bad = [
+        ("gl_challenger_step", None, ctypes.addressof(src), 1, 0, None, 1, gpu.ptr),                 # no challenger
+        ("gl_challenger_step", d.ptr, ctypes.addressof(src), 9, 0, None, 1, gpu.ptr),                # nine sources
+        ("gl_challenger_step", d.ptr, ctypes.addressof(src), 1, 2, None, 1, gpu.ptr),                # challenges but no output
+        ("gl_challenger_step", d.ptr, ctypes.addressof(src), 1, 0, d.ptr, 4, gpu.ptr),               # unknown flag
+        ("gl_challenger_step", d.ptr, None, 1, 0, None, 1, gpu.ptr),                                 # sources announced, none given
+        ("gl_fri_fold_device", d.ptr, 16, 2, None, d.ptr, gpu.ptr),
+        ("gl_fri_fold_device", d.ptr, 16, 0, d.ptr, d.ptr, gpu.ptr),                                 # arity 0
+        ("gl_fri_proof_of_work_device", d.ptr, 12, None, ctypes.addressof(ctypes.c_uint64()), gpu.ptr),
+        ("gl_fri_proof_of_work_device", d.ptr, 41, d.ptr, ctypes.addressof(ctypes.c_uint64()), gpu.ptr),
+        ("gl_merkle_open_batch_device", d.ptr, 4, 1, 4, 12, 2, d.ptr, d.ptr, 1, 0, d.ptr, d.ptr, gpu.ptr),   # 12 leaves
+        ("gl_merkle_open_batch_device", d.ptr, 4, 1, 4, 16, 2, d.ptr, d.ptr, 1, 33, d.ptr, d.ptr, gpu.ptr),  # shift too large
+        ("gl_merkle_open_batch_device", d.ptr, 4, 1, 4, 16, 2, d.ptr, None, 1, 0, d.ptr, d.ptr, gpu.ptr),    # no indices
+    ]
+    planar = (_lib.GlObserveSrc * 1)(_lib.GlObserveSrc(d.ptr, 9, 4))  # 9 elements of a [2][4] vector
+    bad.append(("gl_challenger_step", d.ptr, ctypes.addressof(planar), 1, 0, None, 1, gpu.ptr))
+    for call in bad:
+        with pytest.raises(_lib.Plonky2HipError) as e:
+            _lib.call(*call)
+        assert e.value.code == _lib.GL_E_INVALID, call[0]
+    # and the zero-work forms are accepted: no sources, no challenges; zero queries
+    _lib.call("gl_challenger_step", d.ptr, None, 0, 0, None, 1, gpu.ptr)
+    _lib.call("gl_merkle_open_batch_device", d.ptr, 4, 1, 4, 16, 2, d.ptr, d.ptr, 0, 0, d.ptr, d.ptr, gpu.ptr)
+    gpu.synchronize()
+    assert not d.download()[:12].any() and int(d.download()[28]) == 0   # the reset left an empty transcript
+    d.free()
