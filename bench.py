@@ -665,7 +665,11 @@ def main():
             extra["prove"] = pr
 
     if not args.no_prove and args.prove_in_flight > 1:
-        fl = bench_prove_in_flight(pg, ctx.device, dist, args.prove_degree_bits, args.prove_wires, args.prove_in_flight, max(4, 2 * args.prove_reps))
+        if dist.world == 1:  # one rank: a failure of this leg (device memory, a second context) costs the leg, not the line
+            fl = guarded_leg("prove_in_flight", lambda: bench_prove_in_flight(pg, ctx.device, dist, args.prove_degree_bits, args.prove_wires, args.prove_in_flight,
+                                                                               max(4, 2 * args.prove_reps)))
+        else:               # several ranks meet at barriers inside the leg: an exception must end the job, not strand the others
+            fl = bench_prove_in_flight(pg, ctx.device, dist, args.prove_degree_bits, args.prove_wires, args.prove_in_flight, max(4, 2 * args.prove_reps))
         if dist.rank == 0:
             extra["prove_in_flight"] = fl
 
