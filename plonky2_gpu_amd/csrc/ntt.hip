@@ -931,13 +931,12 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         return hipSuccess;
     }
 
-    // Diagnostic build only (PLONKY2_NTT_TWO_PASS_22_INPLACE=1): 2^22 bit-reversed as 2048 x 2048 in two passes IN PLACE with the kernels
-    // that exist — the eight-lane-group column pass, then the round-1 kernel over 2048-point rows (no direct in-place row pass exists
-    // for rows of that length). Measured in round 6 (profiles/r06_ntt_sizes.jsonl) to say what item 4 of VERDICT r5 is worth
-    // before a new row kernel is written.
-    static const bool two_pass_22_inplace = [] {
+    // 2^22 bit-reversed as 2048 x 2048 in two passes IN PLACE (round 6): the eight-lane-group column pass, then the in-place row pass
+    // over 2048-point rows with two waves per row (ntt_direct.hip, HALVES). PLONKY2_NTT_TWO_PASS_22_INPLACE=0 in the diagnostic build
+    // restores the three-pass plan, =generic takes the round-1 kernel for the rows (the first measurement of this plan: slower).
+    static const int two_pass_22_inplace = [] {
         const char *e = PLONKY2_KNOB("PLONKY2_NTT_TWO_PASS_22_INPLACE");
-        return e && e[0] == '1';
+        return !direct_mode() ? 0 : (e && e[0] == '0') ? 0 : (e && e[0] == 'g') ? 2 : 1;
     }();
     if (log_n <= 20 || (log_n == 21 && wide_ok(11, 1024)) || (log_n == 22 && !natural && two_pass_22_inplace && wide_ok(11, 2048))) {
         // two passes: n = N1 * N2, N1 = 2^la (strided "column" pass), N2 = 2^lb (row pass); 2^21 = 2048 x 1024 with the
@@ -1015,7 +1014,10 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
                 p.out_m = 1;
                 p.flags = F_LOAD_ROWS | F_STORE_ROWS;
             }
-            e = dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);
+            if (log_n == 22 && !natural && two_pass_22_inplace == 1)
+                e = nttk::launch_row_inplace_direct_2048(p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);
+            else
+                e = dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;

@@ -658,12 +658,24 @@ struct RowInplaceGeom {
     static constexpr uint32_t WBUF_BYTES = 1084 * 8;   // per wave
     static constexpr uint32_t XBYTES = 16 * WBUF_BYTES;
     static constexpr uint32_t LDS_BYTES = XBYTES + RowGeom::TW1_BYTES + RowGeom::TW2_BYTES;
+    // HALVES (rows of 2048 points): [lane][i] = w_2048^(lane + 64 i), the twiddles of the radix-2 stage that is formed on load
+    static constexpr uint32_t TW0_STRIDE = 136, TW0_BYTES = 64 * TW0_STRIDE;
+    static constexpr uint32_t LDS_BYTES_HALVES = LDS_BYTES + TW0_BYTES;
 };
+static_assert(RowInplaceGeom::LDS_BYTES_HALVES <= 160 * 1024, "the wave buffers and the three twiddle tables must fit the 160 KiB of LDS");
 
+// HALVES (round 6): rows of 2048 points, two waves per row. A 2048-point DIF transform is one radix-2 stage — x_j + x_(j+1024) feeds the
+// even frequencies, (x_j - x_(j+1024)) w_2048^j the odd ones — followed by two independent 1024-point transforms whose bit-reversed
+// outputs are the two halves of the row: frequency k = 2 k' + h sits at position h 1024 + bitrev10(k'). Unit u = (row, h): the wave
+// loads BOTH halves of the row (its partner wave, the next unit, reads the same 16 KiB a moment later: L2), forms its half's input of
+// the 1024-point pipeline below on the way in, and stores into its half. One general multiplication per element of the odd half
+// (table TW0); the even half costs an addition.
+template <bool HALVES>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_row_inplace_direct_kernel(const PassParams p, const uint32_t rows_total, const uint32_t rows_per_poly, const uint32_t gy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char *TW1 = ldsb + RowInplaceGeom::XBYTES;
     unsigned char *TW2 = TW1 + RowGeom::TW1_BYTES;
+    unsigned char *TW0 = TW2 + RowGeom::TW2_BYTES;   // HALVES only
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char *X = ldsb + wave * RowInplaceGeom::WBUF_BYTES;   // this wave's buffer
@@ -671,20 +683,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     for (uint32_t e = tid; e < 64 * 16; e += 1024) {
         const uint32_t l = e >> 4, ka = e & 15;
         *reinterpret_cast<uint64_t *>(TW1 + l * RowGeom::TW1_STRIDE + ka * 8) = p.twh[(ka * l) << 2];
+        if constexpr (HALVES) *reinterpret_cast<uint64_t *>(TW0 + l * RowInplaceGeom::TW0_STRIDE + ka * 8) = p.twh[(l + 64 * ka) << 1];   // ka plays i here
     }
     if (tid < 64) {
         const uint32_t q = tid >> 4, kb = tid & 15;
         *reinterpret_cast<uint64_t *>(TW2 + q * RowGeom::TW2_STRIDE + kb * 8) = p.twh[(kb * q) << 6];
     }
 
-    // which rows this wave walks: row u of the launch = (z, a, row inside the polynomial), row fastest
+    // which rows this wave walks: row u of the launch = (z, a, row inside the polynomial), row fastest; HALVES: rows_total counts
+    // UNITS (row, half), half fastest — W is even, so a wave keeps its half
     const uint32_t W = gridDim.x * 16;
     const uint32_t u0 = blockIdx.x * 16 + wave;
     const uint32_t n_rows = u0 < rows_total ? (rows_total - u0 + W - 1) / W : 0;
+    const uint32_t half = HALVES ? (u0 & 1) : 0;
     auto row_ptr = [&](uint32_t k, bool out) -> uint64_t {
-        const uint32_t u = u0 + k * W;
+        const uint32_t uu = u0 + k * W, u = HALVES ? uu >> 1 : uu;
         const uint32_t row = u % rows_per_poly, r2 = u / rows_per_poly, a = r2 % gy, z = r2 / gy;
-        return out ? a * p.out_sa + z * p.out_sz + (uint64_t)row * p.out_t : a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t;
+        return out ? a * p.out_sa + z * p.out_sz + (uint64_t)row * p.out_t + (HALVES ? half * 1024u : 0u) : a * p.in_sa + z * p.in_sz + (uint64_t)row * p.in_t;
     };
 
     const uint32_t q = lane & 3, hi4 = lane >> 2;
@@ -699,6 +714,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     };
 
     uint64_t A[16], B[16];
+    // HALVES: the other half of the row, x_(j + 1024), arrives in B (free between the last exchange write of a unit and the next first round)
     auto issue_loads = [&](uint32_t k) {
         const uint64_t *base = p.src + row_ptr(k, false);
         const uint32_t off = opaque_lane() * 8;
@@ -707,8 +723,34 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             A[i] = g_ld(base, off + i * 512);
         });
     };
+    // HALVES: the other half of the row of unit k. Issued LATE — behind the last use of B of the unit before it — so that A2 can live in
+    // the registers B has just left (A + A2 + B at once do not fit 128 registers); the stores of that unit travel in front of first_round
+    auto issue_loads_other_half = [&](uint32_t k) {
+        if constexpr (HALVES) {
+            const uint64_t *base = p.src + row_ptr(k, false);
+            const uint32_t off = opaque_lane() * 8 + 8192;
+            static_for<0, 16>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                B[i] = g_ld(base, off + i * 512);
+            });
+        }
+    };
     // radix 16 over i on A, twiddle, E1 write
     auto first_round = [&]() {
+        if constexpr (HALVES) {   // the radix-2 stage of the 2048-point row: this wave's half of its outputs
+            if (half == 0) {
+                static_for<0, 16>([&](auto I_) { constexpr int i = decltype(I_)::value; A[i] = gl::add(A[i], B[i]); });
+            } else {
+                // eight elements at a time, fenced: left to itself the scheduler reads all sixteen twiddles ahead (32 more registers)
+                static_for<0, 2>([&](auto G_) {
+                    constexpr int g0 = 8 * decltype(G_)::value;
+                    const uint32_t tw0_base = opaque_lane() * RowInplaceGeom::TW0_STRIDE;
+                    static_for<g0, g0 + 8>([&](auto I_) { constexpr int i = decltype(I_)::value; A[i] = gl::sub(A[i], B[i]); });
+                    mul_run<g0, g0 + 8>(A, [](auto I_) { return decltype(I_)::value; }, [&](auto I_) { return lds_ld(TW0, tw0_base + decltype(I_)::value * 8); }, [](auto) {});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        }
         radix_dif<4, 0>(A);
         mul_run<1, 16>(A, [](auto S_) { return decltype(S_)::value; }, [&](auto S_) { return lds_ld(TW1, tw1_base + brev_c(decltype(S_)::value, 4) * 8); }, [](auto) {});
         static_for<0, 16>([&](auto S_) {
@@ -719,7 +761,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         tile_sync<64>();
     };
     // everything after E1 of the row whose first round is in the buffer, up to its stores
-    auto rest_of_row = [&](uint32_t k) {
+    auto rest_of_row = [&](uint32_t k, bool more) {
         static_for<0, 16>([&](auto H_) {
             constexpr int h = decltype(H_)::value;
             B[h] = lds_ld(X, e1r + h * 544);
@@ -768,16 +810,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             });
         }
         tile_sync<64>();
+        __builtin_amdgcn_sched_barrier(0);   // behind the unit's stores: only the prefetched A is live here
+        if (more) issue_loads_other_half(k + 1);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     lds_barrier();  // tables
     if (n_rows == 0) return;
     issue_loads(0);
+    issue_loads_other_half(0);
     first_round();
     if (n_rows > 1) issue_loads(1);
 #pragma unroll 1
     for (uint32_t k = 0; k < n_rows; k++) {
-        rest_of_row(k);
+        rest_of_row(k, k + 1 < n_rows);
         if (k + 1 < n_rows) {
             first_round();
             if (k + 2 < n_rows) issue_loads(k + 2);
@@ -785,17 +831,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
 }
 
+template <bool HALVES = false>
 hipError_t launch_row_inplace_direct_t(const PassParams &p, dim3 grid, hipStream_t stream) {
+    constexpr uint32_t lds_bytes = HALVES ? RowInplaceGeom::LDS_BYTES_HALVES : RowInplaceGeom::LDS_BYTES;
     static DynamicLds attr;
-    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_row_inplace_direct_kernel), RowInplaceGeom::LDS_BYTES); e != hipSuccess) return e;
+    if (hipError_t e = allow_dynamic_lds(attr, reinterpret_cast<const void *>(&ntt_row_inplace_direct_kernel<HALVES>), lds_bytes); e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint64_t rows_total = (uint64_t)p.t_limit * grid.y * grid.z;
+    const uint64_t rows_total = (uint64_t)p.t_limit * grid.y * grid.z * (HALVES ? 2 : 1);
     if (rows_total == 0) return hipSuccess;
     if (rows_total > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const uint64_t need = (rows_total + 15) / 16;
     const uint32_t wgs = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
-    hipLaunchKernelGGL(ntt_row_inplace_direct_kernel, dim3(wgs), dim3(1024), RowInplaceGeom::LDS_BYTES, stream, p, (uint32_t)rows_total, p.t_limit, (uint32_t)grid.y);
+    hipLaunchKernelGGL(ntt_row_inplace_direct_kernel<HALVES>, dim3(wgs), dim3(1024), lds_bytes, stream, p, (uint32_t)rows_total, p.t_limit, (uint32_t)grid.y);
     return hipGetLastError();
 }
 
@@ -848,7 +896,9 @@ hipError_t launch_col_direct_final(const PassParams &p, dim3 grid, hipStream_t s
     return launch_col_direct_t<3, true, false, true>(p, grid, stream);
 }
 
-hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream) { return launch_row_inplace_direct_t(p, grid, stream); }
+hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream) { return launch_row_inplace_direct_t<false>(p, grid, stream); }
+// rows of 2048 points in place, two waves per row (the kernel's HALVES form)
+hipError_t launch_row_inplace_direct_2048(const PassParams &p, dim3 grid, hipStream_t stream) { return launch_row_inplace_direct_t<true>(p, grid, stream); }
 
 hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t stream) {
     return (p.flags & F_INVERSE) ? launch_row_natural_direct_t<true>(p, grid, stream) : launch_row_natural_direct_t<false>(p, grid, stream);

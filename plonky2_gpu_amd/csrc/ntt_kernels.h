@@ -396,6 +396,7 @@ hipError_t launch_row_natural_direct(const PassParams &p, dim3 grid, hipStream_t
 // Row pass of 1024-point rows IN PLACE (bit-reversed output), any tile geometry of the planner: the rows are
 // src + a * in_sa + z * in_sz + row * in_t for row < t_limit, a < grid.y, z < grid.z (in_m == 1), written to the same place in dst.
 hipError_t launch_row_inplace_direct(const PassParams &p, dim3 grid, hipStream_t stream);
+hipError_t launch_row_inplace_direct_2048(const PassParams &p, dim3 grid, hipStream_t stream);
 
 }  // namespace nttk
 }  // namespace plonky2_hip

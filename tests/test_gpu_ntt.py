@@ -130,8 +130,10 @@ def test_full_size_round_trip_and_linearity(gpu, oracle):
 
 @pytest.mark.parametrize("log_n", [21, 22, 23, 24])
 def test_ntt_three_pass_sizes(gpu, oracle, log_n):
-    """2^21 (two passes, 2048-point direct column pass) and 2^22..2^24 (the three-pass plan; 2^24 is the largest size
-    gl_ntt_batch accepts): oracle equality on both columns, round trip, and the bit-reversed variant on the second one."""
+    """2^21 (two passes, 2048-point direct column pass), 2^22 (two passes in every order since round 6: natural forward, the inverse on
+    the index-reversed input, bit-reversed in place with the two-waves-per-row kernel for 2048-point rows) and 2^23..2^24 (the
+    three-pass plan; 2^24 is the largest size gl_ntt_batch accepts): oracle equality on both columns, round trip, and the bit-reversed
+    variant on the second one."""
     import plonky2_gpu_amd as pg
 
     n = 1 << log_n
@@ -170,6 +172,8 @@ def test_two_pass_plan_for_2e22_over_several_workspace_chunks_and_against_the_th
         assert (f[c] == exp[k]).all(), c
     assert (pg.ifft_with_options(gpu, f) == oracle.canon(x)).all()
     inv = pg.ifft_with_options(gpu, x)
+    brev = pg.fft_with_options(gpu, x, bit_reversed=True)   # two passes in place: column pass + the two-waves-per-row kernel
+    assert (brev[17] == f[17][bitrev_perm(log_n)]).all()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as tmp:
         np.save(os.path.join(tmp, "x.npy"), x)
@@ -180,12 +184,14 @@ import plonky2_gpu_amd as pg
 ctx = pg.Context(0)
 np.save({os.path.join(tmp, 'f.npy')!r}, pg.fft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r})))
 np.save({os.path.join(tmp, 'i.npy')!r}, pg.ifft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r})))
+np.save({os.path.join(tmp, 'b.npy')!r}, pg.fft_with_options(ctx, np.load({os.path.join(tmp, 'x.npy')!r}), bit_reversed=True))
 """
-        env = dict(os.environ, PLONKY2_NTT_TWO_PASS_22="0", PLONKY2_HIP_LIBRARY=os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))
+        env = dict(os.environ, PLONKY2_NTT_TWO_PASS_22="0", PLONKY2_NTT_TWO_PASS_22_INPLACE="0", PLONKY2_HIP_LIBRARY=os.path.join(root, "plonky2_gpu_amd", "libplonky2_hip_debug.so"))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert (np.load(os.path.join(tmp, "f.npy")) == f).all(), "the two-pass and the three-pass plan disagree"
         assert (np.load(os.path.join(tmp, "i.npy")) == inv).all(), "the two-pass and the three-pass INVERSE disagree"
+        assert (np.load(os.path.join(tmp, "b.npy")) == brev).all(), "the two-pass and the three-pass BIT-REVERSED transform disagree"
 
 
 def test_ntt_batch_with_more_than_2e32_elements(gpu, oracle):
