@@ -956,8 +956,13 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         // Natural order: pass B writes its tile transposed (k1 + N1*k2), i.e. into rows that other
         // workgroups still have to read, so the intermediate goes through the scratch workspace,
         // a chunk of columns at a time (the chunk's intermediate stays in L2 / Infinity Cache).
+        // The two-waves-per-row pass over 2048-point rows (2^22 bit-reversed) is NOT in place either: a row's two waves each read the
+        // whole row and each write half of it, with nothing ordering one wave's stores behind the other's loads — its input is the
+        // workspace, like the natural-order plans' (found by the 18-column test of round 6: one column passed by timing alone).
+        const bool halves_rows = log_n == 22 && !natural && two_pass_22_inplace == 1;
+        const bool via_workspace = natural || halves_rows;
         uint64_t chunk = 65535;
-        if (natural) {
+        if (via_workspace) {
             if (!tb.scratch || tb.scratch_elems < n) return hipErrorInvalidValue;
             chunk = tb.scratch_elems / n;
             if (chunk > 65535) chunk = 65535;
@@ -968,8 +973,8 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
         }
         for (uint64_t off = 0; off < n_polys; off += chunk) {
             const uint64_t cnt = n_polys - off < chunk ? n_polys - off : chunk;
-            uint64_t *mid = natural ? tb.scratch : dst + off * dst_stride;
-            const uint64_t mid_stride = natural ? n : dst_stride;
+            uint64_t *mid = via_workspace ? tb.scratch : dst + off * dst_stride;
+            const uint64_t mid_stride = via_workspace ? n : dst_stride;
             // pass A
             base_params(p, tb);
             p.src = src + off * src_stride;
@@ -1014,7 +1019,7 @@ hipError_t ntt_batch(const NttTables &tb, const uint64_t *src, uint64_t *dst, ui
                 p.out_m = 1;
                 p.flags = F_LOAD_ROWS | F_STORE_ROWS;
             }
-            if (log_n == 22 && !natural && two_pass_22_inplace == 1)
+            if (halves_rows)
                 e = nttk::launch_row_inplace_direct_2048(p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);
             else
                 e = dispatch_pass<false>(lb, p, dim3((unsigned)(N1 / TB), (unsigned)cnt, 1), stream);

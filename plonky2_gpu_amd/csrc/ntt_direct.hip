@@ -669,7 +669,8 @@ static_assert(RowInplaceGeom::LDS_BYTES_HALVES <= 160 * 1024, "the wave buffers 
 // outputs are the two halves of the row: frequency k = 2 k' + h sits at position h 1024 + bitrev10(k'). Unit u = (row, h): the wave
 // loads BOTH halves of the row (its partner wave, the next unit, reads the same 16 KiB a moment later: L2), forms its half's input of
 // the 1024-point pipeline below on the way in, and stores into its half. One general multiplication per element of the odd half
-// (table TW0); the even half costs an addition.
+// (table TW0); the even half costs an addition. NOT in place: nothing orders one wave's stores behind its partner's loads of the same
+// row, so the planner gives this form a source (the workspace) that is not its destination.
 template <bool HALVES>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_row_inplace_direct_kernel(const PassParams p, const uint32_t rows_total, const uint32_t rows_per_poly, const uint32_t gy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];

@@ -89,7 +89,7 @@ record; the NTT, LDE, hashing and gate kernels are unchanged since, what happens
 commit across the devices seen in rounds 5 and 6): **{d['value']/1e3:.1f} k NTT/s** at 2^20 (64-column batches, forward + inverse, natural order;
 {r['ms']:.3f} ms per batch transform = **{r['frac']:.3f} of the 8 TB/s HBM specification**, HBM-side traffic 2.00 × the algorithmic bytes,
 vector-issue bound) through the direct passes of `csrc/ntt_direct.hip`; 2^22 in two passes in every order — natural forward 0.213,
-inverse 0.205, bit-reversed 0.217 of 8 TB/s against 0.19 / 0.18 / 0.20 for three passes (`profiles/r06_ntt_sizes.jsonl`); `from_values` of 2^20 rows x 135 columns (rate 8, cap height 4) in **{e['commit_ms']:.1f} ms** =
+inverse 0.205, bit-reversed 0.211 of 8 TB/s against 0.19 / 0.18 / 0.20 for three passes (`profiles/r06_ntt_sizes.jsonl`); `from_values` of 2^20 rows x 135 columns (rate 8, cap height 4) in **{e['commit_ms']:.1f} ms** =
 **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, 81 % of it Poseidon leaf hashing with the MDS layers on the matrix cores (`csrc/poseidon.h`: an i8
 product per byte plane), and 117–125 M leaves/s at 2^21–2^23 rows of the same width; `prove()` at the ed25519 proof's shape (n = 2^18,
 234 wires, the whole 25-gate table) in **{e['prove']['prove_ms']:.1f} ms** through the native `gl_prove` ({pl['2^20 rows']['prove_ms']:.0f} ms at 2^20 rows) — its transcript
