@@ -98,8 +98,108 @@ def analyse(d, proofs):
         print("  %-48s %6.1f %9.1f" % (b[:48], c / proofs, ns / proofs / 1e3))
 
 
+def run_in_flight(degree_bits, proofs, k):
+    """`k` host threads x own context x own circuit handle, `proofs` proofs each, after a warm-up and a 0.4 s pause (for `overlap`)"""
+    import threading
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+
+    import plonky2_gpu_amd as pg
+    import synth_circuit
+    from plonky2_gpu_amd.challenger import hash_no_pad
+
+    ctxs = [pg.Context(0) for _ in range(k)]
+    circuit, wires, pis = synth_circuit.make(degree_bits, num_wires=234, num_routed=80, num_constants=8, seed=1, gate_table="ed25519")
+    synth_circuit.set_public_input_row(wires, hash_no_pad(ctxs[0], pis))
+    ncs = [pg.NativeCircuit(c, dict(circuit, circuit_digest=None)) for c in ctxs]
+    bufs = [pg.DeviceBuffer.from_host(c, np.ascontiguousarray(wires)) for c in ctxs]
+    for i in range(k):
+        for _ in range(2):
+            ncs[i].prove_bytes(bufs[i], pis)
+        ctxs[i].synchronize()
+    time.sleep(0.4)
+
+    def work(i):
+        for _ in range(proofs):
+            ncs[i].prove_bytes(bufs[i], pis)
+        ctxs[i].synchronize()
+
+    t = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    print(json.dumps({"in_flight": k, "proofs": proofs * k, "ms_per_proof_wall_clock_under_the_profiler": (time.perf_counter() - t) / (proofs * k) * 1e3}))
+
+
+def overlap(d, proofs):
+    """Everything after the pause of a run_in_flight trace: per stream, the time its kernels run; the time kernels of at least two
+    different streams run at once; which kernels of one proof run beside which of the other."""
+    recs = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            recs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r["Stream_Id"]), int(r["Thread_Id"])))
+    recs.sort()
+    cut, end = 0, recs[0][1]
+    for i in range(1, len(recs)):
+        if recs[i][0] - end > 300e6:
+            cut = i
+        end = max(end, recs[i][1])
+    recs = recs[cut:]
+    t0, t1 = recs[0][0], max(r[1] for r in recs)
+    threads = sorted({r[4] for r in recs})
+    ev = []
+    for s_, e_, n, st, th in recs:
+        ev.append((s_, 1, th, n))
+        ev.append((e_, -1, th, n))
+    ev.sort()
+    active = {th: {} for th in threads}   # thread -> kernel name -> count running
+    last, any_busy, both_busy = t0, 0, 0
+    pair_ns = {}
+    for t, dlt, th, n in ev:
+        running = [x for x in threads if active[x]]
+        if running:
+            any_busy += t - last
+        if len(running) >= 2:
+            both_busy += t - last
+            a, b = (max(active[x], key=lambda k_: active[x][k_]) for x in running[:2])
+            key = tuple(sorted((a, b)))
+            pair_ns[key] = pair_ns.get(key, 0) + (t - last)
+        last = t
+        cnt = active[th].get(n, 0) + dlt
+        if cnt:
+            active[th][n] = cnt
+        else:
+            active[th].pop(n, None)
+    per_thread = {}
+    for th in threads:
+        iv = sorted((r[0], r[1]) for r in recs if r[4] == th)
+        busy, e = 0, iv[0][0]
+        for s_, e_ in iv:
+            if s_ > e:
+                busy += e_ - s_
+                e = e_
+            elif e_ > e:
+                busy += e_ - e
+                e = e_
+        per_thread[str(th)] = {"kernels": len(iv), "streams": len({r[3] for r in recs if r[4] == th}), "busy_ms": busy / 1e6}
+    print(json.dumps({"host_threads": len(threads), "proofs": proofs, "wall_ms": (t1 - t0) / 1e6, "ms_per_proof": (t1 - t0) / 1e6 / proofs,
+                      "device_busy_ms": any_busy / 1e6, "kernels_of_two_host_threads_running_at_once_ms": both_busy / 1e6,
+                      "frac_of_wall_with_both": both_busy / (t1 - t0), "per_host_thread": per_thread}))
+    print("what runs beside what (kernel of one proof | kernel of the other), ms")
+    for (a, b), ns in sorted(pair_ns.items(), key=lambda kv: -kv[1])[:25]:
+        print("  %-44s | %-44s %9.2f" % (a[:44], b[:44], ns / 1e6))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "run_in_flight":
+        run_in_flight(int(sys.argv[2]) if len(sys.argv) > 2 else 18, int(sys.argv[3]) if len(sys.argv) > 3 else 6, int(sys.argv[4]) if len(sys.argv) > 4 else 2)
+    elif sys.argv[1] == "overlap":
+        overlap(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 12)
+    elif sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 18, int(sys.argv[3]) if len(sys.argv) > 3 else 6)
     else:
         analyse(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 6)
