@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--prove-degree-bits", type=int, default=18)
     ap.add_argument("--prove-wires", type=int, default=234)
     ap.add_argument("--prove-reps", type=int, default=3)
-    ap.add_argument("--prove-in-flight", type=int, default=2, help="host threads, each with its own context and circuit, proving at the same time on one GPU for prove_proofs_per_s (0 = skip)")
+    ap.add_argument("--prove-in-flight", type=int, default=3, help="host threads, each with its own context and circuit, proving at the same time on one GPU for prove_proofs_per_s (0 = skip)")
     ap.add_argument("--prove-larger", default="19,20", help="further trace sizes (log2 rows) at which one proof of the same shape is timed, rank 0 at N = 1 ('' = none)")
     ap.add_argument("--commit-cols", type=int, default=135)
     ap.add_argument("--commit-log-n", type=int, default=20)

@@ -31,6 +31,7 @@ def main():
     pl, ref, st = e["prove_larger_traces"], e["reference_gpu_kernels_on_this_mi355x"], e["commit_stage_ms_one_at_a_time"]
     fl = e["prove_in_flight"]
     hk = e["commit_hash_kernel_counters"]
+    clock = (" at %.2f GHz" % hk["clock_GHz_during_kernel"]) if hk.get("clock_GHz_during_kernel") else ""
     s = open(P("DESIGN.md")).read()
     a = s.index("## 5. Measurement (one MI355X; `profiles/r0")
     b = s.index("`bench.py`: a step is `pairs_per_step` forward + inverse transforms")
@@ -38,8 +39,8 @@ def main():
 
 One table. The first column of values is `profiles/r06_bench.json` — ONE device, ONE `gpurun` call that also collected the kernel
 statistics and counters the line quotes (`tools/gpu_runs/r06_pmc_and_bench.sh`; `tests/test_bench_guard.py` ties this table to that
-file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 % and more (this call's device clocked {hk['clock_GHz_during_kernel']:.2f} GHz under the
-hashing kernel; one seen earlier in the round 2.03: 124.5 k NTT/s, 65.3 ms, 48.0 ms); the other call of this round, NTT/s / commit / prove: {"; ".join(other_devices())} —
+file, `tools/docs_from_bench.py` writes it). Devices of the pool differ by ±2.5 % and more (124.5–131.4 k NTT/s, 61.3–65.3 ms for the commit and 46.7–48.2 ms for a proof on
+the devices this round's calls landed on, clocking 2.03–2.08 GHz under the hashing kernel); the other call of this round, NTT/s / commit / prove: {"; ".join(other_devices())} —
 `profiles/r06_bench_first.json`. The second column is what the DRIVER measured at the end of round 5 (`BENCH_r05.json`) — the number on
 record; the NTT, LDE, hashing and gate kernels are unchanged since, what happens between them is not (§3.6, §4.1).
 
@@ -50,7 +51,7 @@ record; the NTT, LDE, hashing and gate kernels are unchanged since, what happens
 | the two kernels under rocprofv3 (same command) | column pass {col:.1f} µs + row pass {row:.1f} µs = {col+row:.1f} µs | (builder's r05 device: 279.0 + 224.5) | `profiles/r06_ntt_kernel_stats.csv` |
 | HBM-side traffic (FETCH_SIZE × 2 + WRITE_SIZE) | {r['traffic']/1e9:.3f} GB = **{r['traffic_over_algorithmic']:.2f} ×** algorithmic (the second pass) | same | `roofline.traffic`, `profiles/r06_pmc_summary.json` |
 | vector-issue estimate (VALU instructions × 4 cycles ÷ SIMDs ÷ kernel cycles); waves parked at `s_waitcnt` / barrier | `int_alu_frac` {r['int_alu_frac']:.2f}; 0.39 in both passes; LDS bank conflicts 0 | 0.71 | `roofline.int_alu_frac`, `profiles/r06_pmc_summary.json` |
-| commit configs[2] (135 × 2^20, rate 8, cap 4, leaf-major copy included) | **{e['commit_ms']:.1f} ms** → **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, {e['commit_hbm_frac']:.3f} of the HBM roofline; without the leaf-major copy {e['commit_ms_without_leaf_major_copy']:.1f}; stages one at a time: iNTT {st['ifft (values -> coefficients)']:.1f} + LDE {st['coset LDE (bit-reversed)']:.1f} + hashing and tree {st['leaf hashing + tree layers']:.1f} | 61.3 ms, 137 M (from the tail's speed-up × baseline) | `extra.commit_*`, top-level `commit_ms`, `merkle_leaves_per_s`, `commit_hbm_frac`; hashing kernel: {hk['valu_insts_per_wavefront']:.0f} vector + {hk['matrix_insts_per_wavefront']:.0f} matrix instructions per wavefront at {hk['clock_GHz_during_kernel']:.2f} GHz, issue estimate {hk['valu_issue_estimate_frac_of_cycles']:.2f} |
+| commit configs[2] (135 × 2^20, rate 8, cap 4, leaf-major copy included) | **{e['commit_ms']:.1f} ms** → **{e['merkle_leaves_per_s']/1e6:.0f} M leaves/s**, {e['commit_hbm_frac']:.3f} of the HBM roofline; without the leaf-major copy {e['commit_ms_without_leaf_major_copy']:.1f}; stages one at a time: iNTT {st['ifft (values -> coefficients)']:.1f} + LDE {st['coset LDE (bit-reversed)']:.1f} + hashing and tree {st['leaf hashing + tree layers']:.1f} | 61.3 ms, 137 M (from the tail's speed-up × baseline) | `extra.commit_*`, top-level `commit_ms`, `merkle_leaves_per_s`, `commit_hbm_frac`; hashing kernel: {hk['valu_insts_per_wavefront']:.0f} vector + {hk['matrix_insts_per_wavefront']:.0f} matrix instructions per wavefront{clock}, issue estimate {hk['valu_issue_estimate_frac_of_cycles']:.2f} |
 | full-width commits at north_star's trace sizes (135 columns; round 5, kernels unchanged; a device on which 2^20 takes 64.4 ms) | 2^21 133.8 ms, 2^22 280.8 ms, 2^23 574.1 ms = 125 / 119 / 117 M leaves/s, 0.020 / 0.019 / 0.019 (LDE 18 / 36 / 72 GB) | — | `profiles/r05_sweep.jsonl` |
 | `prove()` at the ed25519 shape (n = 2^18, 234 wires, whole gate table), one proof at a time | **{e['prove']['prove_ms']:.1f} ms** per proof = {1e3/e['prove']['prove_ms']:.1f} proofs/s (wires commitment {e['prove']['stage_ms']['wires commitment']:.1f}, quotient {e['prove']['stage_ms']['quotient polys']:.1f}) | 47.8 ms (from the tail) | top-level `prove_ms`, `extra.prove`; 47.0 ms on the faster devices of this round (`profiles/r06_bench_prove.json`), 48.9 before the device-resident transcript |
 | the same with **{fl['in_flight']} proofs in flight** (host threads × own context × own circuit handle) | **{fl['proofs_per_s']:.1f} proofs/s** = {fl['ms_per_proof']:.1f} ms per proof, {fl['proofs_per_s']*e['prove']['prove_ms']/1e3:.2f} × one at a time; every proof byte-equal to the one made alone | — (contexts took turns) | top-level `prove_proofs_per_s_in_flight`, `extra.prove_in_flight`; 23.4 (1.15 ×) with two, 24.0 (1.18 ×) with three on another device: `profiles/r06_inflight.json` |
