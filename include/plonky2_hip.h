@@ -456,8 +456,12 @@ typedef struct GlCircuitDesc {
 GlError gl_circuit_create(const GlCircuitDesc *desc, void **circuit, void *ctx);
 void gl_circuit_destroy(void *circuit);
 /* gl_prove recycles its working buffers from proof to proof of the same circuit (one proof's worth of
- * HBM stays attached to the circuit: ~10 GB at n = 2^18 with 234 wires). gl_circuit_trim releases them
- * without destroying the circuit; the next proof allocates again. Call it only between proofs. */
+ * HBM stays attached to the circuit PER CONTEXT that proves with it: ~10 GB at n = 2^18 with 234 wires, plus a
+ * page-locked staging buffer of a few hundred KiB for what travels between host and device). gl_circuit_trim
+ * releases them without destroying the circuit; the next proof allocates again. Call it only between proofs.
+ * Since 0.6 the proof's transcript lives in device memory (gl_challenger_step): gl_prove synchronises with the
+ * device where the HOST computes with a challenge (betas / gammas, alphas, zeta, the FRI alpha), for the
+ * proof-of-work witness, and once for everything that goes into the proof bytes. */
 GlError gl_circuit_trim(void *circuit);
 /* circuit digest (4) and constants_sigmas cap (4 << cap_height): what VerifierOnlyCircuitData holds */
 GlError gl_circuit_info(const void *circuit, uint64_t *h_digest, uint64_t *h_constants_sigmas_cap);
